@@ -1,0 +1,54 @@
+"""Build libdeepcut_hip.so (HIP kernels + C-ABI) for gfx950, in-tree.
+
+    python deepcut-cnn_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container; the
+resulting .so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libdeepcut_hip.so")
+SOURCES = ["formats.cpp", "net.cpp", "c_api.cpp", "kernels.hip"]
+HEADERS = ["formats.h", "net.h", "kernels.h", os.path.join("..", "..", "include", "deepcut_hip.h")]
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for f in SOURCES + HEADERS:
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return False
+
+
+def build_lib(force=False, verbose=True):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, "lib", src + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

@@ -1,0 +1,306 @@
+// c_api.cpp — the extern "C" boundary declared in include/deepcut_hip.h.  No C++ exception and no
+// C++ type crosses it.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/deepcut_hip.h"
+#include "net.h"
+
+using namespace dc;
+
+// dc_net* / dc_blob* are dc::Net* / dc::NetBlob* behind opaque C names
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+template <typename F>
+int guard(F&& f) {
+  try {
+    f();
+    return DC_OK;
+  } catch (const DcError& e) {
+    return fail(e.code, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(DC_EDEVICE, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(DC_EINVAL, e.what());
+  }
+}
+inline Net* N(dc_net* n) { return reinterpret_cast<Net*>(n); }
+inline NetBlob* B(dc_blob* b) { return reinterpret_cast<NetBlob*>(b); }
+#define REQUIRE(p)                                                   \
+  if (!(p)) return fail(DC_EINVAL, "null argument: " #p)
+}  // namespace
+
+extern "C" {
+
+const char* dc_last_error(void) { return g_err.c_str(); }
+const char* dc_version(void) { return "deepcut_hip 0.1 (gfx950)"; }
+
+int dc_set_mode(int mode) {
+  if (mode != DC_MODE_CPU && mode != DC_MODE_GPU) return fail(DC_EINVAL, "mode must be DC_MODE_CPU or DC_MODE_GPU");
+  Context::get().mode = mode;
+  return DC_OK;
+}
+int dc_get_mode(void) { return Context::get().mode; }
+int dc_set_device(int id) {
+  int n = device_count();
+  if (id < 0 || (n > 0 && id >= n))
+    return fail(DC_EDEVICE, "device " + std::to_string(id) + " out of range (" + std::to_string(n) + " visible)");
+  Context::get().device = id;
+  if (n > 0 && hipSetDevice(id) != hipSuccess) return fail(DC_EDEVICE, "hipSetDevice failed");
+  return DC_OK;
+}
+int dc_get_device(void) { return Context::get().device; }
+int dc_device_count(void) { return device_count(); }
+
+int dc_net_create_from_text(const char* text, const char* model, int phase, dc_net** out) {
+  REQUIRE(text);
+  REQUIRE(out);
+  *out = nullptr;
+  return guard([&] {
+    std::unique_ptr<Net> n(Net::create(text, phase));
+    if (model && *model) n->copy_from(model);
+    *out = reinterpret_cast<dc_net*>(n.release());
+  });
+}
+int dc_net_create(const char* proto, const char* model, int phase, dc_net** out) {
+  REQUIRE(proto);
+  REQUIRE(out);
+  *out = nullptr;
+  return guard([&] {
+    std::string text = read_file(proto);
+    if (model && *model) {  // CheckFile (_caffe.cpp:45-52): fail before building the net
+      FILE* f = std::fopen(model, "rb");
+      if (!f) throw DcError(DC_EIO, std::string("Could not open file ") + model);
+      std::fclose(f);
+    }
+    std::unique_ptr<Net> n(Net::create(text, phase));
+    if (model && *model) n->copy_from(model);
+    *out = reinterpret_cast<dc_net*>(n.release());
+  });
+}
+int dc_net_destroy(dc_net* net) {
+  if (net) delete N(net);
+  return DC_OK;
+}
+int dc_net_set_option(dc_net* net, int key, int value) {
+  REQUIRE(net);
+  return guard([&] {
+    Net* n = N(net);
+    if (key == DC_OPT_FUSE) {
+      if (n->fuse != value) n->plan_valid = false;
+      n->fuse = value;
+    } else if (key == DC_OPT_HIPGRAPH) {
+      n->use_graph = value;
+    } else {
+      throw DcError(DC_EINVAL, "unknown option " + std::to_string(key));
+    }
+  });
+}
+int dc_net_copy_from(dc_net* net, const char* path) {
+  REQUIRE(net);
+  REQUIRE(path);
+  return guard([&] { N(net)->copy_from(path); });
+}
+int dc_net_save(dc_net* net, const char* path) {
+  REQUIRE(net);
+  REQUIRE(path);
+  return guard([&] { N(net)->save(path); });
+}
+const char* dc_net_name(dc_net* net) { return net ? N(net)->name.c_str() : ""; }
+
+int dc_net_num_layers(dc_net* net) { return net ? (int)N(net)->layers.size() : 0; }
+const char* dc_net_layer_name(dc_net* net, int i) {
+  if (!net || i < 0 || i >= (int)N(net)->layers.size()) return nullptr;
+  return N(net)->layers[i].name.c_str();
+}
+const char* dc_net_layer_type(dc_net* net, int i) {
+  if (!net || i < 0 || i >= (int)N(net)->layers.size()) return nullptr;
+  return N(net)->layers[i].type.c_str();
+}
+int dc_net_num_blobs(dc_net* net) { return net ? (int)N(net)->blobs.size() : 0; }
+const char* dc_net_blob_name(dc_net* net, int i) {
+  if (!net || i < 0 || i >= (int)N(net)->blobs.size()) return nullptr;
+  return N(net)->blobs[i]->name.c_str();
+}
+int dc_net_blob(dc_net* net, const char* name, dc_blob** out) {
+  REQUIRE(net);
+  REQUIRE(name);
+  REQUIRE(out);
+  auto it = N(net)->blob_index.find(name);
+  if (it == N(net)->blob_index.end()) return fail(DC_EINVAL, std::string("Unknown blob name ") + name);
+  *out = reinterpret_cast<dc_blob*>(N(net)->blobs[it->second].get());
+  return DC_OK;
+}
+int dc_net_num_inputs(dc_net* net) { return net ? (int)N(net)->inputs.size() : 0; }
+const char* dc_net_input_name(dc_net* net, int i) {
+  if (!net || i < 0 || i >= (int)N(net)->inputs.size()) return nullptr;
+  return N(net)->blobs[N(net)->inputs[i]]->name.c_str();
+}
+int dc_net_num_outputs(dc_net* net) { return net ? (int)N(net)->outputs.size() : 0; }
+const char* dc_net_output_name(dc_net* net, int i) {
+  if (!net || i < 0 || i >= (int)N(net)->outputs.size()) return nullptr;
+  return N(net)->blobs[N(net)->outputs[i]]->name.c_str();
+}
+int dc_net_layer_num_params(dc_net* net, const char* layer) {
+  if (!net || !layer) return 0;
+  int li = N(net)->layer_index(layer);
+  return li < 0 ? 0 : (int)N(net)->layers[li].params.size();
+}
+int dc_net_param(dc_net* net, const char* layer, int idx, dc_blob** out) {
+  REQUIRE(net);
+  REQUIRE(layer);
+  REQUIRE(out);
+  int li = N(net)->layer_index(layer);
+  if (li < 0) return fail(DC_EINVAL, std::string("Unknown layer name ") + layer);
+  auto& ps = N(net)->layers[li].params;
+  if (idx < 0 || idx >= (int)ps.size()) return fail(DC_EINVAL, "param index out of range");
+  *out = reinterpret_cast<dc_blob*>(ps[idx].get());
+  return DC_OK;
+}
+
+int dc_net_reshape(dc_net* net) {
+  REQUIRE(net);
+  return guard([&] { N(net)->reshape(); });
+}
+int dc_net_forward(dc_net* net, int start, int end, float* loss) {
+  REQUIRE(net);
+  if (loss) *loss = 0.f;
+  int nl = (int)N(net)->layers.size();
+  if (start < 0 || end >= nl || start > end + 1)
+    return fail(DC_EINVAL, "forward range out of bounds (net.cpp:566-567)");
+  return guard([&] { N(net)->forward(start, end); });
+}
+int dc_net_forward_all(dc_net* net) {
+  REQUIRE(net);
+  return guard([&] { N(net)->forward(0, (int)N(net)->layers.size() - 1); });
+}
+
+int dc_blob_num_axes(dc_blob* b) { return b ? (int)B(b)->st->shape.size() : 0; }
+int dc_blob_shape(dc_blob* b, int* ndim, int* dims) {
+  REQUIRE(b);
+  REQUIRE(ndim);
+  REQUIRE(dims);
+  auto& s = B(b)->st->shape;
+  if (s.size() > 8) return fail(DC_EINVAL, "too many axes");
+  *ndim = (int)s.size();
+  for (size_t i = 0; i < s.size(); ++i) dims[i] = s[i];
+  return DC_OK;
+}
+int dc_blob_count(dc_blob* b) { return b ? (int)B(b)->st->count() : 0; }
+int dc_blob_reshape(dc_blob* b, int ndim, const int* dims) {
+  REQUIRE(b);
+  REQUIRE(dims);
+  if (ndim < 0 || ndim > 8) return fail(DC_EINVAL, "bad number of axes");
+  return guard([&] {
+    Storage& s = *B(b)->st;
+    if (s.is_param) throw DcError(DC_EINVAL, "parameter blobs cannot be reshaped");
+    s.reshape(std::vector<int>(dims, dims + ndim));
+  });
+}
+static int blob_host(dc_blob* b, float** out, bool mut) {
+  return guard([&] {
+    Storage& s = *B(b)->st;
+    if (s.elided && !s.is_param)
+      throw DcError(DC_EUNSUP, "blob '" + B(b)->name + "' is folded into a fused kernel in the current plan and never "
+                                "materialised; create the net with DC_OPT_FUSE 0 to observe it");
+    if (s.head == HEAD_AT_GPU) {
+      if (!s.owner) throw DcError(DC_EINVAL, "orphan blob");
+      s.owner->sync_to_host(s);
+    }
+    *out = s.host_ptr();
+    if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
+    if (mut) {
+      s.head = HEAD_AT_CPU;
+      if (s.is_param && s.owner) s.owner->weights_dirty = true;
+    }
+  });
+}
+int dc_blob_cpu_data(dc_blob* b, const float** out) {
+  REQUIRE(b);
+  REQUIRE(out);
+  float* p = nullptr;
+  int r = blob_host(b, &p, false);
+  *out = p;
+  return r;
+}
+int dc_blob_mutable_cpu_data(dc_blob* b, float** out) {
+  REQUIRE(b);
+  REQUIRE(out);
+  return blob_host(b, out, true);
+}
+int dc_blob_head(dc_blob* b) { return b ? B(b)->st->head : 0; }
+int dc_blob_gpu_data(dc_blob* b, const void** dev, int* pitch) {
+  REQUIRE(b);
+  REQUIRE(dev);
+  return guard([&] {
+    Storage& s = *B(b)->st;
+    if (s.is_param) throw DcError(DC_EUNSUP, "parameters are packed per kernel on the device; no NHWC image exists");
+    if (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED) {
+      if (!s.owner) throw DcError(DC_EINVAL, "orphan blob");
+      s.owner->sync_to_device(s);
+    }
+    *dev = s.dev;
+    if (pitch) *pitch = s.cp();
+  });
+}
+
+int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device, float* prob,
+                         float* loc_pred, float* next_pred, void* stream) {
+  REQUIRE(net);
+  REQUIRE(input);
+  if (n <= 0 || h <= 0 || w <= 0) return fail(DC_EINVAL, "bad batch shape");
+  return guard([&] { N(net)->forward_batch(input, n, h, w, is_device != 0, prob, loc_pred, next_pred, stream); });
+}
+
+int dc_net_flops(dc_net* net, double* flops) {
+  REQUIRE(net);
+  REQUIRE(flops);
+  return guard([&] {
+    Net* n = N(net);
+    n->reshape();
+    std::vector<int> sig;
+    for (int bi : n->inputs)
+      for (int d : n->blobs[bi]->st->shape) sig.push_back(d);
+    if (!n->plan_valid || sig != n->plan_input_shape) n->build_plan();
+    *flops = n->plan_flops;
+  });
+}
+int dc_net_num_launches(dc_net* net) {
+  if (!net) return 0;
+  int r = 0;
+  guard([&] {
+    N(net)->plan_text();
+    r = (int)N(net)->plan.size();
+  });
+  return r;
+}
+const char* dc_net_plan_text(dc_net* net) {
+  if (!net) return nullptr;
+  Net* n = N(net);
+  int rc = guard([&] {
+    n->reshape();
+    std::vector<int> sig;
+    for (int bi : n->inputs)
+      for (int d : n->blobs[bi]->st->shape) sig.push_back(d);
+    if (!n->plan_valid || sig != n->plan_input_shape) n->build_plan();
+    n->text_buf = n->plan_text();
+  });
+  return rc == DC_OK ? n->text_buf.c_str() : nullptr;
+}
+const char* dc_net_profile_text(dc_net* net, int iters) {
+  if (!net) return nullptr;
+  Net* n = N(net);
+  int rc = guard([&] { n->text_buf = n->profile_text(iters > 0 ? iters : 10); });
+  return rc == DC_OK ? n->text_buf.c_str() : nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// kernels.h — launch interface of the gfx950 kernels (kernels.hip).  Plain structs, no HIP types
+// in the signatures except the opaque stream, so net.cpp stays host-only C++.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace dc {
+
+// One K-segment of the gather-GEMM: `klen` consecutive floats of the source row
+// (oy*sy + dy), starting at element (ox*sx + xoff); klen % 32 == 0.
+struct ConvTap {
+  int dy;
+  int xoff;
+  int klen;
+  int pad_;
+};
+
+constexpr int kMaxTaps = 49;
+
+// out[pixel][co] = act( (sum_k A[pixel][k] * W[co][k]) * scale[co] + shift[co] (+ resid[pixel][co]) )
+//   pixel = (n, oy, ox) over an NB x OH x OW grid,
+//   A[pixel][.] = concatenation over taps of  x[n][oy*sy+dy][ox*sx+xoff .. +klen)   (0 outside the row/image),
+//   W packed [Cout][Ktot] with k contiguous (Ktot = sum klen).
+// Covers every Convolution of the path (1x1, 1x1 stride 2, 3x3, dilated 3x3, the 7x7 stem seen as
+// 7 row-taps of 8 NHWC4 pixels) and, per output-parity class, the stride-2 Deconvolution heads.
+struct ConvGemmParams {
+  const float* x;
+  long x_img_stride;  // elements between images
+  int x_row_stride;   // elements between rows
+  int x_rows;         // H of the source
+  int x_rowlen;       // valid elements in a row (W*C)
+  int sy, sx;         // source step per output pixel: rows / elements
+  int ntaps;
+  ConvTap taps[kMaxTaps];
+  const float* w;
+  int Ktot;
+  int NB, OH, OW;
+  int M;  // NB*OH*OW
+  int Cout;
+  float* y;  // pre-offset to the first output element of this launch
+  long y_img_stride;
+  int y_row_stride;  // elements per oy step
+  int y_pix_stride;  // elements per ox step
+  const float* resid;  // same addressing as y (may alias y), or null
+  const float* scale;  // [Cout] or null (=1)
+  const float* shift;  // [Cout] or null (=0)
+  int relu;
+  int sigmoid_ch;  // channels [0, sigmoid_ch) get the logistic
+};
+
+// Tile variants of conv_gemm.  BM x BN output tile per 256-thread workgroup, 4 waves arranged
+// WR x WC x WK (WK = waves splitting the K range of the same output tile, reduced through LDS).
+struct ConvVariant {
+  const char* name;
+  int BM, BN, WR, WC, WK;
+};
+int conv_num_variants();
+const ConvVariant& conv_variant(int i);
+// workgroups this variant launches for the problem
+int conv_variant_bk(int i);
+long conv_grid(const ConvGemmParams& p, int variant);
+// returns hipError_t as int
+int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream);
+
+// MAX pooling, NHWC, windows clipped to the image (pooling_layer.cpp:140-187).
+int launch_maxpool(const float* x, float* y, int NB, int H, int W, int C, int OH, int OW, int k, int s,
+                   int pad, void* stream);
+
+// y = act(x*a[c] + b[c] + z)   (a,b,z optional) — the stand-alone BatchNorm/Scale/ReLU/Eltwise/Sigmoid
+// layers when they are not folded into a producing convolution.
+int launch_eltwise(const float* x, const float* z, const float* a, const float* b, float* y, long total,
+                   int C, int relu, int sigmoid, void* stream);
+
+// crop the top-left (offset oh,ow) OH x OW window of an NHWC tensor (crop_layer.cpp:37-50)
+int launch_crop(const float* x, float* y, int NB, int H, int W, int C, int oh, int ow, int OH, int OW,
+                void* stream);
+
+// layout changes at the Blob boundary (host side is NCHW, blob.hpp:153-164)
+// src NCHW [NB,C,H,W] -> dst NHWC with channel pitch CP (>= C, extra channels zeroed)
+int launch_nchw_to_nhwc(const float* src, float* dst, int NB, int C, int H, int W, int CP, void* stream);
+// src NHWC pitch CP, channels [c0, c0+C) -> dst NCHW [NB,C,H,W]
+int launch_nhwc_to_nchw(const float* src, float* dst, int NB, int C, int H, int W, int CP, int c0,
+                        void* stream);
+
+}  // namespace dc

@@ -1,0 +1,1327 @@
+// net.cpp — see net.h.  Host-side graph runtime: parse, InsertSplits, shape inference, weight
+// loading, lowering to a fused launch plan, and execution on one HIP stream.
+#include "net.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <sstream>
+
+#include "../../include/deepcut_hip.h"
+
+namespace dc {
+
+#define HIPCHECK(expr)                                                                               \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      throw DcError(DC_EDEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));           \
+  } while (0)
+#define KCHECK(expr)                                                                                 \
+  do {                                                                                               \
+    int e_ = (expr);                                                                                 \
+    if (e_ != 0)                                                                                     \
+      throw DcError(DC_EDEVICE, std::string(#expr) + " failed: " + hipGetErrorString((hipError_t)e_)); \
+  } while (0)
+
+// ---- context ------------------------------------------------------------------------------------
+Context& Context::get() {
+  static thread_local Context c;
+  return c;
+}
+int device_count() {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  (void)hipGetLastError();
+  cached = n;
+  return n;
+}
+
+// ---- Storage ------------------------------------------------------------------------------------
+Storage::~Storage() {
+  if (host) {
+    if (host_pinned) (void)hipHostFree(host);
+    else std::free(host);
+  }
+  if (dev) (void)hipFree(dev);
+  if (stage) (void)hipFree(stage);
+}
+size_t Storage::count() const {
+  size_t c = 1;
+  for (int d : shape) c *= (size_t)d;
+  return c;
+}
+int Storage::cp() const {
+  int c = dim(1);
+  return pad4 ? (c + 3) / 4 * 4 : c;
+}
+size_t Storage::dev_count() const { return (size_t)dim(0) * dim(2) * dim(3) * cp(); }
+void Storage::reshape(const std::vector<int>& s) {
+  for (int d : s)
+    if (d < 0) throw DcError(DC_ESHAPE, "negative blob dimension");
+  shape = s;
+  if (count() > host_cap && host) {
+    // Blob::Reshape replaces the SyncedMemory when capacity grows (blob.cpp:37-41)
+    if (host_pinned) (void)hipHostFree(host);
+    else std::free(host);
+    host = nullptr;
+    host_cap = 0;
+    head = UNINITIALIZED;
+  }
+}
+float* Storage::host_ptr() {
+  size_t n = std::max<size_t>(count(), 1);
+  if (!host) {
+    host_pinned = false;
+    if (device_count() > 0 && !is_param) {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, n * sizeof(float), hipHostMallocDefault) == hipSuccess) {
+        host = (float*)p;
+        host_pinned = true;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    if (!host) host = (float*)std::malloc(n * sizeof(float));
+    if (!host) throw DcError(DC_EDEVICE, "out of host memory");
+    std::memset(host, 0, n * sizeof(float));
+    host_cap = n;
+  }
+  return host;
+}
+void Storage::ensure_dev(size_t n) {
+  if (n <= dev_cap && dev) return;
+  if (dev) HIPCHECK(hipFree(dev));
+  dev = nullptr;
+  HIPCHECK(hipMalloc((void**)&dev, std::max<size_t>(n, 4) * sizeof(float)));
+  HIPCHECK(hipMemset(dev, 0, std::max<size_t>(n, 4) * sizeof(float)));  // pitch-padding channels stay 0
+  dev_cap = n;
+}
+void Storage::ensure_stage(size_t n) {
+  if (n <= stage_cap && stage) return;
+  if (stage) HIPCHECK(hipFree(stage));
+  stage = nullptr;
+  HIPCHECK(hipMalloc((void**)&stage, std::max<size_t>(n, 4) * sizeof(float)));
+  stage_cap = n;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------
+namespace {
+std::string split_layer_name(const std::string& layer, const std::string& blob, int idx) {
+  return blob + "_" + layer + "_" + std::to_string(idx) + "_split";  // insert_splits.cpp:127-133
+}
+std::string split_blob_name(const std::string& layer, const std::string& blob, int idx, int k) {
+  return split_layer_name(layer, blob, idx) + "_" + std::to_string(k);  // insert_splits.cpp:135-141
+}
+
+struct RawLayer {
+  std::string name, type;
+  std::vector<std::string> bottoms, tops;
+  TextMsg def;
+  bool is_split = false;
+};
+
+bool phase_included(const TextMsg& l, int phase) {
+  // NetStateRule with a phase only (net.cpp:286-327).  Other rule kinds are not on this path.
+  auto phase_of = [](const std::string& s) { return (s == "TEST" || s == "1") ? 1 : 0; };
+  auto inc = l.subs("include"), exc = l.subs("exclude");
+  if (!inc.empty()) {
+    for (auto* r : inc)
+      if (!r->has("phase") || phase_of(r->str("phase")) == phase) return true;
+    return false;
+  }
+  for (auto* r : exc)
+    if (r->has("phase") && phase_of(r->str("phase")) == phase) return false;
+  return true;
+}
+
+// InsertSplits (src/caffe/util/insert_splits.cpp:12-101), loss weights ignored (none on this path)
+std::vector<RawLayer> insert_splits(const std::vector<std::string>& inputs, const std::vector<RawLayer>& in) {
+  typedef std::pair<int, int> P;
+  std::map<std::string, P> last_top;
+  std::map<P, P> bottom_src;
+  std::map<P, int> top_count, split_idx;
+  for (int i = 0; i < (int)inputs.size(); ++i) last_top[inputs[i]] = P(-1, i);
+  for (int i = 0; i < (int)in.size(); ++i) {
+    for (int j = 0; j < (int)in[i].bottoms.size(); ++j) {
+      auto it = last_top.find(in[i].bottoms[j]);
+      if (it == last_top.end())
+        throw DcError(DC_EINVAL, "Unknown bottom blob '" + in[i].bottoms[j] + "' (layer '" + in[i].name +
+                                     "', bottom index " + std::to_string(j) + ")");
+      bottom_src[P(i, j)] = it->second;
+      ++top_count[it->second];
+    }
+    for (int j = 0; j < (int)in[i].tops.size(); ++j) last_top[in[i].tops[j]] = P(i, j);
+  }
+  auto lname = [&](int i) { return i < 0 ? std::string("input") : in[i].name; };
+  auto make_split = [&](const std::string& layer, const std::string& blob, int idx, int n) {
+    RawLayer s;
+    s.name = split_layer_name(layer, blob, idx);
+    s.type = "Split";
+    s.is_split = true;
+    s.bottoms.push_back(blob);
+    for (int k = 0; k < n; ++k) s.tops.push_back(split_blob_name(layer, blob, idx, k));
+    return s;
+  };
+  std::vector<RawLayer> out;
+  for (int i = 0; i < (int)inputs.size(); ++i)
+    if (top_count[P(-1, i)] > 1) out.push_back(make_split("input", inputs[i], i, top_count[P(-1, i)]));
+  for (int i = 0; i < (int)in.size(); ++i) {
+    RawLayer l = in[i];
+    for (int j = 0; j < (int)l.bottoms.size(); ++j) {
+      P src = bottom_src[P(i, j)];
+      if (top_count[src] > 1) l.bottoms[j] = split_blob_name(lname(src.first), l.bottoms[j], src.second, split_idx[src]++);
+    }
+    out.push_back(l);
+    for (int j = 0; j < (int)l.tops.size(); ++j)
+      if (top_count[P(i, j)] > 1) out.push_back(make_split(l.name, l.tops[j], j, top_count[P(i, j)]));
+  }
+  return out;
+}
+
+int pair_or(const TextMsg* m, const char* rep, const char* single, int idx, int def) {
+  // ConvolutionParameter: repeated kernel_size/stride/pad/dilation or the _h/_w form
+  // (base_conv_layer.cpp:23-99)
+  if (!m) return def;
+  if (m->has(single)) return (int)m->num(single, def);
+  auto v = m->nums(rep);
+  if (v.empty()) return def;
+  return (int)(v.size() == 1 ? v[0] : v[std::min<size_t>(idx, v.size() - 1)]);
+}
+}  // namespace
+
+// ---- Net: construction ----------------------------------------------------------------------------
+Net::~Net() {
+  release_graph();
+  for (auto& v : vecs)
+    if (v.dev) (void)hipFree(v.dev);
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+Net* Net::create(const std::string& text, int phase) {
+  std::unique_ptr<Net> n(new Net());
+  n->phase = phase;
+  TextMsg root = parse_text_proto(text);
+  n->init_from(root);
+  return n.release();
+}
+
+int Net::layer_index(const std::string& nm) const {
+  for (int i = 0; i < (int)layers.size(); ++i)
+    if (layers[i].name == nm) return i;
+  return -1;
+}
+
+void Net::init_from(const TextMsg& root) {
+  name = root.str("name");
+  if (!root.subs("layers").empty())
+    throw DcError(DC_EUNSUP, "prototxt uses the deprecated V1 'layers' field; upgrade it (upgrade_net_proto_text)");
+  std::vector<std::string> in_names = root.strs("input");
+  std::vector<std::vector<int>> in_shapes;
+  {
+    auto dims = root.nums("input_dim");
+    auto shapes = root.subs("input_shape");
+    if (!shapes.empty()) {
+      for (auto* s : shapes) {
+        std::vector<int> d;
+        for (double v : s->nums("dim")) d.push_back((int)v);
+        in_shapes.push_back(d);
+      }
+    } else {
+      if (dims.size() != 4 * in_names.size())
+        throw DcError(DC_EINVAL, "input_dim count must be 4 per input (net.cpp:84-90)");
+      for (size_t i = 0; i < in_names.size(); ++i)
+        in_shapes.push_back({(int)dims[4 * i], (int)dims[4 * i + 1], (int)dims[4 * i + 2], (int)dims[4 * i + 3]});
+    }
+    if (in_shapes.size() != in_names.size()) throw DcError(DC_EINVAL, "one input_shape per input required");
+  }
+  std::vector<RawLayer> raw;
+  for (auto* l : root.subs("layer")) {
+    if (!phase_included(*l, phase)) continue;
+    RawLayer r;
+    r.name = l->str("name");
+    r.type = l->str("type");
+    r.bottoms = l->strs("bottom");
+    r.tops = l->strs("top");
+    r.def = *l;
+    raw.push_back(std::move(r));
+  }
+  std::vector<RawLayer> full = insert_splits(in_names, raw);
+
+  std::set<std::string> available;
+  auto new_blob = [&](const std::string& nm, std::shared_ptr<Storage> st) {
+    auto b = std::make_shared<NetBlob>();
+    b->name = nm;
+    if (!st) {
+      st = std::make_shared<Storage>();
+      st->id = (int)storages.size();
+      st->owner = this;
+      storages.push_back(st);
+    }
+    b->st = st;
+    blob_index[nm] = (int)blobs.size();
+    blobs.push_back(b);
+    return (int)blobs.size() - 1;
+  };
+  for (size_t i = 0; i < in_names.size(); ++i) {
+    if (blob_index.count(in_names[i])) throw DcError(DC_EINVAL, "duplicate input '" + in_names[i] + "'");
+    int bi = new_blob(in_names[i], nullptr);
+    blobs[bi]->st->reshape(in_shapes[i]);
+    inputs.push_back(bi);
+    available.insert(in_names[i]);
+  }
+  for (auto& r : full) {
+    LayerRec L;
+    L.name = r.name;
+    L.type = r.type;
+    L.def = r.def;
+    L.is_split = r.is_split;
+    for (size_t j = 0; j < r.bottoms.size(); ++j) {  // Net::AppendBottom (net.cpp:440-467)
+      auto it = blob_index.find(r.bottoms[j]);
+      if (it == blob_index.end() || !available.count(r.bottoms[j]))
+        throw DcError(DC_EINVAL, "Unknown bottom blob '" + r.bottoms[j] + "' (layer '" + r.name +
+                                     "', bottom index " + std::to_string(j) + ")");
+      L.bottoms.push_back(it->second);
+      available.erase(r.bottoms[j]);
+    }
+    for (size_t j = 0; j < r.tops.size(); ++j) {  // Net::AppendTop (net.cpp:384-437)
+      const std::string& tn = r.tops[j];
+      if (j < r.bottoms.size() && tn == r.bottoms[j]) {
+        L.tops.push_back(blob_index[tn]);  // in-place: same Blob
+      } else if (blob_index.count(tn)) {
+        throw DcError(DC_EINVAL, "Top blob '" + tn + "' produced by multiple sources.");
+      } else if (r.is_split) {
+        L.tops.push_back(new_blob(tn, blobs[L.bottoms[0]]->st));  // SplitLayer: ShareData (split_layer.cpp:26-31)
+      } else {
+        L.tops.push_back(new_blob(tn, nullptr));
+      }
+      available.insert(tn);
+    }
+    layers.push_back(std::move(L));
+    setup_layer(layers.back());
+    reshape_layer(layers.back());
+  }
+  for (auto& nm : available) outputs.push_back(blob_index[nm]);  // std::set order = alphabetical (net.cpp:268-273)
+}
+
+void Net::setup_layer(LayerRec& L) {
+  const std::string& t = L.type;
+  auto st_of = [&](int bi) -> Storage& { return *blobs[bi]->st; };
+  auto add_param = [&](std::vector<int> shape, float fill) {
+    auto b = std::make_shared<NetBlob>();
+    b->name = L.name;
+    b->st = std::make_shared<Storage>();
+    b->st->is_param = true;
+    b->st->owner = this;
+    b->st->reshape(shape);
+    float* p = b->st->host_ptr();
+    size_t n = b->st->count();
+    for (size_t i = 0; i < n; ++i) p[i] = fill;
+    b->st->head = HEAD_AT_CPU;
+    L.params.push_back(b);
+  };
+  auto need = [&](size_t nb, size_t nt) {
+    if (L.bottoms.size() != nb || L.tops.size() != nt)
+      throw DcError(DC_EINVAL, "layer '" + L.name + "' (" + t + ") needs " + std::to_string(nb) + " bottom(s) and " +
+                                   std::to_string(nt) + " top(s)");
+  };
+  if (L.is_split) return;
+  if (t == "Convolution" || t == "Deconvolution") {
+    need(1, 1);
+    const TextMsg* cp = L.def.sub("convolution_param");
+    if (!cp) throw DcError(DC_EINVAL, "layer '" + L.name + "': convolution_param missing");
+    ConvSpec& c = L.conv;
+    c.num_output = (int)cp->num("num_output", 0);
+    c.kh = pair_or(cp, "kernel_size", "kernel_h", 0, 0);
+    c.kw = pair_or(cp, "kernel_size", "kernel_w", 1, 0);
+    c.sh = pair_or(cp, "stride", "stride_h", 0, 1);
+    c.sw = pair_or(cp, "stride", "stride_w", 1, 1);
+    c.ph = pair_or(cp, "pad", "pad_h", 0, 0);
+    c.pw = pair_or(cp, "pad", "pad_w", 1, 0);
+    c.dh = pair_or(cp, "dilation", "", 0, 1);
+    c.dw = pair_or(cp, "dilation", "", 1, 1);
+    c.group = (int)cp->num("group", 1);
+    c.bias = cp->boolean("bias_term", true);
+    if (c.num_output <= 0 || c.kh <= 0 || c.kw <= 0 || c.sh <= 0 || c.sw <= 0 || c.dh <= 0 || c.dw <= 0)
+      throw DcError(DC_EINVAL, "layer '" + L.name + "': bad convolution_param");
+    if (c.group != 1) throw DcError(DC_EUNSUP, "layer '" + L.name + "': group != 1 is outside the DeeperCut path");
+    int cin = st_of(L.bottoms[0]).dim(1);
+    if (t == "Convolution") add_param({c.num_output, cin, c.kh, c.kw}, 0.f);
+    else add_param({cin, c.num_output, c.kh, c.kw}, 0.f);  // reverse_dimensions (base_conv_layer.cpp:125-140)
+    if (c.bias) add_param({c.num_output}, 0.f);
+  } else if (t == "BatchNorm") {
+    need(1, 1);
+    const TextMsg* bp = L.def.sub("batch_norm_param");
+    bool ugs = bp ? bp->boolean("use_global_stats", phase == DC_PHASE_TEST) : (phase == DC_PHASE_TEST);
+    if (!ugs)
+      throw DcError(DC_EUNSUP, "layer '" + L.name + "': BatchNorm with use_global_stats=false (batch statistics) is a "
+                               "training mode outside the TEST-phase forward path");
+    L.bn_eps = bp ? (float)bp->num("eps", 1e-5) : 1e-5f;
+    int c = st_of(L.bottoms[0]).dim(1);
+    add_param({c}, 0.f);
+    add_param({c}, 0.f);
+    add_param({1}, 0.f);
+  } else if (t == "Scale") {
+    const TextMsg* sp = L.def.sub("scale_param");
+    if (L.bottoms.size() != 1 || L.tops.size() != 1)
+      throw DcError(DC_EUNSUP, "layer '" + L.name + "': two-bottom Scale is outside the DeeperCut path");
+    int axis = sp ? (int)sp->num("axis", 1) : 1, num_axes = sp ? (int)sp->num("num_axes", 1) : 1;
+    if (axis != 1 || num_axes != 1)
+      throw DcError(DC_EUNSUP, "layer '" + L.name + "': Scale only along the channel axis (axis 1, num_axes 1)");
+    L.scale_bias = sp ? sp->boolean("bias_term", false) : false;
+    float fill = 1.f;  // scale_layer.cpp:33-41: default filler is constant 1
+    if (sp && sp->sub("filler")) fill = (float)sp->sub("filler")->num("value", 0.0);
+    int c = st_of(L.bottoms[0]).dim(1);
+    add_param({c}, fill);
+    if (L.scale_bias) add_param({c}, 0.f);
+  } else if (t == "ReLU") {
+    need(1, 1);
+    const TextMsg* rp = L.def.sub("relu_param");
+    L.relu_slope = rp ? (float)rp->num("negative_slope", 0.0) : 0.f;
+    if (L.relu_slope != 0.f) throw DcError(DC_EUNSUP, "layer '" + L.name + "': leaky ReLU is outside the DeeperCut path");
+  } else if (t == "Sigmoid") {
+    need(1, 1);
+  } else if (t == "Pooling") {
+    need(1, 1);
+    const TextMsg* pp = L.def.sub("pooling_param");
+    if (!pp) throw DcError(DC_EINVAL, "layer '" + L.name + "': pooling_param missing");
+    std::string pool = pp->str("pool", "MAX");
+    if (pool != "MAX" && pool != "0") throw DcError(DC_EUNSUP, "layer '" + L.name + "': only MAX pooling is on the path");
+    if (pp->boolean("global_pooling", false)) throw DcError(DC_EUNSUP, "layer '" + L.name + "': global_pooling unsupported");
+    L.pool_k = (int)pp->num("kernel_size", 0);
+    L.pool_s = (int)pp->num("stride", 1);
+    L.pool_p = (int)pp->num("pad", 0);
+    if (pp->has("kernel_h") || pp->has("stride_h") || pp->has("pad_h"))
+      throw DcError(DC_EUNSUP, "layer '" + L.name + "': rectangular pooling unsupported");
+    if (L.pool_k <= 0 || L.pool_s <= 0 || L.pool_p >= L.pool_k) throw DcError(DC_EINVAL, "layer '" + L.name + "': bad pooling_param");
+  } else if (t == "Eltwise") {
+    if (L.bottoms.size() != 2 || L.tops.size() != 1)
+      throw DcError(DC_EUNSUP, "layer '" + L.name + "': Eltwise needs exactly two bottoms on this path");
+    const TextMsg* ep = L.def.sub("eltwise_param");
+    if (ep) {
+      std::string op = ep->str("operation", "SUM");
+      if (op != "SUM" && op != "1") throw DcError(DC_EUNSUP, "layer '" + L.name + "': only Eltwise SUM is on the path");
+      for (double c : ep->nums("coeff"))
+        if (c != 1.0) throw DcError(DC_EUNSUP, "layer '" + L.name + "': Eltwise coeff != 1 unsupported");
+    }
+  } else if (t == "Crop") {
+    need(2, 1);
+    const TextMsg* cp = L.def.sub("crop_param");
+    L.crop_oh = cp ? (int)cp->num("offset_height", 0) : 0;  // fork-specific CropParameter (caffe.proto:610-615)
+    L.crop_ow = cp ? (int)cp->num("offset_width", 0) : 0;
+  } else {
+    throw DcError(DC_EUNSUP, "layer '" + L.name + "': type '" + t + "' is outside the DeeperCut forward path "
+                             "(supported: Convolution, Deconvolution, BatchNorm, Scale, ReLU, Pooling, Eltwise, Crop, Sigmoid, Split)");
+  }
+}
+
+void Net::reshape_layer(LayerRec& L) {
+  auto st_of = [&](int bi) -> Storage& { return *blobs[bi]->st; };
+  const std::string& t = L.type;
+  if (L.is_split) return;  // shares the bottom's storage
+  Storage& b0 = st_of(L.bottoms[0]);
+  if (b0.shape.size() != 4) throw DcError(DC_ESHAPE, "layer '" + L.name + "': bottom must be 4-D");
+  int N = b0.dim(0), C = b0.dim(1), H = b0.dim(2), W = b0.dim(3);
+  Storage& top = st_of(L.tops[0]);
+  if (t == "Convolution" || t == "Deconvolution") {
+    const ConvSpec& c = L.conv;
+    int cin_w = (t == "Convolution") ? L.params[0]->st->dim(1) : L.params[0]->st->dim(0);
+    if (cin_w != C)
+      throw DcError(DC_ESHAPE, "layer '" + L.name + "': input has " + std::to_string(C) + " channels, weights expect " +
+                                   std::to_string(cin_w));
+    int ekh = c.dh * (c.kh - 1) + 1, ekw = c.dw * (c.kw - 1) + 1;
+    int OH, OW;
+    if (t == "Convolution") {  // conv_layer.cpp:8-22
+      OH = (H + 2 * c.ph - ekh) / c.sh + 1;
+      OW = (W + 2 * c.pw - ekw) / c.sw + 1;
+      if (H + 2 * c.ph < ekh || W + 2 * c.pw < ekw) OH = OW = 0;
+    } else {  // deconv_layer.cpp:8-22
+      OH = c.sh * (H - 1) + ekh - 2 * c.ph;
+      OW = c.sw * (W - 1) + ekw - 2 * c.pw;
+    }
+    if (OH <= 0 || OW <= 0) throw DcError(DC_ESHAPE, "layer '" + L.name + "': input " + std::to_string(H) + "x" +
+                                                         std::to_string(W) + " too small");
+    b0.pad4 = true;
+    top.reshape({N, c.num_output, OH, OW});
+  } else if (t == "Pooling") {  // pooling_layer.cpp:79-123
+    int k = L.pool_k, s = L.pool_s, p = L.pool_p;
+    int OH = (int)std::ceil((float)(H + 2 * p - k) / s) + 1;
+    int OW = (int)std::ceil((float)(W + 2 * p - k) / s) + 1;
+    if (p) {
+      if ((OH - 1) * s >= H + p) --OH;
+      if ((OW - 1) * s >= W + p) --OW;
+    }
+    if (OH <= 0 || OW <= 0) throw DcError(DC_ESHAPE, "layer '" + L.name + "': input too small for pooling");
+    top.reshape({N, C, OH, OW});
+  } else if (t == "Eltwise") {
+    Storage& b1 = st_of(L.bottoms[1]);
+    if (b1.shape != b0.shape) {
+      auto sh = [](const Storage& s) {
+        std::string r;
+        for (int d : s.shape) r += (r.empty() ? "" : "x") + std::to_string(d);
+        return r;
+      };
+      throw DcError(DC_ESHAPE, "layer '" + L.name + "': Eltwise bottoms differ in shape (" + sh(b0) + " vs " + sh(b1) + ")");
+    }
+    top.reshape(b0.shape);
+  } else if (t == "Crop") {  // crop_layer.cpp:25-34: strictly larger
+    Storage& b1 = st_of(L.bottoms[1]);
+    if (!(H - L.crop_oh > b1.dim(2)) || !(W - L.crop_ow > b1.dim(3)))
+      throw DcError(DC_ESHAPE, "layer '" + L.name + "': invalid offset (Crop needs bottom[0] strictly larger than bottom[1])");
+    top.reshape({N, C, b1.dim(2), b1.dim(3)});
+  } else {  // BatchNorm, Scale, ReLU, Sigmoid
+    if ((t == "BatchNorm" || t == "Scale") && L.params[0]->st->dim(0) != C)
+      throw DcError(DC_ESHAPE, "layer '" + L.name + "': channel count changed");
+    if (L.tops[0] != L.bottoms[0]) top.reshape(b0.shape);
+  }
+}
+
+void Net::reshape() {
+  for (auto& L : layers) reshape_layer(L);
+}
+
+// ---- weights --------------------------------------------------------------------------------------
+void Net::copy_from(const std::string& path) {
+  ModelFile m = read_caffemodel(path);
+  for (auto& src : m.layers) {  // Net::CopyTrainedLayersFrom (net.cpp:805-840)
+    int li = layer_index(src.name);
+    if (li < 0) continue;  // "Ignoring source layer"
+    LayerRec& L = layers[li];
+    if (L.params.size() != src.blobs.size())
+      throw DcError(DC_ESHAPE, "Incompatible number of blobs for layer " + src.name + ": net has " +
+                                   std::to_string(L.params.size()) + ", file has " + std::to_string(src.blobs.size()));
+    for (size_t j = 0; j < src.blobs.size(); ++j) {
+      Storage& dst = *L.params[j]->st;
+      const BlobData& sb = src.blobs[j];
+      // Blob::ShapeEquals (blob.cpp:413-433): legacy 4-D shapes compare after left-padding with 1s
+      std::vector<int> a = dst.shape, b = sb.shape;
+      auto strip = [](std::vector<int> v) {
+        while (v.size() > 1 && v.front() == 1) v.erase(v.begin());
+        return v;
+      };
+      if (a != b && strip(a) != strip(b)) {
+        auto sh = [](const std::vector<int>& s) {
+          std::string r;
+          for (int d : s) r += (r.empty() ? "" : " ") + std::to_string(d);
+          return r;
+        };
+        throw DcError(DC_ESHAPE, "Cannot copy param " + std::to_string(j) + " weights from layer '" + src.name +
+                                     "'; shape mismatch.  Source param shape is " + sh(b) + "; target param shape is " + sh(a));
+      }
+      if (sb.data.size() != dst.count())
+        throw DcError(DC_ESHAPE, "layer '" + src.name + "' param " + std::to_string(j) + ": data length " +
+                                     std::to_string(sb.data.size()) + " != " + std::to_string(dst.count()));
+      std::memcpy(dst.host_ptr(), sb.data.data(), sb.data.size() * sizeof(float));
+      dst.head = HEAD_AT_CPU;
+    }
+  }
+  weights_dirty = true;
+}
+
+void Net::save(const std::string& path) {
+  ModelFile m;
+  m.name = name;
+  for (auto& L : layers) {  // Net::ToProto writes every layer, with its blobs (net.cpp:910-925)
+    LayerBlobs lb;
+    lb.name = L.name;
+    lb.type = L.type;
+    for (int b : L.bottoms) lb.bottoms.push_back(blobs[b]->name);
+    for (int t : L.tops) lb.tops.push_back(blobs[t]->name);
+    for (auto& p : L.params) {
+      BlobData bd;
+      bd.shape = p->st->shape;
+      bd.data.assign(p->st->host_ptr(), p->st->host_ptr() + p->st->count());
+      lb.blobs.push_back(std::move(bd));
+    }
+    m.layers.push_back(std::move(lb));
+  }
+  write_caffemodel(path, m);
+}
+
+// ---- lowering ---------------------------------------------------------------------------------------
+namespace {
+struct LOp {
+  enum Kind { CONV, DECONV, POOL, ELT, CROP } kind = CONV;
+  std::vector<int> lids;
+  int in = -1, in2 = -1, out = -1;
+  int wl = -1;
+  std::vector<double> a, b;  // folded per-channel affine (empty = identity)
+  bool relu = false, sigmoid = false;
+  int oh = 0, ow = 0;
+  bool fused_crop = false;
+  bool dead = false;
+};
+
+// cost model used to pick the tile variant (cycles; see DESIGN.md "Tile selection")
+double variant_cost(const ConvGemmParams& p, int v) {
+  const ConvVariant& cv = conv_variant(v);
+  int bk = conv_variant_bk(v);
+  int FM = cv.BM / cv.WR / 32, FN = cv.BN / cv.WC / 32;
+  double wgs = (double)conv_grid(p, v);
+  double mfma = (double)FM * FN * (p.Ktot / 2.0) / cv.WK * 64.0;
+  double tiles = (double)p.Ktot / bk;
+  double per_wg = mfma + tiles * 220.0 + 2500.0;
+  double rounds = std::ceil(wgs / 256.0);
+  // the matrix pipe is shared by co-resident waves, so rounds serialise; partial last round costs a full one
+  double t_mfma = rounds * per_wg;
+  double bytes = wgs * (double)p.Ktot * (cv.BM + cv.BN) * 4.0;
+  double t_l2 = bytes / 4500.0;  // ~11 TB/s aggregate L2->LDS at 2.4 GHz
+  return std::max(t_mfma, t_l2);
+}
+}  // namespace
+
+static int env_int(const char* k, int def) {
+  const char* v = std::getenv(k);
+  return v ? std::atoi(v) : def;
+}
+
+void Net::build_plan() {
+  const int nL = (int)layers.size();
+  auto sid = [&](int bi) { return blobs[bi]->st->id; };
+  std::vector<LOp> ops;
+  std::vector<char> absorbed(nL, 0);
+
+  auto inplace_on = [&](int j, int storage) {
+    const LayerRec& L = layers[j];
+    return !L.is_split && L.bottoms.size() == 1 && L.tops.size() == 1 && L.bottoms[0] == L.tops[0] &&
+           sid(L.tops[0]) == storage;
+  };
+  auto ensure_affine = [&](LOp& op, int C) {
+    if (op.a.empty()) {
+      op.a.assign(C, 1.0);
+      op.b.assign(C, 0.0);
+    }
+  };
+  auto fold_bn = [&](LOp& op, const LayerRec& L) {  // batch_norm_layer.cpp:86-93,138-149
+    int C = L.params[0]->st->dim(0);
+    ensure_affine(op, C);
+    const float* mean = L.params[0]->st->host_ptr();
+    const float* var = L.params[1]->st->host_ptr();
+    float sfv = L.params[2]->st->host_ptr()[0];
+    double sf = sfv == 0.f ? 0.0 : 1.0 / (double)sfv;
+    for (int c = 0; c < C; ++c) {
+      double s = 1.0 / std::sqrt((double)var[c] * sf + (double)L.bn_eps);
+      op.a[c] = op.a[c] * s;
+      op.b[c] = (op.b[c] - (double)mean[c] * sf) * s;
+    }
+  };
+  auto fold_scale = [&](LOp& op, const LayerRec& L) {  // scale_layer.cpp:109-134, bias_layer.cpp:72-87
+    int C = L.params[0]->st->dim(0);
+    ensure_affine(op, C);
+    const float* g = L.params[0]->st->host_ptr();
+    const float* be = L.scale_bias ? L.params[1]->st->host_ptr() : nullptr;
+    for (int c = 0; c < C; ++c) {
+      op.a[c] = op.a[c] * (double)g[c];
+      op.b[c] = op.b[c] * (double)g[c] + (be ? (double)be[c] : 0.0);
+    }
+  };
+  // absorb the in-place BatchNorm / Scale / ReLU / Sigmoid layers that directly follow layer i on `op.out`
+  auto absorb_chain = [&](LOp& op, int i, bool allow_affine) {
+    int j = i + 1;
+    while (j < nL && !op.relu && !op.sigmoid && inplace_on(j, op.out)) {
+      const LayerRec& L = layers[j];
+      if (L.type == "BatchNorm" && allow_affine) fold_bn(op, L);
+      else if (L.type == "Scale" && allow_affine) fold_scale(op, L);
+      else if (L.type == "ReLU") op.relu = true;
+      else if (L.type == "Sigmoid") op.sigmoid = true;
+      else break;
+      absorbed[j] = 1;
+      op.lids.push_back(j);
+      ++j;
+    }
+  };
+
+  // pass 1: one op per layer group
+  for (int i = 0; i < nL; ++i) {
+    if (absorbed[i] || layers[i].is_split) continue;
+    const LayerRec& L = layers[i];
+    LOp op;
+    op.lids.push_back(i);
+    op.in = sid(L.bottoms[0]);
+    op.out = sid(L.tops[0]);
+    if (L.type == "Convolution" || L.type == "Deconvolution") {
+      op.kind = L.type == "Convolution" ? LOp::CONV : LOp::DECONV;
+      op.wl = i;
+      if (L.conv.bias) {
+        const float* bias = L.params[1]->st->host_ptr();
+        op.a.assign(L.conv.num_output, 1.0);
+        op.b.assign(bias, bias + L.conv.num_output);
+      }
+      if (op.in != op.out) absorb_chain(op, i, true);
+    } else if (L.type == "Pooling") {
+      op.kind = LOp::POOL;
+    } else if (L.type == "Eltwise") {
+      op.kind = LOp::ELT;
+      op.in2 = sid(L.bottoms[1]);
+      absorb_chain(op, i, false);
+    } else if (L.type == "Crop") {
+      op.kind = LOp::CROP;
+      op.oh = L.crop_oh;
+      op.ow = L.crop_ow;
+    } else {  // stand-alone BatchNorm / Scale / ReLU / Sigmoid
+      op.kind = LOp::ELT;
+      if (L.type == "BatchNorm") fold_bn(op, L);
+      else if (L.type == "Scale") fold_scale(op, L);
+      else if (L.type == "ReLU") op.relu = true;
+      else if (L.type == "Sigmoid") op.sigmoid = true;
+      if (!op.relu && !op.sigmoid) absorb_chain(op, i, true);
+    }
+    ops.push_back(std::move(op));
+  }
+
+  // pass 2: residual-add and deconvolution-head fusion
+  if (fuse >= 1) {
+    const int nS = (int)storages.size();
+    auto analyse = [&](std::vector<int>& prod, std::vector<std::vector<int>>& cons) {
+      prod.assign(nS, -1);
+      cons.assign(nS, {});
+      for (int k = 0; k < (int)ops.size(); ++k) {
+        if (ops[k].dead) continue;
+        cons[ops[k].in].push_back(k);
+        if (ops[k].in2 >= 0) cons[ops[k].in2].push_back(k);
+        prod[ops[k].out] = k;
+      }
+    };
+    std::vector<int> prod;
+    std::vector<std::vector<int>> cons;
+    for (int e = 0; e < (int)ops.size(); ++e) {
+      LOp& E = ops[e];
+      if (E.dead || E.kind != LOp::ELT || E.in2 < 0 || !E.a.empty() || E.in == E.out || E.in2 == E.out) continue;
+      analyse(prod, cons);
+      int cand[2][2] = {{E.in2, E.in}, {E.in, E.in2}};
+      if (prod[E.in] > prod[E.in2]) std::swap(cand[0], cand[1]);
+      for (auto& c : cand) {
+        int X = c[0], other = c[1];
+        int pk = prod[X];
+        if (pk < 0 || cons[X].size() != 1) continue;
+        LOp& P = ops[pk];
+        if (P.kind == LOp::CONV && !P.relu && !P.sigmoid && P.in2 < 0 && prod[other] < pk && P.in != P.out) {
+          P.in2 = other;
+          P.out = E.out;
+          P.relu = E.relu;
+          P.sigmoid = E.sigmoid;
+          P.lids.insert(P.lids.end(), E.lids.begin(), E.lids.end());
+          E.dead = true;
+          break;
+        }
+        if (P.kind == LOp::CROP) {
+          int dk = prod[P.in];
+          if (dk < 0 || cons[P.in].size() != 1) continue;
+          LOp& D = ops[dk];
+          if (D.kind != LOp::DECONV || D.relu || D.sigmoid || D.in2 >= 0) continue;
+          LOp F = D;
+          F.in2 = other;
+          F.out = E.out;
+          F.oh = P.oh;
+          F.ow = P.ow;
+          F.fused_crop = true;
+          F.relu = E.relu;
+          F.sigmoid = E.sigmoid;
+          F.lids.insert(F.lids.end(), P.lids.begin(), P.lids.end());
+          F.lids.insert(F.lids.end(), E.lids.begin(), E.lids.end());
+          D.dead = true;
+          P.dead = true;
+          ops[e] = F;  // executes at the Eltwise's position: both operands are ready there
+          break;
+        }
+      }
+    }
+  }
+
+  // tensors combined element-wise / pooled / cropped must agree on channel pitch: propagate before any
+  // launch parameters are derived from cp()
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (auto& op : ops) {
+      if (op.dead || op.kind == LOp::CONV || op.kind == LOp::DECONV) continue;
+      bool p4 = storages[op.in]->pad4 || storages[op.out]->pad4 || (op.in2 >= 0 && storages[op.in2]->pad4);
+      if (!p4) continue;
+      for (int sx : {op.in, op.in2, op.out})
+        if (sx >= 0 && !storages[sx]->pad4) storages[sx]->pad4 = true, changed = true;
+    }
+  }
+  {
+    std::vector<char> live(storages.size(), 0);
+    for (int bi : inputs) live[blobs[bi]->st->id] = 1;
+    for (auto& op : ops)
+      if (!op.dead) live[op.out] = 1;
+    for (auto& st : storages) st->elided = !live[st->id];
+  }
+
+  // finalize: launches
+  plan.clear();
+  plan_flops = 0;
+  if (weights_dirty) {
+    for (auto& v : vecs)
+      if (v.dev) (void)hipFree(v.dev);
+    vecs.clear();
+    vec_keys_.clear();
+    weights_dirty = false;
+    release_graph();
+  }
+  auto get_vec = [&](const std::string& key, const std::function<void(std::vector<float>&)>& fill) {
+    auto it = vec_keys_.find(key);
+    if (it != vec_keys_.end()) return it->second;
+    DevVec v;
+    fill(v.host);
+    vecs.push_back(std::move(v));
+    vec_keys_[key] = (int)vecs.size() - 1;
+    return (int)vecs.size() - 1;
+  };
+  auto label_of = [&](const LOp& op) {
+    std::string s;
+    for (size_t k = 0; k < op.lids.size(); ++k) {
+      if (k) s += "+";
+      s += layers[op.lids[k]].name;
+    }
+    return s;
+  };
+  const int force_variant = env_int("DC_CONV_VARIANT", -1);
+
+  auto affine_vecs = [&](const LOp& op, Launch& l, int C) {
+    if (op.a.empty()) return;
+    std::string key = std::to_string(op.lids.front()) + ":" + std::to_string(op.lids.size());
+    l.scale = get_vec("a:" + key, [&](std::vector<float>& h) {
+      h.resize(C);
+      for (int c = 0; c < C; ++c) h[c] = (float)op.a[c];
+    });
+    l.shift = get_vec("b:" + key, [&](std::vector<float>& h) {
+      h.resize(C);
+      for (int c = 0; c < C; ++c) h[c] = (float)op.b[c];
+    });
+  };
+  auto choose_variant = [&](Launch& l, int kgcd) {
+    int best = -1;
+    double bc = 0;
+    for (int v = 0; v < conv_num_variants(); ++v) {
+      if (kgcd % conv_variant_bk(v) != 0) continue;
+      if (force_variant >= 0 && v != force_variant) continue;
+      double c = variant_cost(l.cg, v);
+      if (best < 0 || c < bc) best = v, bc = c;
+    }
+    if (best < 0)
+      for (int v = 0; v < conv_num_variants(); ++v) {
+        if (kgcd % conv_variant_bk(v) != 0) continue;
+        double c = variant_cost(l.cg, v);
+        if (best < 0 || c < bc) best = v, bc = c;
+      }
+    l.variant = best;
+    l.kernel = std::string("conv_gemm<") + conv_variant(best).name + ">";
+    l.grid = conv_grid(l.cg, best);
+  };
+
+  for (auto& op : ops) {
+    if (op.dead) continue;
+    Launch base;
+    base.label = label_of(op);
+    base.first_layer = *std::min_element(op.lids.begin(), op.lids.end());
+    base.last_layer = *std::max_element(op.lids.begin(), op.lids.end());
+    base.in = op.in;
+    base.in2 = op.in2;
+    base.out = op.out;
+    base.relu = op.relu;
+    base.sigmoid = op.sigmoid;
+    Storage& X = *storages[op.in];
+    Storage& Y = *storages[op.out];
+    const int N = X.dim(0), C = X.dim(1), H = X.dim(2), W = X.dim(3);
+    const int CP = X.cp();
+    const int OC = Y.dim(1), OHt = Y.dim(2), OWt = Y.dim(3), OCP = Y.cp();
+    if (op.kind == LOp::CONV) {
+      const LayerRec& L = layers[op.wl];
+      const ConvSpec& c = L.conv;
+      Launch l = base;
+      l.kind = Launch::CONV;
+      ConvGemmParams& g = l.cg;
+      g.x_img_stride = (long)H * W * CP;
+      g.x_row_stride = W * CP;
+      g.x_rows = H;
+      g.x_rowlen = W * CP;
+      g.sy = c.sh;
+      g.sx = c.sw * CP;
+      int kgcd;
+      const bool rowtap = (CP % 32) != 0;
+      if (rowtap) {
+        // small-channel input (the 3->4 channel stem): one tap per kernel ROW, the kw adjacent pixels of
+        // that row being contiguous in NHWC; K per tap = kw*CP rounded up to 32 with zero weights
+        if (c.dw != 1 || CP % 4 != 0)
+          throw DcError(DC_EUNSUP, "layer '" + L.name + "': convolution over " + std::to_string(C) +
+                                       " channels needs dilation_w 1 (row-tap path) or a multiple of 32 channels");
+        int klen = (c.kw * CP + 31) / 32 * 32;
+        if (c.kh > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': kernel too tall");
+        g.ntaps = c.kh;
+        for (int ky = 0; ky < c.kh; ++ky) g.taps[ky] = ConvTap{ky * c.dh - c.ph, -c.pw * CP, klen, 0};
+        g.Ktot = c.kh * klen;
+        kgcd = klen;
+        l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          h.assign((size_t)c.num_output * g.Ktot, 0.f);
+          const float* w = L.params[0]->st->host_ptr();  // [Cout][Cin][kh][kw]
+          for (int co = 0; co < c.num_output; ++co)
+            for (int ci = 0; ci < C; ++ci)
+              for (int ky = 0; ky < c.kh; ++ky)
+                for (int kx = 0; kx < c.kw; ++kx)
+                  h[(size_t)co * g.Ktot + ky * klen + kx * CP + ci] = w[(((size_t)co * C + ci) * c.kh + ky) * c.kw + kx];
+        });
+      } else {
+        if (c.kh * c.kw > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': kernel larger than 7x7");
+        g.ntaps = c.kh * c.kw;
+        for (int ky = 0; ky < c.kh; ++ky)
+          for (int kx = 0; kx < c.kw; ++kx)
+            g.taps[ky * c.kw + kx] = ConvTap{ky * c.dh - c.ph, (kx * c.dw - c.pw) * CP, CP, 0};
+        g.Ktot = g.ntaps * CP;
+        kgcd = CP;
+        l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          h.assign((size_t)c.num_output * g.Ktot, 0.f);
+          const float* w = L.params[0]->st->host_ptr();
+          const int taps = c.kh * c.kw;
+          for (int co = 0; co < c.num_output; ++co)
+            for (int ci = 0; ci < C; ++ci) {
+              const float* src = w + ((size_t)co * C + ci) * taps;
+              float* dst = h.data() + (size_t)co * g.Ktot + ci;
+              for (int tp = 0; tp < taps; ++tp) dst[(size_t)tp * CP] = src[tp];
+            }
+        });
+      }
+      g.NB = N;
+      g.OH = OHt;
+      g.OW = OWt;
+      g.M = N * OHt * OWt;
+      g.Cout = OC;
+      g.y_img_stride = (long)OHt * OWt * OCP;
+      g.y_row_stride = OWt * OCP;
+      g.y_pix_stride = OCP;
+      g.relu = op.relu;
+      g.sigmoid_ch = op.sigmoid ? OC : 0;
+      affine_vecs(op, l, OC);
+      l.flops = 2.0 * g.M * (double)OC * C * c.kh * c.kw;
+      plan_flops += l.flops;
+      choose_variant(l, kgcd);
+      plan.push_back(std::move(l));
+    } else if (op.kind == LOp::DECONV) {
+      // stride-s transposed convolution = s*s ordinary gather-GEMMs, one per output residue class
+      // (Y mod s, X mod s): output pixel (s*i + r) receives tap k iff (r + p - k*d) % s == 0, from input
+      // row i + (r + p - k*d)/s  (col2im_cpu, im2col.cpp:163-197, inverted: output-stationary).
+      const LayerRec& L = layers[op.wl];
+      const ConvSpec& c = L.conv;
+      if (CP % 32 != 0) throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution input channels must be a multiple of 32");
+      const int DH = c.sh * (H - 1) + c.dh * (c.kh - 1) + 1 - 2 * c.ph;  // full deconv output
+      const int DW = c.sw * (W - 1) + c.dw * (c.kw - 1) + 1 - 2 * c.pw;
+      const int oh = op.fused_crop ? op.oh : 0, ow = op.fused_crop ? op.ow : 0;
+      plan_flops += 2.0 * (double)C * H * W * N * OC * c.kh * c.kw;  // SURVEY §8(d) definition
+      bool any = false;
+      for (int ry = 0; ry < c.sh; ++ry)
+        for (int rx = 0; rx < c.sw; ++rx) {
+          // rows of this class inside the (cropped) output window: Y = s*i + ry, y = Y - oh in [0, OHt)
+          auto range = [](int r, int s, int off, int outn, int full, int& i0, int& cnt) {
+            int lo = off - r;  // s*i >= lo
+            i0 = lo <= 0 ? 0 : (lo + s - 1) / s;
+            int hiY = std::min(full, off + outn) - 1;  // last Y
+            int i1 = (hiY - r) >= 0 ? (hiY - r) / s : -1;
+            cnt = i1 - i0 + 1;
+          };
+          int i0, nh, j0, nw;
+          range(ry, c.sh, oh, OHt, DH, i0, nh);
+          range(rx, c.sw, ow, OWt, DW, j0, nw);
+          if (nh <= 0 || nw <= 0) continue;
+          std::vector<std::pair<int, int>> tky, tkx;  // (k, source offset)
+          for (int k = 0; k < c.kh; ++k)
+            if ((ry + c.ph - k * c.dh) % c.sh == 0) tky.push_back({k, (ry + c.ph - k * c.dh) / c.sh});
+          for (int k = 0; k < c.kw; ++k)
+            if ((rx + c.pw - k * c.dw) % c.sw == 0) tkx.push_back({k, (rx + c.pw - k * c.dw) / c.sw});
+          Launch l = base;
+          l.kind = Launch::CONV;
+          l.label += " [class " + std::to_string(ry) + "," + std::to_string(rx) + "]";
+          ConvGemmParams& g = l.cg;
+          g.x_img_stride = (long)H * W * CP;
+          g.x_row_stride = W * CP;
+          g.x_rows = H;
+          g.x_rowlen = W * CP;
+          g.sy = 1;
+          g.sx = CP;
+          g.ntaps = (int)(tky.size() * tkx.size());
+          if (g.ntaps > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': too many taps");
+          int ti = 0;
+          for (auto& a : tky)
+            for (auto& b : tkx) g.taps[ti++] = ConvTap{a.second + i0, (b.second + j0) * CP, CP, 0};
+          g.Ktot = g.ntaps * CP;
+          g.NB = N;
+          g.OH = nh;
+          g.OW = nw;
+          g.M = N * nh * nw;
+          g.Cout = OC;
+          g.y_img_stride = (long)OHt * OWt * OCP;
+          g.y_row_stride = c.sh * OWt * OCP;
+          g.y_pix_stride = c.sw * OCP;
+          l.y_off = ((long)(c.sh * i0 + ry - oh) * OWt + (c.sw * j0 + rx - ow)) * OCP;
+          g.relu = op.relu;
+          g.sigmoid_ch = op.sigmoid ? OC : 0;
+          affine_vecs(op, l, OC);
+          if (g.ntaps == 0) {
+            // a class no kernel tap reaches (k < s): output = bias only; run it as a 1-tap GEMM over a
+            // zero-length... not reachable for k >= s; refuse rather than emit garbage
+            throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution with kernel smaller than stride");
+          }
+          l.w = get_vec("w:" + std::to_string(op.wl) + ":" + std::to_string(ry) + "," + std::to_string(rx),
+                        [&](std::vector<float>& h) {
+                          h.assign((size_t)OC * g.Ktot, 0.f);
+                          const float* w = L.params[0]->st->host_ptr();  // [Cin][Cout][kh][kw]
+                          int t2 = 0;
+                          for (auto& a : tky)
+                            for (auto& b : tkx) {
+                              for (int co = 0; co < OC; ++co)
+                                for (int ci = 0; ci < C; ++ci)
+                                  h[(size_t)co * g.Ktot + (size_t)t2 * CP + ci] =
+                                      w[(((size_t)ci * OC + co) * c.kh + a.first) * c.kw + b.first];
+                              ++t2;
+                            }
+                        });
+          l.flops = 2.0 * g.M * (double)OC * C * g.ntaps;
+          choose_variant(l, CP);
+          plan.push_back(std::move(l));
+          any = true;
+        }
+      if (!any) throw DcError(DC_ESHAPE, "layer '" + L.name + "': empty deconvolution output");
+    } else if (op.kind == LOp::POOL) {
+      const LayerRec& L = layers[op.lids[0]];
+      Launch l = base;
+      l.kind = Launch::POOL;
+      l.kernel = "maxpool";
+      l.pk = L.pool_k;
+      l.ps = L.pool_s;
+      l.pp = L.pool_p;
+      plan.push_back(std::move(l));
+    } else if (op.kind == LOp::ELT) {
+      Launch l = base;
+      l.kind = Launch::ELT;
+      l.kernel = "eltwise";
+      affine_vecs(op, l, C);
+      plan.push_back(std::move(l));
+    } else {
+      Launch l = base;
+      l.kind = Launch::CROP;
+      l.kernel = "crop";
+      l.oh = op.oh;
+      l.ow = op.ow;
+      plan.push_back(std::move(l));
+    }
+  }
+  plan_valid = true;
+  plan_input_shape.clear();
+  for (int bi : inputs)
+    for (int d : blobs[bi]->st->shape) plan_input_shape.push_back(d);
+  release_graph();
+}
+
+// ---- execution ----------------------------------------------------------------------------------------
+void Net::ensure_device() {
+  if (device_count() <= 0)
+    throw DcError(DC_EDEVICE, "no HIP device visible: libdeepcut_hip has no CPU compute path (the CPU restatement of the "
+                              "reference is test-only, under oracle/)");
+  Context& c = Context::get();
+  if (device < 0) device = c.device;
+  HIPCHECK(hipSetDevice(device));
+  if (!stream) {
+    hipStream_t s;
+    HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    stream = s;
+  }
+}
+
+void Net::upload_vecs() {
+  for (auto& v : vecs)
+    if (!v.dev && !v.host.empty()) {
+      HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * sizeof(float)));
+      HIPCHECK(hipMemcpy(v.dev, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
+      v.uploaded = v.host.size();
+      std::vector<float>().swap(v.host);  // the packed image lives in HBM only
+    }
+}
+
+void Net::release_graph() {
+  if (graph_exec) {
+    (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    graph_exec = nullptr;
+  }
+}
+
+void Net::sync_to_device(Storage& s) {
+  if (s.head == HEAD_AT_GPU || s.head == SYNCED) return;
+  ensure_device();
+  size_t n = s.count();
+  s.ensure_dev(s.dev_count());
+  if (s.shape.size() == 4) {
+    s.ensure_stage(n);
+    HIPCHECK(hipMemcpyAsync(s.stage, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    KCHECK(launch_nchw_to_nhwc(s.stage, s.dev, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), stream));
+  } else {
+    HIPCHECK(hipMemcpyAsync(s.dev, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  }
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  s.head = SYNCED;
+}
+
+void Net::sync_to_host(Storage& s) {
+  if (s.head != HEAD_AT_GPU) {
+    s.host_ptr();
+    if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
+    return;
+  }
+  ensure_device();
+  size_t n = s.count();
+  float* h = s.host_ptr();
+  if (s.shape.size() == 4) {
+    s.ensure_stage(n);
+    KCHECK(launch_nhwc_to_nchw(s.dev, s.stage, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), 0, stream));
+    HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  } else {
+    HIPCHECK(hipMemcpyAsync(h, s.dev, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  }
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  s.head = SYNCED;
+}
+
+void Net::run_launch(const Launch& l, void* s) {
+  Storage& X = *storages[l.in];
+  Storage& Y = *storages[l.out];
+  switch (l.kind) {
+    case Launch::CONV: {
+      ConvGemmParams g = l.cg;
+      g.x = X.dev + l.x_off;
+      g.y = Y.dev + l.y_off;
+      g.resid = l.in2 >= 0 ? storages[l.in2]->dev + l.y_off : nullptr;
+      g.w = vecs[l.w].dev;
+      g.scale = l.scale >= 0 ? vecs[l.scale].dev : nullptr;
+      g.shift = l.shift >= 0 ? vecs[l.shift].dev : nullptr;
+      KCHECK(launch_conv_gemm(g, l.variant, s));
+      break;
+    }
+    case Launch::POOL:
+      KCHECK(launch_maxpool(X.dev, Y.dev, X.dim(0), X.dim(2), X.dim(3), X.cp(), Y.dim(2), Y.dim(3), l.pk, l.ps, l.pp, s));
+      break;
+    case Launch::ELT:
+      KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale >= 0 ? vecs[l.scale].dev : nullptr,
+                            l.shift >= 0 ? vecs[l.shift].dev : nullptr, Y.dev, (long)Y.dev_count(), Y.cp(), l.relu,
+                            l.sigmoid, s));
+      break;
+    case Launch::CROP:
+      KCHECK(launch_crop(X.dev, Y.dev, X.dim(0), X.dim(2), X.dim(3), X.cp(), l.oh, l.ow, Y.dim(2), Y.dim(3), s));
+      break;
+  }
+}
+
+void Net::run_plan(int start, int end, void* s) {
+  for (auto& l : plan) {
+    if (l.last_layer < start || l.first_layer > end) continue;
+    if (l.first_layer < start || l.last_layer > end)
+      throw DcError(DC_EINVAL, "forward range [" + std::to_string(start) + "," + std::to_string(end) +
+                                   "] cuts through the fused group '" + l.label + "'; use DC_OPT_FUSE 0 for partial ranges");
+    run_launch(l, s);
+  }
+}
+
+static void prepare_buffers(Net& n, bool& grew) {
+  grew = false;
+  auto prep = [&](int sidx) {
+    Storage& s = *n.storages[sidx];
+    size_t need = s.dev_count();
+    if (!s.dev || s.dev_cap < need) {
+      s.ensure_dev(need);
+      grew = true;
+    }
+  };
+  for (auto& l : n.plan) {
+    prep(l.in);
+    prep(l.out);
+    if (l.in2 >= 0) prep(l.in2);
+  }
+}
+
+void Net::forward(int start, int end) {
+  if (Context::get().mode != DC_MODE_GPU)
+    throw DcError(DC_ENOCPU, "forward() in CPU mode: libdeepcut_hip provides the MI355X path only — call set_mode_gpu() "
+                             "(the CPU restatement of the reference is test infrastructure under oracle/)");
+  reshape();
+  std::vector<int> sig;
+  for (int bi : inputs)
+    for (int d : blobs[bi]->st->shape) sig.push_back(d);
+  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();
+  ensure_device();
+  upload_vecs();
+  bool grew;
+  prepare_buffers(*this, grew);
+  if (grew) release_graph();
+  // inputs of the executed range whose host copy is authoritative go up first (SyncedMemory::to_gpu)
+  for (auto& l : plan) {
+    if (l.last_layer < start || l.first_layer > end) continue;
+    for (int sidx : {l.in, l.in2})
+      if (sidx >= 0) {
+        Storage& s = *storages[sidx];
+        if (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED) {
+          bool produced_earlier = false;
+          for (auto& m : plan) {
+            if (&m == &l) break;
+            if (m.last_layer < start || m.first_layer > end) continue;
+            if (m.out == sidx) produced_earlier = true;
+          }
+          if (!produced_earlier) sync_to_device(s);
+        }
+      }
+  }
+  const bool whole = start <= 0 && end >= (int)layers.size() - 1;
+  if (use_graph && whole) {
+    if (!graph_exec) {
+      hipGraph_t graph;
+      HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+      try {
+        run_plan(start, end, stream);
+      } catch (...) {
+        hipGraph_t g2;
+        (void)hipStreamEndCapture((hipStream_t)stream, &g2);
+        throw;
+      }
+      HIPCHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
+      hipGraphExec_t ge;
+      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      graph_exec = ge;
+    }
+    HIPCHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  } else {
+    run_plan(start, end, stream);
+  }
+  for (auto& l : plan) {
+    if (l.last_layer < start || l.first_layer > end) continue;
+    storages[l.out]->head = HEAD_AT_GPU;
+  }
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+}
+
+void Net::forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc, float* next,
+                        void* user_stream) {
+  if (Context::get().mode != DC_MODE_GPU)
+    throw DcError(DC_ENOCPU, "forward_batch() in CPU mode: libdeepcut_hip provides the MI355X path only");
+  if (inputs.size() != 1) throw DcError(DC_EINVAL, "forward_batch needs a single-input net");
+  Storage& in = *blobs[inputs[0]]->st;
+  int C = in.dim(1);
+  in.reshape({n, C, h, w});
+  reshape();
+  std::vector<int> sig = in.shape;
+  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();
+  ensure_device();
+  upload_vecs();
+  bool grew;
+  prepare_buffers(*this, grew);
+  if (grew) release_graph();
+  void* s = user_stream ? user_stream : stream;
+  size_t cnt = in.count();
+  if (is_device) {
+    KCHECK(launch_nchw_to_nhwc(input, in.dev, n, C, h, w, in.cp(), s));
+  } else {
+    in.ensure_stage(cnt);
+    HIPCHECK(hipMemcpyAsync(in.stage, input, cnt * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
+    KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, n, C, h, w, in.cp(), s));
+  }
+  in.head = HEAD_AT_GPU;
+  const int last = (int)layers.size() - 1;
+  if (use_graph && s == stream) {
+    if (!graph_exec) {
+      hipGraph_t graph;
+      HIPCHECK(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+      try {
+        run_plan(0, last, s);
+      } catch (...) {
+        hipGraph_t g2;
+        (void)hipStreamEndCapture((hipStream_t)s, &g2);
+        throw;
+      }
+      HIPCHECK(hipStreamEndCapture((hipStream_t)s, &graph));
+      hipGraphExec_t ge;
+      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      graph_exec = ge;
+    }
+    HIPCHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)s));
+  } else {
+    run_plan(0, last, s);
+  }
+  for (auto& l : plan) storages[l.out]->head = HEAD_AT_GPU;
+  struct Out {
+    const char* name;
+    float* dst;
+  } outs[3] = {{"prob", prob}, {"loc_pred", loc}, {"next_pred", next}};
+  for (auto& o : outs) {
+    if (!o.dst) continue;
+    auto it = blob_index.find(o.name);
+    if (it == blob_index.end()) throw DcError(DC_EINVAL, std::string("net has no blob '") + o.name + "'");
+    Storage& st = *blobs[it->second]->st;
+    size_t m = st.count();
+    if (is_device) {
+      KCHECK(launch_nhwc_to_nchw(st.dev, o.dst, st.dim(0), st.dim(1), st.dim(2), st.dim(3), st.cp(), 0, s));
+    } else {
+      st.ensure_stage(m);
+      KCHECK(launch_nhwc_to_nchw(st.dev, st.stage, st.dim(0), st.dim(1), st.dim(2), st.dim(3), st.cp(), 0, s));
+      HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
+    }
+  }
+  if (!(is_device && user_stream)) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+std::string Net::plan_text() {
+  if (!plan_valid) {
+    reshape();
+    build_plan();
+  }
+  std::ostringstream os;
+  os << "# plan for input";
+  for (int d : plan_input_shape) os << " " << d;
+  os << ": " << plan.size() << " launches, " << plan_flops / 1e9 << " GFLOP algorithmic, fuse=" << fuse << "\n";
+  for (size_t i = 0; i < plan.size(); ++i) {
+    const Launch& l = plan[i];
+    os << i << "\t" << l.kernel << "\t";
+    if (l.kind == Launch::CONV)
+      os << "M=" << l.cg.M << " N=" << l.cg.Cout << " K=" << l.cg.Ktot << " taps=" << l.cg.ntaps << " grid=" << l.grid
+         << (l.in2 >= 0 ? " +resid" : "") << (l.relu ? " +relu" : "") << (l.cg.sigmoid_ch ? " +sigmoid" : "");
+    os << "\t" << l.label << "\n";
+  }
+  return os.str();
+}
+
+std::string Net::profile_text(int iters) {
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "profile in CPU mode");
+  if (!plan_valid) throw DcError(DC_EINVAL, "profile_text: run forward() first");
+  ensure_device();
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  std::ostringstream os;
+  os << "idx\tkernel\tus\tGFLOP\tTFLOP/s\tgrid\tlabel\n";
+  double total_us = 0;
+  for (size_t i = 0; i < plan.size(); ++i) {
+    const Launch& l = plan[i];
+    run_launch(l, stream);  // warm
+    HIPCHECK(hipEventRecord(e0, (hipStream_t)stream));
+    for (int k = 0; k < iters; ++k) run_launch(l, stream);
+    HIPCHECK(hipEventRecord(e1, (hipStream_t)stream));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1000.0 / iters;
+    total_us += us;
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%zu\t%s\t%.2f\t%.3f\t%.2f\t%ld\t%s\n", i, l.kernel.c_str(), us, l.flops / 1e9,
+                  us > 0 ? l.flops / us / 1e6 : 0.0, l.grid, l.label.c_str());
+    os << buf;
+  }
+  os << "# sum of per-launch times: " << total_us << " us\n";
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return os.str();
+}
+
+}  // namespace dc

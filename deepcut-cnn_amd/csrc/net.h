@@ -1,0 +1,172 @@
+// net.h — graph runtime of the DeeperCut forward path: the MI355X-native counterpart of
+// caffe::Net / caffe::Layer / caffe::Blob / caffe::SyncedMemory / caffe::Caffe for the TEST-phase
+// forward of models/deepercut/*.prototxt (reference: src/caffe/net.cpp, include/caffe/layer.hpp,
+// src/caffe/blob.cpp, src/caffe/syncedmem.cpp, src/caffe/common.cpp).
+//
+// It is not a layer-by-layer interpreter.  Net::Init semantics (InsertSplits, in-place tops, output
+// discovery, name-matched weight loading) are reproduced so that the pycaffe-visible surface is the
+// reference's, but execution goes through a *lowered plan*: BatchNorm+Scale(+bias)+ReLU are folded
+// into the producing convolution's epilogue, residual Eltwise adds and the Deconvolution+Crop+Eltwise
+// heads are fused, activations live channels-last (NHWC) in HBM, and every convolution /
+// deconvolution is one launch (4 for a stride-2 deconvolution: one per output parity class) of the
+// gather-GEMM MFMA kernel in kernels.hip.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "formats.h"
+#include "kernels.h"
+
+namespace dc {
+
+// ---- Caffe context (common.cpp:13-20: thread-local mode + device) ---------------------------------
+struct Context {
+  int mode = 0;     // DC_MODE_CPU (reference default, common.cpp:55,100)
+  int device = 0;
+  static Context& get();
+};
+int device_count();  // 0 without a GPU; never throws
+
+// ---- SyncedMemory + Blob ----------------------------------------------------------------------------
+enum Head { UNINITIALIZED = 0, HEAD_AT_CPU = 1, HEAD_AT_GPU = 2, SYNCED = 3 };
+
+struct Net;
+struct Storage {
+  std::vector<int> shape;  // logical Caffe shape (N,C,H,W for activations)
+  float* host = nullptr;
+  size_t host_cap = 0;
+  bool host_pinned = false;
+  float* dev = nullptr;  // NHWC image, channel pitch cp()
+  size_t dev_cap = 0;
+  float* stage = nullptr;  // device NCHW staging for up/download
+  size_t stage_cap = 0;
+  int head = UNINITIALIZED;
+  bool pad4 = false;   // channel pitch rounded up to 4 (tensors read by the gather-GEMM)
+  bool is_param = false;
+  bool elided = false;  // absorbed by fusion in the current plan: never materialised
+  Net* owner = nullptr;  // params: owning net (marks packed weights stale on mutable access)
+  int id = -1;
+
+  ~Storage();
+  size_t count() const;
+  int dim(int i) const { return i < (int)shape.size() ? shape[i] : 1; }
+  int cp() const;                 // channel pitch of the device image
+  size_t dev_count() const;       // elements of the device image
+  void reshape(const std::vector<int>& s);  // Blob::Reshape: capacity only grows (blob.cpp:23-43)
+  float* host_ptr();              // allocates + zero-fills on first touch (syncedmem.cpp:25-31)
+  void ensure_dev(size_t n);
+  void ensure_stage(size_t n);
+};
+
+struct NetBlob {
+  std::string name;
+  std::shared_ptr<Storage> st;
+};
+
+struct ConvSpec {
+  int num_output = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1, group = 1;
+  bool bias = true;
+};
+
+struct LayerRec {
+  std::string name, type;
+  std::vector<int> bottoms, tops;  // indices into Net::blobs
+  TextMsg def;                     // the layer { } message
+  std::vector<std::shared_ptr<NetBlob>> params;
+  bool is_split = false;
+  // parsed parameters
+  ConvSpec conv;
+  int pool_k = 1, pool_s = 1, pool_p = 0;
+  float bn_eps = 1e-5f;
+  bool scale_bias = false;
+  float relu_slope = 0.f;
+  int crop_oh = 0, crop_ow = 0;
+};
+
+// ---- lowered plan -----------------------------------------------------------------------------------
+struct DevVec {
+  std::vector<float> host;
+  float* dev = nullptr;
+  size_t uploaded = 0;
+};
+
+struct Launch {
+  enum Kind { CONV, POOL, ELT, CROP } kind = CONV;
+  std::string label;    // e.g. "res4b3_branch2b+bn+scale+relu"
+  std::string kernel;   // variant / kernel name
+  int first_layer = 0, last_layer = 0;
+  int in = -1, in2 = -1, out = -1;  // storage ids (in2: residual / second operand)
+  // CONV
+  ConvGemmParams cg{};  // pointers filled at launch time
+  int variant = 0;
+  int w = -1, scale = -1, shift = -1;  // DevVec ids
+  long x_off = 0, y_off = 0;           // element offsets into in / out images
+  double flops = 0;                    // algorithmic 2*MAC
+  long grid = 0;
+  // POOL
+  int pk = 0, ps = 0, pp = 0;
+  // ELT
+  int relu = 0, sigmoid = 0;
+  // CROP
+  int oh = 0, ow = 0;
+};
+
+struct Net {
+  std::string name;
+  int phase = 1;
+  std::vector<LayerRec> layers;  // after InsertSplits
+  std::vector<std::shared_ptr<NetBlob>> blobs;
+  std::map<std::string, int> blob_index;
+  std::vector<std::shared_ptr<Storage>> storages;
+  std::vector<int> inputs, outputs;  // blob indices
+
+  int fuse = 1;
+  int use_graph = 0;
+  bool weights_dirty = true;
+  bool plan_valid = false;
+  std::vector<int> plan_input_shape;
+  std::vector<Launch> plan;
+  std::vector<DevVec> vecs;
+  std::map<std::string, int> vec_keys_;  // packed-weight cache: key -> index in vecs
+  double plan_flops = 0;
+  void* stream = nullptr;
+  int device = -1;
+  void* graph_exec = nullptr;
+  std::string text_buf;
+
+  ~Net();
+  static Net* create(const std::string& prototxt_text, int phase);
+  void copy_from(const std::string& path);
+  void save(const std::string& path);
+  void reshape();         // propagate input shapes through every layer (Net::Reshape)
+  void build_plan();      // lower to launches for the current shapes (host only; no device needed)
+  void forward(int start, int end);
+  void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
+                     float* next, void* user_stream);
+  void sync_to_host(Storage& s);       // SyncedMemory::to_cpu
+  void sync_to_device(Storage& s);     // SyncedMemory::to_gpu
+  std::string plan_text();
+  std::string profile_text(int iters);
+  int layer_index(const std::string& name) const;
+
+ private:
+  void init_from(const TextMsg& root);
+  void setup_layer(LayerRec& L);
+  void reshape_layer(LayerRec& L);
+  void ensure_device();
+  void upload_vecs();
+  void run_launch(const Launch& l, void* s);
+  void run_plan(int start, int end, void* s);
+  void release_graph();
+};
+
+// stand-alone layer forward on the device (Layer::Forward_gpu surface), host NCHW in/out
+void layer_forward(const std::string& layer_prototxt, const std::vector<const float*>& bottoms,
+                   const std::vector<std::vector<int>>& bottom_shapes,
+                   const std::vector<std::vector<float>>& weights, std::vector<float>& top,
+                   std::vector<int>& top_shape);
+
+}  // namespace dc

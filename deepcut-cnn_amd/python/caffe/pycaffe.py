@@ -1,0 +1,335 @@
+"""ctypes binding of libdeepcut_hip.so with the reference's pycaffe names and semantics
+(python/caffe/pycaffe.py:22-108, python/caffe/_caffe.cpp:76-96,159-193,219-277)."""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+TRAIN = 0  # caffe.proto:253-256
+TEST = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_CANDIDATES = [
+    os.environ.get("DEEPCUT_HIP_LIB", ""),
+    os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdeepcut_hip.so")),
+]
+
+
+class DeepcutError(RuntimeError):
+    """Raised for every failure the reference would LOG(FATAL)/CHECK-abort on, and for I/O errors
+    (the reference raises RuntimeError('Could not open file ...'), _caffe.cpp:45-52)."""
+
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, msg)
+        self.code = code
+
+
+def lib_path():
+    for p in _LIB_CANDIDATES:
+        if p and os.path.exists(p):
+            return p
+    raise ImportError(
+        "libdeepcut_hip.so not found (looked in %s). Build it with `python deepcut-cnn_amd/build.py`; "
+        "there is no Python/CPU fallback for the forward path." % [p for p in _LIB_CANDIDATES if p])
+
+
+def _load():
+    lib = C.CDLL(lib_path())
+    vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
+    sig = {
+        "dc_last_error": (cp, []),
+        "dc_version": (cp, []),
+        "dc_set_mode": (ci, [ci]),
+        "dc_get_mode": (ci, []),
+        "dc_set_device": (ci, [ci]),
+        "dc_get_device": (ci, []),
+        "dc_device_count": (ci, []),
+        "dc_net_create": (ci, [cp, cp, ci, C.POINTER(vp)]),
+        "dc_net_create_from_text": (ci, [cp, cp, ci, C.POINTER(vp)]),
+        "dc_net_destroy": (ci, [vp]),
+        "dc_net_set_option": (ci, [vp, ci, ci]),
+        "dc_net_copy_from": (ci, [vp, cp]),
+        "dc_net_save": (ci, [vp, cp]),
+        "dc_net_name": (cp, [vp]),
+        "dc_net_num_layers": (ci, [vp]),
+        "dc_net_layer_name": (cp, [vp, ci]),
+        "dc_net_layer_type": (cp, [vp, ci]),
+        "dc_net_num_blobs": (ci, [vp]),
+        "dc_net_blob_name": (cp, [vp, ci]),
+        "dc_net_blob": (ci, [vp, cp, C.POINTER(vp)]),
+        "dc_net_num_inputs": (ci, [vp]),
+        "dc_net_input_name": (cp, [vp, ci]),
+        "dc_net_num_outputs": (ci, [vp]),
+        "dc_net_output_name": (cp, [vp, ci]),
+        "dc_net_layer_num_params": (ci, [vp, cp]),
+        "dc_net_param": (ci, [vp, cp, ci, C.POINTER(vp)]),
+        "dc_net_reshape": (ci, [vp]),
+        "dc_net_forward": (ci, [vp, ci, ci, C.POINTER(C.c_float)]),
+        "dc_net_forward_all": (ci, [vp]),
+        "dc_blob_num_axes": (ci, [vp]),
+        "dc_blob_shape": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "dc_blob_count": (ci, [vp]),
+        "dc_blob_reshape": (ci, [vp, ci, C.POINTER(ci)]),
+        "dc_blob_cpu_data": (ci, [vp, C.POINTER(C.POINTER(C.c_float))]),
+        "dc_blob_mutable_cpu_data": (ci, [vp, C.POINTER(C.POINTER(C.c_float))]),
+        "dc_blob_head": (ci, [vp]),
+        "dc_blob_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
+        "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
+        "dc_net_flops": (ci, [vp, C.POINTER(C.c_double)]),
+        "dc_net_num_launches": (ci, [vp]),
+        "dc_net_plan_text": (cp, [vp]),
+        "dc_net_profile_text": (cp, [vp, ci]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+_lib, EXPORTED_SYMBOLS = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise DeepcutError(rc, (_lib.dc_last_error() or b"").decode())
+
+
+def set_mode_cpu():
+    _check(_lib.dc_set_mode(0))
+
+
+def set_mode_gpu():
+    _check(_lib.dc_set_mode(1))
+
+
+def set_device(device_id):
+    _check(_lib.dc_set_device(int(device_id)))
+
+
+def device_count():
+    return _lib.dc_device_count()
+
+
+class Blob(object):
+    """caffe.Blob (_caffe.cpp:259-277).  `.data` is a writable float32 NCHW view of the blob's host
+    memory whose base object keeps the owning Net alive (python/caffe/test/test_net.py:48-60)."""
+
+    def __init__(self, handle, owner):
+        self._h = handle
+        self._owner = owner  # keeps the Net (and thus the memory) alive
+
+    @property
+    def shape(self):
+        n = C.c_int()
+        dims = (C.c_int * 8)()
+        _check(_lib.dc_blob_shape(self._h, C.byref(n), dims))
+        return tuple(dims[i] for i in range(n.value))
+
+    def _legacy(self, i):
+        s = self.shape
+        s = (1,) * (4 - len(s)) + s  # Blob::LegacyShape (blob.hpp:118-134)
+        return s[i]
+
+    num = property(lambda self: self._legacy(0))
+    channels = property(lambda self: self._legacy(1))
+    height = property(lambda self: self._legacy(2))
+    width = property(lambda self: self._legacy(3))
+    count = property(lambda self: _lib.dc_blob_count(self._h))
+
+    def reshape(self, *dims):
+        if len(dims) == 1 and hasattr(dims[0], "__len__"):
+            dims = tuple(dims[0])
+        arr = (C.c_int * len(dims))(*[int(d) for d in dims])
+        _check(_lib.dc_blob_reshape(self._h, len(dims), arr))
+
+    @property
+    def data(self):
+        p = C.POINTER(C.c_float)()
+        _check(_lib.dc_blob_mutable_cpu_data(self._h, C.byref(p)))  # Blob::mutable_cpu_data (_caffe.cpp:273)
+        shape = self.shape
+        n = int(np.prod(shape)) if shape else 1
+        buf = (C.c_float * n).from_address(C.addressof(p.contents))
+        buf._owner = self  # ndarray.base chain -> ctypes array -> Blob -> Net
+        return np.frombuffer(buf, dtype=np.float32).reshape(shape)
+
+    @property
+    def head(self):
+        return _lib.dc_blob_head(self._h)
+
+    def gpu_data(self):
+        """(device pointer of the NHWC image, channel pitch) — Blob::gpu_data."""
+        p = C.c_void_p()
+        pitch = C.c_int()
+        _check(_lib.dc_blob_gpu_data(self._h, C.byref(p), C.byref(pitch)))
+        return p.value, pitch.value
+
+
+class _NetHandle(object):
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        if self.h:
+            _lib.dc_net_destroy(self.h)
+            self.h = None
+
+
+class Net(object):
+    """caffe.Net(model_def, model_bin, phase) / caffe.Net(model_def, phase)  (_caffe.cpp:76-96,227-228)."""
+
+    def __init__(self, model_def, *args, **kw):
+        if len(args) == 2:
+            weights, phase = args
+        elif len(args) == 1:
+            weights, phase = None, args[0]
+        else:
+            raise TypeError("Net(model_def, [weights,] phase)")
+        h = C.c_void_p()
+        if kw.get("from_text"):
+            rc = _lib.dc_net_create_from_text(model_def.encode(), weights.encode() if weights else None, int(phase), C.byref(h))
+        else:
+            rc = _lib.dc_net_create(model_def.encode(), weights.encode() if weights else None, int(phase), C.byref(h))
+        _check(rc)
+        self._handle = _NetHandle(h)
+        self._h = h
+        if "fuse" in kw:
+            self.set_option(1, int(kw["fuse"]))
+        if "hipgraph" in kw:
+            self.set_option(2, int(kw["hipgraph"]))
+        self._blobs = None
+        self._params = None
+
+    def set_option(self, key, value):
+        _check(_lib.dc_net_set_option(self._h, int(key), int(value)))
+
+    # --- pycaffe.py:22-59 -----------------------------------------------------------------
+    @property
+    def blobs(self):
+        if self._blobs is None:
+            d = OrderedDict()
+            for i in range(_lib.dc_net_num_blobs(self._h)):
+                name = _lib.dc_net_blob_name(self._h, i)
+                bh = C.c_void_p()
+                _check(_lib.dc_net_blob(self._h, name, C.byref(bh)))
+                d[name.decode()] = Blob(bh, self._handle)
+            self._blobs = d
+        return self._blobs
+
+    @property
+    def _layer_names(self):
+        return [_lib.dc_net_layer_name(self._h, i).decode() for i in range(_lib.dc_net_num_layers(self._h))]
+
+    @property
+    def layer_types(self):
+        return [_lib.dc_net_layer_type(self._h, i).decode() for i in range(_lib.dc_net_num_layers(self._h))]
+
+    @property
+    def params(self):
+        if self._params is None:
+            d = OrderedDict()
+            for name in self._layer_names:
+                n = _lib.dc_net_layer_num_params(self._h, name.encode())
+                if n > 0:
+                    lst = []
+                    for j in range(n):
+                        bh = C.c_void_p()
+                        _check(_lib.dc_net_param(self._h, name.encode(), j, C.byref(bh)))
+                        lst.append(Blob(bh, self._handle))
+                    d[name] = lst
+            self._params = d
+        return self._params
+
+    @property
+    def inputs(self):
+        return [_lib.dc_net_input_name(self._h, i).decode() for i in range(_lib.dc_net_num_inputs(self._h))]
+
+    @property
+    def outputs(self):
+        return [_lib.dc_net_output_name(self._h, i).decode() for i in range(_lib.dc_net_num_outputs(self._h))]
+
+    @property
+    def name(self):
+        return _lib.dc_net_name(self._h).decode()
+
+    # --- pycaffe.py:62-108 ----------------------------------------------------------------
+    def _forward(self, start, end):
+        loss = C.c_float()
+        _check(_lib.dc_net_forward(self._h, int(start), int(end), C.byref(loss)))
+        return loss.value
+
+    def forward(self, blobs=None, start=None, end=None, **kwargs):
+        if blobs is None:
+            blobs = []
+        names = self._layer_names
+        start_ind = names.index(start) if start is not None else 0
+        if end is not None:
+            end_ind = names.index(end)
+            outputs = set([end] + blobs)
+        else:
+            end_ind = len(names) - 1
+            outputs = set(self.outputs + blobs)
+        if kwargs:
+            if set(kwargs.keys()) != set(self.inputs):
+                raise Exception("Input blob arguments do not match net inputs.")
+            for in_, blob in kwargs.items():
+                if blob.shape[0] != self.blobs[in_].num:
+                    raise Exception("Input is not batch sized")
+                self.blobs[in_].data[...] = blob
+        self._forward(start_ind, end_ind)
+        return {out: self.blobs[out].data for out in outputs}
+
+    def reshape(self):
+        _check(_lib.dc_net_reshape(self._h))
+
+    def copy_from(self, path):
+        _check(_lib.dc_net_copy_from(self._h, path.encode()))
+
+    def save(self, path):
+        _check(_lib.dc_net_save(self._h, path.encode()))
+
+    # --- extensions (no pycaffe counterpart) ---------------------------------------------------
+    def forward_batch(self, images, want=("prob", "loc_pred", "next_pred")):
+        """images: float32 [n,3,H,W] host array -> dict of NCHW host arrays (one batched launch plan)."""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        n, c, h, w = x.shape
+        self.blobs["data"].reshape(n, c, h, w)
+        self.reshape()
+        outs = {}
+        ptrs = {}
+        for k in ("prob", "loc_pred", "next_pred"):
+            if k in want:
+                outs[k] = np.empty(self.blobs[k].shape, np.float32)
+                ptrs[k] = outs[k].ctypes.data_as(C.c_void_p)
+            else:
+                ptrs[k] = None
+        _check(_lib.dc_net_forward_batch(self._h, x.ctypes.data_as(C.c_void_p), n, h, w, 0, ptrs["prob"],
+                                         ptrs["loc_pred"], ptrs["next_pred"], None))
+        return outs
+
+    def forward_device(self, in_ptr, n, h, w, prob_ptr=None, loc_ptr=None, next_ptr=None, stream=None):
+        """Device-resident batch: raw device pointers (e.g. torch tensor .data_ptr()), asynchronous on
+        `stream` when given."""
+        _check(_lib.dc_net_forward_batch(self._h, C.c_void_p(in_ptr), n, h, w, 1, C.c_void_p(prob_ptr or 0),
+                                         C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(stream or 0)))
+
+    def flops(self):
+        v = C.c_double()
+        _check(_lib.dc_net_flops(self._h, C.byref(v)))
+        return v.value
+
+    def num_launches(self):
+        return _lib.dc_net_num_launches(self._h)
+
+    def plan_text(self):
+        t = _lib.dc_net_plan_text(self._h)
+        if t is None:
+            _check(-1)
+        return t.decode()
+
+    def profile_text(self, iters=10):
+        t = _lib.dc_net_profile_text(self._h, iters)
+        if t is None:
+            raise DeepcutError(-1, (_lib.dc_last_error() or b"").decode())
+        return t.decode()

@@ -1,0 +1,6 @@
+"""Host-side tools of the MI355X DeeperCut path: model-definition generator, .caffemodel writer and
+the conditioned synthetic-weight generator used by tests and bench.py (the trained weights are not
+shipped with the reference: models/deepercut/download_models.sh fetches them)."""
+from .model_zoo import deepercut_prototxt, deepercut_layer_table  # noqa: F401
+from .caffemodel import write_caffemodel, read_caffemodel  # noqa: F401
+from .synth import synth_weights, write_synth_caffemodel  # noqa: F401

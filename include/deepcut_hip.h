@@ -1,0 +1,163 @@
+/*
+ * deepcut_hip.h — C ABI of libdeepcut_hip.so, the MI355X (gfx950) forward path of the
+ * DeeperCut part detector.
+ *
+ * This is the drop-in boundary for the ONE hot path of eldar/deepcut-cnn: the TEST-phase
+ * forward of models/deepercut/ResNet-152.prototxt behind caffe::Net::ForwardFromTo /
+ * pycaffe net.forward().  The reference has no C ABI (it binds C++ to Python through
+ * Boost.Python, python/caffe/_caffe.cpp); every entry point below names the reference
+ * interface it stands in for (file:line relative to the reference tree).  A maintainer
+ * binds these with ctypes / pybind / Boost.Python exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DC_E* code on failure; the message is
+ *     available from dc_last_error() (thread local).  Nothing aborts the process (the
+ *     reference LOG(FATAL)s; we never continue silently either).
+ *   - handles are opaque; a dc_blob* is owned by its net (or, for dc_blob_create, by the
+ *     caller) and stays valid until that owner is destroyed.
+ *   - host tensors are float32, C-contiguous NCHW exactly as caffe::Blob (blob.hpp:153-164).
+ *     Device tensors are channels-last (NHWC) float32; see DESIGN.md "Data layout in HBM".
+ *   - mode/device are per thread, like caffe::Caffe (common.cpp:13-20).
+ *   - there is NO CPU compute path in this library: dc_net_forward in CPU mode fails with
+ *     DC_ENOCPU.  The CPU restatement of the reference lives in oracle/ and is test-only.
+ */
+#ifndef DEEPCUT_HIP_H_
+#define DEEPCUT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK 0
+#define DC_EINVAL (-1)   /* bad argument / malformed model                         */
+#define DC_EIO (-2)      /* "Could not open file ..." (_caffe.cpp:45-52)            */
+#define DC_ESHAPE (-3)   /* shape / blob-count mismatch (net.cpp:822-834)           */
+#define DC_EUNSUP (-4)   /* layer type or parameter outside the supported path      */
+#define DC_EDEVICE (-5)  /* HIP runtime error / no gfx950 device                    */
+#define DC_ENOCPU (-6)   /* forward requested in CPU mode: not provided             */
+
+#define DC_MODE_CPU 0 /* caffe::Caffe::CPU (common.hpp:107) */
+#define DC_MODE_GPU 1 /* caffe::Caffe::GPU                  */
+#define DC_PHASE_TRAIN 0 /* caffe.proto:253-256 */
+#define DC_PHASE_TEST 1
+
+/* dc_net_set_option keys */
+#define DC_OPT_FUSE 1       /* 0: every named blob materialised (Caffe-visible semantics);
+                               1 (default): residual-add and head fusion                     */
+#define DC_OPT_HIPGRAPH 2   /* 1: replay the per-shape launch sequence as a hipGraph        */
+
+typedef struct dc_net dc_net;
+typedef struct dc_blob dc_blob;
+
+/* ---- error / context ---------------------------------------------------------------- */
+const char* dc_last_error(void);
+const char* dc_version(void);
+
+/* Caffe::set_mode / Caffe::mode  (common.hpp:148-150; _caffe.cpp:38-39)                  */
+int dc_set_mode(int mode);
+int dc_get_mode(void);
+/* Caffe::SetDevice (common.cpp:140-158; _caffe.cpp:221)                                  */
+int dc_set_device(int device_id);
+int dc_get_device(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails)                    */
+int dc_device_count(void);
+
+/* ---- Net ------------------------------------------------------------------------------ */
+/* Net<float>::Net(param_file, phase) + CopyTrainedLayersFrom(weights)
+ * (net.cpp:31-37,843-858; _caffe.cpp:76-96).  caffemodel may be NULL.                    */
+int dc_net_create(const char* prototxt_path, const char* caffemodel_path, int phase, dc_net** out);
+/* same, from an in-memory prototxt string                                                */
+int dc_net_create_from_text(const char* prototxt_text, const char* caffemodel_path, int phase,
+                            dc_net** out);
+int dc_net_destroy(dc_net* net);
+int dc_net_set_option(dc_net* net, int key, int value);
+/* Net::CopyTrainedLayersFrom(file) (net.cpp:805-858): match by layer name, check blob
+ * count and shape, ignore unmatched source layers.                                       */
+int dc_net_copy_from(dc_net* net, const char* caffemodel_path);
+/* Net::ToProto + WriteProtoToBinaryFile (net.cpp:910-925; _caffe.cpp:98-102)             */
+int dc_net_save(dc_net* net, const char* caffemodel_path);
+const char* dc_net_name(dc_net* net);
+
+/* Net::layer_names / layers()[i]->type() (net.hpp:126-133), AFTER InsertSplits           */
+int dc_net_num_layers(dc_net* net);
+const char* dc_net_layer_name(dc_net* net, int i);
+const char* dc_net_layer_type(dc_net* net, int i);
+/* Net::blob_names / blobs (net.hpp:122-125,135), creation order, split blobs included    */
+int dc_net_num_blobs(dc_net* net);
+const char* dc_net_blob_name(dc_net* net, int i);
+/* Net::blob_by_name (net.cpp:947-957); unknown name -> DC_EINVAL                         */
+int dc_net_blob(dc_net* net, const char* name, dc_blob** out);
+/* Net::input_blob_indices / output_blob_indices (net.hpp:182-189): outputs are the
+ * unconsumed blobs in alphabetical order (net.cpp:268-273)                               */
+int dc_net_num_inputs(dc_net* net);
+const char* dc_net_input_name(dc_net* net, int i);
+int dc_net_num_outputs(dc_net* net);
+const char* dc_net_output_name(dc_net* net, int i);
+/* Net::layers()[i]->blobs()[j]  (pycaffe net.params, pycaffe.py:40-51)                   */
+int dc_net_layer_num_params(dc_net* net, const char* layer_name);
+int dc_net_param(dc_net* net, const char* layer_name, int idx, dc_blob** out);
+
+/* Net::Reshape (net.cpp:744-749): propagate the current input shapes                     */
+int dc_net_reshape(dc_net* net);
+/* Net::ForwardFromTo(start, end) (net.cpp:565-581; _caffe.cpp:231 "_forward").  Layer
+ * indices are those of dc_net_layer_name.  Re-derives every shape from the current input
+ * shape (Layer::Forward calls Reshape, layer.hpp:451-456).  Synchronous: on return all
+ * outputs are computed.  *loss (may be NULL) receives 0 (no loss layers on this path).   */
+int dc_net_forward(dc_net* net, int start, int end, float* loss);
+/* Net::ForwardPrefilled convenience: whole net                                           */
+int dc_net_forward_all(dc_net* net);
+
+/* ---- Blob (caffe::Blob<float> + SyncedMemory) ----------------------------------------- */
+/* Blob::shape (blob.hpp:52-71).  dims must hold 4 ints (params may have 1 axis)          */
+int dc_blob_num_axes(dc_blob* b);
+int dc_blob_shape(dc_blob* b, int* ndim, int* dims /*[8]*/);
+int dc_blob_count(dc_blob* b);
+/* Blob::Reshape (blob.cpp:23-43; _caffe.cpp:181-193): capacity only grows                */
+int dc_blob_reshape(dc_blob* b, int ndim, const int* dims);
+/* Blob::cpu_data / mutable_cpu_data (blob.cpp:82-86,105-109 -> syncedmem.cpp:25-77,
+ * 103-128).  The pointer is host memory owned by the blob, NCHW, valid until a reshape
+ * grows the blob or the owner is destroyed.  mutable_: host becomes authoritative
+ * (HEAD_AT_CPU) so the next forward re-uploads; a pending device result is downloaded first. */
+int dc_blob_cpu_data(dc_blob* b, const float** out);
+int dc_blob_mutable_cpu_data(dc_blob* b, float** out);
+/* SyncedMemory::head() (syncedmem.hpp:59): 0 UNINITIALIZED 1 HEAD_AT_CPU 2 HEAD_AT_GPU 3 SYNCED */
+int dc_blob_head(dc_blob* b);
+/* Blob::gpu_data (blob.cpp:88-92): device pointer of the channels-last (NHWC) image of the
+ * blob, plus its channel pitch (>= channels; the 3-channel input is stored with pitch 4). */
+int dc_blob_gpu_data(dc_blob* b, const void** dev_ptr, int* channel_pitch);
+
+/* ---- batched / sharded extension (no reference counterpart: the reference forwards one
+ * image at a time, conv_layer.cpp:31).  Runs `n` same-shape images as one batch:
+ * inputs  : host or device NCHW float32 [n,3,H,W] (is_device selects)
+ * outputs : prob [n,14,h,w], loc_pred [n,28,h,w], next_pred [n,364,h,w] NCHW float32, host or
+ *           device like the input; any of them may be NULL to skip the copy-out.
+ * stream  : hipStream_t to enqueue on (NULL = the net's own stream); when a stream is given
+ *           and buffers are device-side the call is asynchronous.                         */
+int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
+                         float* prob, float* loc_pred, float* next_pred, void* stream);
+
+/* ---- Layer::Forward_gpu surface ---------------------------------------------------------
+ * One reference layer stand-alone = a one-layer prototxt given to dc_net_create_from_text with
+ * DC_OPT_FUSE 0, weights injected through dc_net_param + dc_blob_mutable_cpu_data: the CDNA4
+ * counterpart of src/caffe/layers/{conv,deconv,batch_norm,scale,relu,pooling,eltwise,crop,
+ * sigmoid}_layer Forward_gpu (tests/test_layers_gpu.py drives every layer type this way).   */
+
+/* ---- introspection used by bench.py / DESIGN.md ----------------------------------------- */
+/* algorithmic FLOPs (2*MAC of conv+deconv) of the current shape               */
+int dc_net_flops(dc_net* net, double* flops);
+/* number of kernel launches in the current plan                                           */
+int dc_net_num_launches(dc_net* net);
+/* human-readable launch plan of the current shape (kernel variant, tile, grid per op);
+ * pointer valid until the next call on this net                                           */
+const char* dc_net_plan_text(dc_net* net);
+/* time each op of the current plan with hipEvents on the net's stream (iters runs each);
+ * returns a text table (op, kernel, us, GFLOP, TFLOP/s); pointer valid until next call    */
+const char* dc_net_profile_text(dc_net* net, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCUT_HIP_H_ */
