@@ -4,3 +4,4 @@ shipped with the reference: models/deepercut/download_models.sh fetches them).""
 from .model_zoo import deepercut_prototxt, deepercut_layer_table  # noqa: F401
 from .caffemodel import write_caffemodel, read_caffemodel  # noqa: F401
 from .synth import synth_weights, write_synth_caffemodel  # noqa: F401
+from .shard import lpt_shards, gather_maps, gather_maps_known  # noqa: F401

@@ -74,17 +74,22 @@ def _f32(a):
 # ---------------------------------------------------------------------------------------------
 # single-layer entry points (NCHW float32 in / out)
 # ---------------------------------------------------------------------------------------------
+def _hw(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
 def conv_forward(x, w, bias=None, stride=1, pad=0, dilation=1):
+    """stride / pad / dilation: int or (h, w)."""
     x, w = _f32(x), _f32(w)
     n, c, h, wd = x.shape
     co, ci, kh, kw = w.shape
     assert ci == c
-    oh = (h + 2 * pad - (dilation * (kh - 1) + 1)) // stride + 1
-    ow = (wd + 2 * pad - (dilation * (kw - 1) + 1)) // stride + 1
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(pad), _hw(dilation)
+    oh = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    ow = (wd + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     y = np.empty((n, co, oh, ow), np.float32)
     b = _f32(bias) if bias is not None else None
-    lib().oracle_conv_forward(_p(x), n, c, h, wd, _p(w), _p(b), co, kh, kw, pad, pad, stride, stride, dilation,
-                              dilation, _p(y))
+    lib().oracle_conv_forward(_p(x), n, c, h, wd, _p(w), _p(b), co, kh, kw, ph, pw, sh, sw, dh, dw, _p(y))
     return y
 
 
