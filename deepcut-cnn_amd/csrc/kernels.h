@@ -12,7 +12,7 @@ struct ConvTap {
   int dy;
   int xoff;
   int klen;
-  int pad_;
+  int soff;  // (dy*x_row_stride + xoff) - x_bias  >= 0: uniform element displacement of this tap
 };
 
 constexpr int kMaxTaps = 49;
@@ -30,6 +30,7 @@ struct ConvGemmParams {
   int x_rows;         // H of the source
   int x_rowlen;       // valid elements in a row (W*C)
   int sy, sx;         // source step per output pixel: rows / elements
+  int x_bias;         // min over taps of (dy*x_row_stride + xoff) (<= 0), filled by launch_conv_gemm
   int ntaps;
   ConvTap taps[kMaxTaps];
   const float* w;

@@ -9,6 +9,8 @@
 // (src/caffe/layers/*.cu, src/caffe/util/im2col.cu, math_functions.cu) — see DESIGN.md.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace dc {
@@ -19,6 +21,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // gather-GEMM convolution
 // ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer addressing (V# descriptors): address = base + voffset(VGPR) + soffset(SGPR); an access whose
+// voffset is >= num_records returns 0 / is dropped.  This keeps the K loop almost free of VALU work —
+// which matters because on gfx950 the fp32 MFMA shares the SIMD's fp32 datapath: every VALU
+// instruction issued between MFMAs is paid IN ADDITION to them (tools/probes/mfma_probe.hip:
+// 143 TF/s bare, 91 TF/s with 8 VALU per MFMA, one or two waves per SIMD alike).
+//   * per-thread voffsets are loop invariant, the per-tile displacement (tap, channel block) is uniform
+//     and travels in soffset (SALU);
+//   * zero padding = out-of-range voffset (one v_cndmask per load from a precomputed tap-validity mask).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dc_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 dc_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+constexpr unsigned kOOB = 0x80000000u;  // > any tensor size: hardware returns 0
+
 template <int BM, int BN, int BK, int WR, int WC, int WK>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   static_assert(WR * WC * WK == 4, "4 waves per workgroup");
@@ -32,11 +53,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   static_assert(NA >= 1 && NBV >= 1, "tile too small for the loader");
   constexpr int KCH = BK / 8;            // 8-deep k chunks per tile
   static_assert(KCH % WK == 0, "k chunks must split evenly over WK");
+  constexpr int NCH = KCH / WK;          // chunks this wave owns per tile
+  static_assert(NCH >= 2 && NCH % 2 == 0, "the software pipeline needs an even number (>=2) of chunks per wave");
   constexpr int TILE = (BM + BN) * LDK;  // floats per LDS stage
   static_assert((WK - 1) * BM * BN <= 2 * TILE, "split-K partials must fit in the tile buffers");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 2 * BM];
-  long* rowoff = reinterpret_cast<long*>(smem + 2 * TILE);
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 4 * BM];
+  i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILE);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -50,52 +73,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int tile_m = blockIdx.x / tiles_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
-  const int ohw = p.OH * p.OW;
 
-  // output offsets of this tile's pixel rows (epilogue), -1 = outside the problem
+  // one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
   if (t < BM) {
-    int m = m0 + t;
-    long off = -1;
+    const int m = m0 + t;
+    i32x4 ri = {(int)kOOB, -(1 << 28), 0, -1};
     if (m < p.M) {
-      int n = m / ohw;
-      int rem = m - n * ohw;
-      int oy = rem / p.OW;
-      int ox = rem - oy * p.OW;
-      off = (long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride;
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw;
+      const int rem = m - n * ohw;
+      const int oy = rem / p.OW;
+      const int ox = rem - oy * p.OW;
+      ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * 4);
+      ri.y = oy * p.sy;
+      ri.z = ox * p.sx;
+      ri.w = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * 4);
     }
-    rowoff[t] = off;
+    rowinfo[t] = ri;
   }
+  __syncthreads();
 
   // loader state: this thread stages rows (t / C4) + RPP*i, float4 column (t % C4)
   const int lrow = t / C4;
   const int lc4 = (t % C4) * 4;
-  const float* arow[NA];
-  int aiy[NA], axe[NA];
+  unsigned avoff[NA], amask[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    int m = m0 + lrow + RPP * i;
-    if (m < p.M) {
-      int n = m / ohw;
-      int rem = m - n * ohw;
-      int oy = rem / p.OW;
-      int ox = rem - oy * p.OW;
-      aiy[i] = oy * p.sy;
-      axe[i] = ox * p.sx + lc4;
-      arow[i] = p.x + (long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + (ox * p.sx + lc4);
-    } else {
-      aiy[i] = -(1 << 28);  // every tap fails the row test
-      axe[i] = 0;
-      arow[i] = p.x;
+    const i32x4 ri = rowinfo[lrow + RPP * i];
+    avoff[i] = (unsigned)ri.x + lc4 * 4;
+    unsigned mk = 0;
+    for (int tp = 0; tp < p.ntaps; ++tp) {  // which taps fall inside the image for this pixel / column
+      const int iy = ri.y + p.taps[tp].dy;
+      const int xe = ri.z + lc4 + p.taps[tp].xoff;
+      const bool ok = (unsigned)iy < (unsigned)p.x_rows && (unsigned)xe < (unsigned)p.x_rowlen;
+      mk |= (ok ? 1u : 0u) << tp;
     }
+    amask[i] = mk;
   }
-  const float* brow[NBV];
-  bool bok[NBV];
+  unsigned bvoff[NBV];
 #pragma unroll
   for (int j = 0; j < NBV; ++j) {
-    int n = n0 + lrow + RPP * j;
-    bok[j] = n < p.Cout;
-    brow[j] = p.w + (long)(bok[j] ? n : 0) * p.Ktot + lc4;
+    const int n = n0 + lrow + RPP * j;
+    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lc4) * 4u : kOOB;  // rows past Cout read as zeros
   }
+  // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
+  // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
+  const __amdgpu_buffer_rsrc_t xr = dc_rsrc(p.x + p.x_bias, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(p.w, 0x7fffffffu);
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -106,33 +130,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int T = p.Ktot / BK;
-  int tap = 0, c0 = 0, kg = 0;
+  int tap = 0, c0 = 0, kg = 0;  // all uniform (SALU)
   f32x4 ra[NA], rb[NBV];
 
-  auto gload = [&]() {
+  auto gload_a = [&]() {
     const ConvTap tp = p.taps[tap];
-    const int doff = tp.dy * p.x_row_stride + tp.xoff + c0;
+    const unsigned soff = (unsigned)(tp.soff + c0) * 4u;
+    const unsigned bit = 1u << tap;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int iy = aiy[i] + tp.dy;
-      int xe = axe[i] + tp.xoff + c0;
-      bool ok = (unsigned)iy < (unsigned)p.x_rows && (unsigned)xe < (unsigned)p.x_rowlen;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(arow[i] + doff);
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < NBV; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bok[j]) v = *reinterpret_cast<const f32x4*>(brow[j] + kg);
-      rb[j] = v;
-    }
+    for (int i = 0; i < NA; ++i) ra[i] = dc_bload4(xr, (amask[i] & bit) ? avoff[i] : kOOB, soff);
     c0 += BK;
-    kg += BK;
     if (c0 >= tp.klen) {
       c0 = 0;
       ++tap;
     }
+  };
+  auto gload_b = [&]() {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) rb[j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * 4u);
+    kg += BK;
   };
   auto lstore = [&](int buf) {
     float* As = smem + buf * TILE;
@@ -144,37 +160,64 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int j = 0; j < NBV; ++j)
       *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LDK + lc4) = rb[j];
   };
-  auto compute = [&](int buf) {
-    const float* As = smem + buf * TILE + (wr * TM + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const float* Bs = smem + buf * TILE + BM * LDK + (wc * TN + (lane & 31)) * LDK + (lane >> 5) * 4;
+  // MFMA operand fragments, two register sets (chunk parity)
+  f32x4 av[2][FM], bv[2][FN];
+  const int frag_a = (wr * TM + (lane & 31)) * LDK + (lane >> 5) * 4 + wk * 8;
+  const int frag_b = BM * LDK + (wc * TN + (lane & 31)) * LDK + (lane >> 5) * 4 + wk * 8;
+  auto frag_load = [&](int buf, int q, int set) {
+    const float* As = smem + buf * TILE + frag_a + q * WK * 8;
+    const float* Bs = smem + buf * TILE + frag_b + q * WK * 8;
 #pragma unroll
-    for (int kc = wk; kc < KCH; kc += WK) {
-      f32x4 av[FM], bv[FN];
+    for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDK);
 #pragma unroll
-      for (int a = 0; a < FM; ++a) av[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDK + kc * 8);
+    for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK);
+  };
+
+  // Software pipeline.  A wave issues in order, so anything that is not interleaved BETWEEN MFMAs in
+  // program order is paid on top of them.  Per K-tile the wave owns NCH chunks of 4 MFMA steps; the
+  // non-MFMA work of the iteration is placed into those steps and pinned with sched_barrier:
+  //   chunk 0, step 0: ds_read the fragments of chunk 1
+  //            step 1: ds_write tile it+1 (registers loaded one iteration ago) into the idle LDS stage
+  //            step 2/3: issue the global loads of tile it+2 (A rows / filter rows)
+  //   chunk q, step 0: ds_read the fragments of chunk q+1
+  //   last chunk, step 1: barrier, then ds_read chunk 0 of tile it+1 from the stage just filled —
+  //            its latency is covered by the 3 remaining MFMA steps of this tile.
+  gload_a();
+  gload_b();
+  lstore(0);
+  if (T > 1) {
+    gload_a();
+    gload_b();
+  }
+  __syncthreads();
+  frag_load(0, 0, 0);
+  for (int it = 0; it < T; ++it) {
+    const int buf = it & 1;
+    const bool more1 = it + 1 < T, more2 = it + 2 < T;
 #pragma unroll
-      for (int b = 0; b < FN; ++b) bv[b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK + kc * 8);
+    for (int q = 0; q < NCH; ++q) {
+      const int cur = q & 1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int st = 0; st < 4; ++st) {
+        if (st == 0 && q + 1 < NCH) frag_load(buf, q + 1, cur ^ 1);
+        if (st == 1 && q + 1 == NCH && more1) {  // after step 0 has consumed (waited for) this chunk's operands
+          __syncthreads();
+          frag_load(buf ^ 1, 0, 0);
+        }
+        if (q == 0 && st == 1 && more1) lstore(buf ^ 1);
+        if (q == 0 && st == 2 && more2) gload_a();
+        if (q == 0 && st == 3 && more2) gload_b();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < FM; ++a)
 #pragma unroll
           for (int b = 0; b < FN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][s], bv[b][s], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  };
-
-  gload();
-  lstore(0);
-  __syncthreads();
-  for (int it = 0; it < T; ++it) {
-    const int buf = it & 1;
-    const bool more = it + 1 < T;
-    if (more) gload();
-    compute(buf);
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
   }
+  __syncthreads();
 
   // in-workgroup split-K: waves wk>0 hand their partial tiles to wave wk==0 through LDS
   if (WK > 1) {
@@ -205,6 +248,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   if (wk != 0) return;
 
   // fused epilogue.  MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
+  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(p.y, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(p.resid ? p.resid : p.y, 0x7fffffffu);
 #pragma unroll
   for (int b = 0; b < FN; ++b) {
     const int co = n0 + wc * TN + b * 32 + (lane & 31);
@@ -214,17 +259,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     const bool sig = co < p.sigmoid_ch;
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
+      unsigned off[16];
+      float rs[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const long off = rowoff[row];
-        if (off >= 0 && cok) {
-          float v = acc[a][b][r] * sc + sh;
-          if (p.resid) v += p.resid[off + co];
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (sig) v = 1.f / (1.f + expf(-v));
-          p.y[off + co] = v;
-        }
+        const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
+        off[r] = (yo >= 0 && cok) ? (unsigned)yo + co * 4 : kOOB;  // masked lanes: load 0 / store dropped
+      }
+      if (p.resid) {  // all 16 shortcut loads in flight at once
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rs[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[r], 0, 0));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[a][b][r] * sc + sh + rs[r];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (sig) v = 1.f / (1.f + expf(-v));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[r], 0, 0);
       }
     }
   }
@@ -250,7 +305,8 @@ const VariantEntry kVariants[] = {
     DC_VARIANT(32, 64, 64, 1, 2, 2),    // 5: in-workgroup split-K 2
     DC_VARIANT(64, 32, 64, 2, 1, 2),    // 6
     DC_VARIANT(32, 32, 128, 1, 1, 4),   // 7: split-K 4 (tiny M*N, long K: res4/res5)
-    DC_VARIANT(32, 32, 32, 1, 1, 4),    // 8: same for K segments that are only multiples of 32
+    DC_VARIANT(32, 32, 64, 1, 1, 4),    // 8: same for K segments that are only multiples of 64
+    DC_VARIANT(32, 64, 32, 1, 2, 2),    // 9: K segments that are only multiples of 32 (the stem)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -265,11 +321,19 @@ long conv_grid(const ConvGemmParams& p, int variant) {
   return tm * tn;
 }
 
-int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream) {
+int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   if (variant < 0 || variant >= kNumVariants) return (int)hipErrorInvalidValue;
   const VariantEntry& e = kVariants[variant];
-  for (int i = 0; i < p.ntaps; ++i)
+  ConvGemmParams p = p_in;
+  if (p.ntaps < 1 || p.ntaps > 32) return (int)hipErrorInvalidValue;  // tap-validity masks are 32 bits
+  int bias = 0;
+  for (int i = 0; i < p.ntaps; ++i) {
     if (p.taps[i].klen % e.BK != 0) return (int)hipErrorInvalidValue;
+    // a tap whose x-validity depends on the channel block (the row-tap stem) must be one K tile
+    bias = std::min(bias, p.taps[i].dy * p.x_row_stride + p.taps[i].xoff);
+  }
+  p.x_bias = bias;
+  for (int i = 0; i < p.ntaps; ++i) p.taps[i].soff = p.taps[i].dy * p.x_row_stride + p.taps[i].xoff - bias;
   long grid = conv_grid(p, variant);
   if (grid <= 0) return 0;
   hipLaunchKernelGGL(e.kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);

@@ -203,6 +203,7 @@ Net::~Net() {
   for (auto& v : vecs)
     if (v.dev) (void)hipFree(v.dev);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+  if (zero_page) (void)hipFree(zero_page);
 }
 
 Net* Net::create(const std::string& text, int phase) {
@@ -1030,6 +1031,10 @@ void Net::ensure_device() {
     hipStream_t s;
     HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     stream = s;
+  }
+  if (!zero_page) {
+    HIPCHECK(hipMalloc((void**)&zero_page, 256));
+    HIPCHECK(hipMemset(zero_page, 0, 256));
   }
 }
 

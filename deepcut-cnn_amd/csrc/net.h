@@ -135,6 +135,7 @@ struct Net {
   void* stream = nullptr;
   int device = -1;
   void* graph_exec = nullptr;
+  float* zero_page = nullptr;  // device zeros read by masked loads
   std::string text_buf;
 
   ~Net();
