@@ -6,23 +6,16 @@
 
 namespace dc {
 
-// One K-segment of the gather-GEMM: `klen` consecutive floats of the source row
-// (oy*sy + dy), starting at element (ox*sx + xoff); klen % 32 == 0.
-struct ConvTap {
-  int dy;
-  int xoff;
-  int klen;
-  int soff;  // (dy*x_row_stride + xoff) - x_bias  >= 0: uniform element displacement of this tap
-};
-
-constexpr int kMaxTaps = 49;
+constexpr int kMaxTaps = 32;  // tap-validity masks are one 32-bit word per staged row
 
 // out[pixel][co] = act( (sum_k A[pixel][k] * W[co][k]) * scale[co] + shift[co] (+ resid[pixel][co]) )
 //   pixel = (n, oy, ox) over an NB x OH x OW grid,
-//   A[pixel][.] = concatenation over taps of  x[n][oy*sy+dy][ox*sx+xoff .. +klen)   (0 outside the row/image),
-//   W packed [Cout][Ktot] with k contiguous (Ktot = sum klen).
+//   A[pixel][.] = concatenation over a (nty x ntx) grid of TAPS of `klen` consecutive floats of source row
+//                 oy*sy + dy0 + ty*ddy, starting at element ox*sx + x0 + tx*ddx  (0 outside the row/image),
+//   W packed [Cout][Ktot] with k contiguous, taps in (ty, tx) order (Ktot = nty*ntx*klen).
 // Covers every Convolution of the path (1x1, 1x1 stride 2, 3x3, dilated 3x3, the 7x7 stem seen as
 // 7 row-taps of 8 NHWC4 pixels) and, per output-parity class, the stride-2 Deconvolution heads.
+// The tap grid is arithmetic so the kernel advances it with scalar adds (no table loads in the K loop).
 struct ConvGemmParams {
   const float* x;
   long x_img_stride;  // elements between images
@@ -30,9 +23,11 @@ struct ConvGemmParams {
   int x_rows;         // H of the source
   int x_rowlen;       // valid elements in a row (W*C)
   int sy, sx;         // source step per output pixel: rows / elements
-  int x_bias;         // min over taps of (dy*x_row_stride + xoff) (<= 0), filled by launch_conv_gemm
-  int ntaps;
-  ConvTap taps[kMaxTaps];
+  int nty, ntx;       // tap grid
+  int dy0, ddy;       // source-row offset of tap row ty: dy0 + ty*ddy
+  int x0, ddx;        // element offset of tap column tx: x0 + tx*ddx
+  int klen;           // K elements per tap (multiple of the variant's BK)
+  int x_bias;         // min over taps of (dy*x_row_stride + xoff) (<= 0); filled by launch_conv_gemm
   const float* w;
   int Ktot;
   int NB, OH, OW;
@@ -47,6 +42,7 @@ struct ConvGemmParams {
   const float* shift;  // [Cout] or null (=0)
   int relu;
   int sigmoid_ch;  // channels [0, sigmoid_ch) get the logistic
+  long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
 };
 
 // Tile variants of conv_gemm.  BM x BN output tile per 256-thread workgroup, 4 waves arranged

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -40,15 +41,17 @@ __device__ __forceinline__ f32x4 dc_bload4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 constexpr unsigned kOOB = 0x80000000u;  // > any tensor size: hardware returns 0
 
-template <int BM, int BN, int BK, int WR, int WC, int WK>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
-  static_assert(WR * WC * WK == 4, "4 waves per workgroup");
+template <int BM, int BN, int BK, int WR, int WC, int WK, int PF>
+__global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int NW = WR * WC * WK;       // waves per workgroup (4 or 8)
+  constexpr int NT = NW * 64;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int LDK = BK + 4;            // padded LDS row, floats (16-B aligned, bank-spread)
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1 && TM % 32 == 0 && TN % 32 == 0, "wave tile = multiples of 32x32");
   constexpr int C4 = BK / 4;             // float4 per tile row
-  constexpr int RPP = 256 / C4;          // tile rows covered by one pass of the 256 threads
+  constexpr int RPP = NT / C4;           // tile rows covered by one pass of the workgroup's threads
   constexpr int NA = BM / RPP, NBV = BN / RPP;
   static_assert(NA >= 1 && NBV >= 1, "tile too small for the loader");
   constexpr int KCH = BK / 8;            // 8-deep k chunks per tile
@@ -56,7 +59,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   constexpr int NCH = KCH / WK;          // chunks this wave owns per tile
   static_assert(NCH >= 2 && NCH % 2 == 0, "the software pipeline needs an even number (>=2) of chunks per wave");
   constexpr int TILE = (BM + BN) * LDK;  // floats per LDS stage
+  constexpr int RPW = 16 / WK;           // accumulator registers each split-K wave finalises
   static_assert((WK - 1) * BM * BN <= 2 * TILE, "split-K partials must fit in the tile buffers");
+  constexpr bool EARLY_RESID = FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
 
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 4 * BM];
   i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILE);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
@@ -73,8 +78,49 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int tile_m = blockIdx.x / tiles_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  const int T = p.Ktot / BK;
+  auto stamp = [&](int slot) {
+    if (p.dbg && lane == 0) {
+      long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
+      d[slot] = slot < 4 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter();
+    }
+  };
+  stamp(0);
+  stamp(4);
 
-  // one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
+  // ---- prologue, ordered so that every exposed memory round trip overlaps another -------------------
+  // (1) filter rows need no pixel decode: their first PF tiles go out immediately
+  const int lrow = t / C4;
+  const int lc4 = (t % C4) * 4;
+  unsigned bvoff[NBV];
+#pragma unroll
+  for (int j = 0; j < NBV; ++j) {
+    const int n = n0 + lrow + RPP * j;
+    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lc4) * 4u : kOOB;  // rows past Cout read as zeros
+  }
+  const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(p.w, 0x7fffffffu);
+  f32x4 ra[PF][NA], rb[PF][NBV];
+  int kg = 0;
+  auto gload_b = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < NBV; ++j) rb[slot][j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * 4u);
+    kg += BK;
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (k < T) gload_b(k);
+
+  // (2) epilogue constants (folded BatchNorm/Scale/bias) also travel now
+  float sc[FN], sh[FN];
+#pragma unroll
+  for (int b = 0; b < FN; ++b) {
+    const int co = n0 + wc * TN + b * 32 + (lane & 31);
+    const bool cok = co < p.Cout;
+    sc[b] = (cok && p.scale) ? p.scale[co] : 1.f;
+    sh[b] = (cok && p.shift) ? p.shift[co] : 0.f;
+  }
+
+  // (3) one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
   if (t < BM) {
     const int m = m0 + t;
     i32x4 ri = {(int)kOOB, -(1 << 28), 0, -1};
@@ -93,33 +139,72 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   }
   __syncthreads();
 
-  // loader state: this thread stages rows (t / C4) + RPP*i, float4 column (t % C4)
-  const int lrow = t / C4;
-  const int lc4 = (t % C4) * 4;
+  // (4) activation rows: loop-invariant voffset + validity bit per tap (zero padding = OOB voffset)
   unsigned avoff[NA], amask[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const i32x4 ri = rowinfo[lrow + RPP * i];
     avoff[i] = (unsigned)ri.x + lc4 * 4;
     unsigned mk = 0;
-    for (int tp = 0; tp < p.ntaps; ++tp) {  // which taps fall inside the image for this pixel / column
-      const int iy = ri.y + p.taps[tp].dy;
-      const int xe = ri.z + lc4 + p.taps[tp].xoff;
-      const bool ok = (unsigned)iy < (unsigned)p.x_rows && (unsigned)xe < (unsigned)p.x_rowlen;
-      mk |= (ok ? 1u : 0u) << tp;
+    int bit = 0;
+    for (int ty = 0; ty < p.nty; ++ty) {
+      const bool rok = (unsigned)(ri.y + p.dy0 + ty * p.ddy) < (unsigned)p.x_rows;
+      for (int tx = 0; tx < p.ntx; ++tx, ++bit) {
+        const bool ok = rok && (unsigned)(ri.z + lc4 + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen;
+        mk |= (ok ? 1u : 0u) << bit;
+      }
     }
     amask[i] = mk;
-  }
-  unsigned bvoff[NBV];
-#pragma unroll
-  for (int j = 0; j < NBV; ++j) {
-    const int n = n0 + lrow + RPP * j;
-    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lc4) * 4u : kOOB;  // rows past Cout read as zeros
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
   // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
   const __amdgpu_buffer_rsrc_t xr = dc_rsrc(p.x + p.x_bias, 0x7fffffffu);
-  const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(p.w, 0x7fffffffu);
+  // tap cursor, all uniform (SALU): (tx, c0, running bit) and the element displacement of the current tap
+  int tx = 0, c0 = 0, tbit = 0;
+  int row_soff = p.dy0 * p.x_row_stride + p.x0 - p.x_bias;  // displacement of tap (ty, 0)
+  int tap_soff = row_soff;
+  auto gload_a = [&](int slot) {
+    const unsigned soff = (unsigned)(tap_soff + c0) * 4u;
+    const unsigned bit = 1u << tbit;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[slot][i] = dc_bload4(xr, (amask[i] & bit) ? avoff[i] : kOOB, soff);
+    c0 += BK;
+    if (c0 >= p.klen) {
+      c0 = 0;
+      ++tbit;
+      ++tx;
+      tap_soff += p.ddx;
+      if (tx >= p.ntx) {
+        tx = 0;
+        row_soff += p.ddy * p.x_row_stride;
+        tap_soff = row_soff;
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (k < T) gload_a(k);
+
+  // (5) output addressing of the rows this wave will finalise, and (small tiles) the shortcut itself.
+  //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
+  //     With in-workgroup split-K every one of the WK waves finalises RPW of the 16 accumulator registers.
+  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(p.y, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(p.resid ? p.resid : p.y, 0x7fffffffu);
+  float rs[EARLY_RESID ? FM * FN * RPW : 1];
+  if (EARLY_RESID && p.resid) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int e = 0; e < RPW; ++e) {
+          const int r = wk * RPW + e;
+          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
+          const int co = n0 + wc * TN + b * 32 + (lane & 31);
+          const unsigned off = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * 4 : kOOB;
+          rs[(a * FN + b) * RPW + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 0));
+        }
+  }
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -129,36 +214,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int T = p.Ktot / BK;
-  int tap = 0, c0 = 0, kg = 0;  // all uniform (SALU)
-  f32x4 ra[NA], rb[NBV];
-
-  auto gload_a = [&]() {
-    const ConvTap tp = p.taps[tap];
-    const unsigned soff = (unsigned)(tp.soff + c0) * 4u;
-    const unsigned bit = 1u << tap;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = dc_bload4(xr, (amask[i] & bit) ? avoff[i] : kOOB, soff);
-    c0 += BK;
-    if (c0 >= tp.klen) {
-      c0 = 0;
-      ++tap;
-    }
-  };
-  auto gload_b = [&]() {
-#pragma unroll
-    for (int j = 0; j < NBV; ++j) rb[j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * 4u);
-    kg += BK;
-  };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int slot) {
     float* As = smem + buf * TILE;
     float* Bs = As + BM * LDK;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDK + lc4) = ra[i];
+      *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDK + lc4) = ra[slot][i];
 #pragma unroll
     for (int j = 0; j < NBV; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LDK + lc4) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LDK + lc4) = rb[slot][j];
   };
   // MFMA operand fragments, two register sets (chunk parity)
   f32x4 av[2][FM], bv[2][FN];
@@ -173,116 +237,143 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK);
   };
 
-  // Software pipeline.  A wave issues in order, so anything that is not interleaved BETWEEN MFMAs in
-  // program order is paid on top of them.  Per K-tile the wave owns NCH chunks of 4 MFMA steps; the
-  // non-MFMA work of the iteration is placed into those steps and pinned with sched_barrier:
+  // ---- K loop: software pipeline -------------------------------------------------------------------
+  // A wave issues in order, and on gfx950 the fp32 MFMA shares the SIMD's fp32 datapath with VALU, so
+  // (a) VALU work in the loop is paid on top of the MFMAs -> there is almost none (buffer addressing);
+  // (b) anything not interleaved BETWEEN MFMAs in program order stalls the matrix pipe -> the loop's
+  //     non-MFMA work is placed into the 4 MFMA steps of each 8-deep chunk and pinned with sched_barrier:
   //   chunk 0, step 0: ds_read the fragments of chunk 1
-  //            step 1: ds_write tile it+1 (registers loaded one iteration ago) into the idle LDS stage
-  //            step 2/3: issue the global loads of tile it+2 (A rows / filter rows)
+  //            step 1: ds_write tile it+1 (ring slot loaded PF iterations ago) into the idle LDS stage
+  //            step 2/3: issue the global loads of tile it+1+PF into the ring slot just freed
   //   chunk q, step 0: ds_read the fragments of chunk q+1
   //   last chunk, step 1: barrier, then ds_read chunk 0 of tile it+1 from the stage just filled —
   //            its latency is covered by the 3 remaining MFMA steps of this tile.
-  gload_a();
-  gload_b();
-  lstore(0);
-  if (T > 1) {
-    gload_a();
-    gload_b();
+  // Tile k lives in ring slot k % PF: filters are streamed from HBM once per forward (263 MB per image
+  // sweep the 256 MB Infinity Cache), so a single tile of lookahead does not cover their latency.
+  lstore(0, 0);
+  if (PF < T) {
+    gload_a(0);
+    gload_b(0);
   }
   __syncthreads();
   frag_load(0, 0, 0);
-  for (int it = 0; it < T; ++it) {
-    const int buf = it & 1;
-    const bool more1 = it + 1 < T, more2 = it + 2 < T;
+  stamp(1);
+  stamp(5);
+  for (int it0 = 0; it0 < T; it0 += PF) {
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-      const int cur = q & 1;
+    for (int u = 0; u < PF; ++u) {
+      const int it = it0 + u;
+      if (it >= T) break;
+      const int buf = it & 1;
+      const int slot = (u + 1) % PF;  // ring slot of tile it+1 (it0 is a multiple of PF)
+      const bool more1 = it + 1 < T, moreP = it + 1 + PF < T;
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        if (st == 0 && q + 1 < NCH) frag_load(buf, q + 1, cur ^ 1);
-        if (st == 1 && q + 1 == NCH && more1) {  // after step 0 has consumed (waited for) this chunk's operands
-          __syncthreads();
-          frag_load(buf ^ 1, 0, 0);
+      for (int q = 0; q < NCH; ++q) {
+        const int cur = q & 1;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          if (st == 0 && q + 1 < NCH) frag_load(buf, q + 1, cur ^ 1);
+          if (st == 1 && q + 1 == NCH && more1) {  // after step 0 has consumed (waited for) this chunk's operands
+            __syncthreads();
+            frag_load(buf ^ 1, 0, 0);
+          }
+          if (q == 0 && st == 1 && more1) lstore(buf ^ 1, slot);
+          if (q == 0 && st == 2 && moreP) gload_a(slot);
+          if (q == 0 && st == 3 && moreP) gload_b(slot);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (q == 0 && st == 1 && more1) lstore(buf ^ 1);
-        if (q == 0 && st == 2 && more2) gload_a();
-        if (q == 0 && st == 3 && more2) gload_b();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  __syncthreads();
 
-  // in-workgroup split-K: waves wk>0 hand their partial tiles to wave wk==0 through LDS
+  stamp(2);
+  stamp(6);
+  // ---- epilogue ---------------------------------------------------------------------------------------
+  // in-workgroup split-K: wave wk keeps registers [wk*RPW, (wk+1)*RPW) of every fragment and receives
+  // the other waves' partials for them through LDS, so all four waves store (no idle waves, 1/WK of the
+  // LDS traffic of a gather-to-one reduction)
   if (WK > 1) {
-    float* part = smem;  // tile buffers are free after the last barrier
-    if (wk > 0) {
-      float* dst = part + (((wk - 1) * WR * WC + wr * WC + wc) * FM * FN) * 16 * 64 + lane;
+    __syncthreads();  // tile buffers are free
+    float* part = smem;
+    // layout: [dst wave q][src wave (wk != q) slot][wr*WC+wc][a][b][e][lane]
+#pragma unroll
+    for (int q = 0; q < WK; ++q) {
+      if (q == wk) continue;
+      const int srcslot = wk < q ? wk : wk - 1;
+      float* dst = part + ((((q * (WK - 1) + srcslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((a * FN + b) * 16 + r) * 64] = acc[a][b][r];
+          for (int e = 0; e < RPW; ++e) dst[((a * FN + b) * RPW + e) * 64] = acc[a][b][q * RPW + e];
     }
     __syncthreads();
-    if (wk == 0) {
 #pragma unroll
-      for (int q = 1; q < WK; ++q) {
-        const float* src = part + (((q - 1) * WR * WC + wr * WC + wc) * FM * FN) * 16 * 64 + lane;
+    for (int sslot = 0; sslot < WK - 1; ++sslot) {
+      const float* src = part + ((((wk * (WK - 1) + sslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
 #pragma unroll
-        for (int a = 0; a < FM; ++a)
+      for (int a = 0; a < FM; ++a)
 #pragma unroll
-          for (int b = 0; b < FN; ++b)
+        for (int b = 0; b < FN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * FN + b) * 16 + r) * 64];
-      }
+          for (int e = 0; e < RPW; ++e) {
+            // runtime register index only inside fully unrolled code: wk is wave-uniform but not constant,
+            // so select with a compile-time loop over the WK possibilities
+#pragma unroll
+            for (int w2 = 0; w2 < WK; ++w2)
+              if (w2 == wk) acc[a][b][w2 * RPW + e] += src[((a * FN + b) * RPW + e) * 64];
+          }
     }
   }
-  if (wk != 0) return;
 
-  // fused epilogue.  MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
-  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(p.y, 0x7fffffffu);
-  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(p.resid ? p.resid : p.y, 0x7fffffffu);
 #pragma unroll
   for (int b = 0; b < FN; ++b) {
     const int co = n0 + wc * TN + b * 32 + (lane & 31);
     const bool cok = co < p.Cout;
-    const float sc = (cok && p.scale) ? p.scale[co] : 1.f;
-    const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
     const bool sig = co < p.sigmoid_ch;
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
-      unsigned off[16];
-      float rs[16];
+      unsigned off[RPW];
+      float rv[RPW];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int e = 0; e < RPW; ++e) {
+        const int r = wk * RPW + e;
         const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
-        off[r] = (yo >= 0 && cok) ? (unsigned)yo + co * 4 : kOOB;  // masked lanes: load 0 / store dropped
+        off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * 4 : kOOB;  // masked lanes: load 0 / store dropped
       }
-      if (p.resid) {  // all 16 shortcut loads in flight at once
+      if (EARLY_RESID) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rs[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[r], 0, 0));
+        for (int e = 0; e < RPW; ++e) rv[e] = p.resid ? rs[(a * FN + b) * RPW + e] : 0.f;
+      } else if (p.resid) {  // all shortcut loads of the fragment in flight at once
+#pragma unroll
+        for (int e = 0; e < RPW; ++e)
+          rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[e], 0, 0));
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+        for (int e = 0; e < RPW; ++e) rv[e] = 0.f;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[a][b][r] * sc + sh + rs[r];
+      for (int e = 0; e < RPW; ++e) {
+        float accv = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WK; ++w2)
+          if (w2 == wk) accv = acc[a][b][w2 * RPW + e];
+        float v = accv * sc[b] + sh[b] + rv[e];
         if (p.relu) v = fmaxf(v, 0.f);
         if (sig) v = 1.f / (1.f + expf(-v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[r], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[e], 0, 0);
       }
     }
   }
+  stamp(3);
+  stamp(7);
 }
 
 namespace {
@@ -291,22 +382,30 @@ struct VariantEntry {
   void (*kernel)(const ConvGemmParams);
   int BK;
 };
-#define DC_VARIANT(BM, BN, BK, WR, WC, WK)                                   \
-  {                                                                          \
-    {#BM "x" #BN "x" #BK "_w" #WR #WC #WK, BM, BN, WR, WC, WK},              \
-        conv_gemm_kernel<BM, BN, BK, WR, WC, WK>, BK                         \
+#define DC_VARIANT(BM, BN, BK, WR, WC, WK, PF)                                     \
+  {                                                                                \
+    {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
+        conv_gemm_kernel<BM, BN, BK, WR, WC, WK, PF>, BK                           \
   }
 const VariantEntry kVariants[] = {
-    DC_VARIANT(128, 128, 32, 2, 2, 1),  // 0: big-M layers (res2/res3)
-    DC_VARIANT(128, 64, 32, 2, 2, 1),   // 1
-    DC_VARIANT(64, 128, 32, 2, 2, 1),   // 2
-    DC_VARIANT(64, 64, 32, 2, 2, 1),    // 3
-    DC_VARIANT(64, 64, 64, 2, 2, 1),    // 4
-    DC_VARIANT(32, 64, 64, 1, 2, 2),    // 5: in-workgroup split-K 2
-    DC_VARIANT(64, 32, 64, 2, 1, 2),    // 6
-    DC_VARIANT(32, 32, 128, 1, 1, 4),   // 7: split-K 4 (tiny M*N, long K: res4/res5)
-    DC_VARIANT(32, 32, 64, 1, 1, 4),    // 8: same for K segments that are only multiples of 64
-    DC_VARIANT(32, 64, 32, 1, 2, 2),    // 9: K segments that are only multiples of 32 (the stem)
+    DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
+    DC_VARIANT(128, 64, 32, 2, 2, 1, 2),   // 1
+    DC_VARIANT(64, 128, 32, 2, 2, 1, 2),   // 2
+    DC_VARIANT(64, 64, 32, 2, 2, 1, 3),    // 3
+    DC_VARIANT(64, 64, 64, 2, 2, 1, 3),    // 4
+    DC_VARIANT(32, 64, 64, 1, 2, 2, 4),    // 5: in-workgroup split-K 2
+    DC_VARIANT(64, 32, 64, 2, 1, 2, 4),    // 6
+    DC_VARIANT(32, 32, 128, 1, 1, 4, 3),   // 7: split-K 4 (tiny M*N, long K: res4/res5)
+    DC_VARIANT(32, 32, 64, 1, 1, 4, 4),    // 8: same for K segments that are only multiples of 64
+    DC_VARIANT(32, 64, 32, 1, 2, 2, 4),    // 9: K segments that are only multiples of 32 (the stem)
+    // 8-wave workgroups: two waves per SIMD, so one wave's LDS/global/SALU work hides under the other's MFMAs
+    DC_VARIANT(32, 64, 64, 1, 2, 4, 4),    // 10
+    DC_VARIANT(64, 64, 64, 2, 2, 2, 3),    // 11
+    DC_VARIANT(128, 64, 32, 2, 2, 2, 2),   // 12
+    DC_VARIANT(128, 128, 32, 2, 2, 2, 2),  // 13
+    DC_VARIANT(64, 64, 32, 2, 2, 2, 3),    // 14
+    DC_VARIANT(32, 32, 128, 1, 1, 8, 3),   // 15
+    DC_VARIANT(64, 128, 32, 2, 2, 2, 2),   // 16
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -325,18 +424,17 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   if (variant < 0 || variant >= kNumVariants) return (int)hipErrorInvalidValue;
   const VariantEntry& e = kVariants[variant];
   ConvGemmParams p = p_in;
-  if (p.ntaps < 1 || p.ntaps > 32) return (int)hipErrorInvalidValue;  // tap-validity masks are 32 bits
-  int bias = 0;
-  for (int i = 0; i < p.ntaps; ++i) {
-    if (p.taps[i].klen % e.BK != 0) return (int)hipErrorInvalidValue;
-    // a tap whose x-validity depends on the channel block (the row-tap stem) must be one K tile
-    bias = std::min(bias, p.taps[i].dy * p.x_row_stride + p.taps[i].xoff);
-  }
+  const int ntaps = p.nty * p.ntx;
+  if (ntaps < 1 || ntaps > kMaxTaps || p.klen % e.BK != 0 || p.Ktot != ntaps * p.klen) return (int)hipErrorInvalidValue;
+  int bias = 0;  // most negative tap displacement: one of the four corners of the arithmetic grid
+  for (int ty : {0, p.nty - 1})
+    for (int tx : {0, p.ntx - 1})
+      bias = std::min(bias, (p.dy0 + ty * p.ddy) * p.x_row_stride + p.x0 + tx * p.ddx);
   p.x_bias = bias;
-  for (int i = 0; i < p.ntaps; ++i) p.taps[i].soff = p.taps[i].dy * p.x_row_stride + p.taps[i].xoff - bias;
   long grid = conv_grid(p, variant);
   if (grid <= 0) return 0;
-  hipLaunchKernelGGL(e.kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+  const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
+  hipLaunchKernelGGL(e.kernel, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 

@@ -203,7 +203,6 @@ Net::~Net() {
   for (auto& v : vecs)
     if (v.dev) (void)hipFree(v.dev);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
-  if (zero_page) (void)hipFree(zero_page);
 }
 
 Net* Net::create(const std::string& text, int phase) {
@@ -565,10 +564,12 @@ double variant_cost(const ConvGemmParams& p, int v) {
   const ConvVariant& cv = conv_variant(v);
   int bk = conv_variant_bk(v);
   int FM = cv.BM / cv.WR / 32, FN = cv.BN / cv.WC / 32;
+  const double wps = cv.WR * cv.WC * cv.WK / 4.0;  // waves per SIMD of one workgroup
   double wgs = (double)conv_grid(p, v);
   double mfma = (double)FM * FN * (p.Ktot / 2.0) / cv.WK * 64.0;
   double tiles = (double)p.Ktot / bk;
-  double per_wg = mfma + tiles * 220.0 + 2500.0;
+  // the matrix pipe serialises the MFMAs of co-resident waves; a second wave hides most per-tile overhead
+  double per_wg = mfma * wps + tiles * (wps > 1 ? 60.0 : 220.0) + 2500.0;
   double rounds = std::ceil(wgs / 256.0);
   // the matrix pipe is shared by co-resident waves, so rounds serialise; partial last round costs a full one
   double t_mfma = rounds * per_wg;
@@ -856,8 +857,13 @@ void Net::build_plan() {
                                        " channels needs dilation_w 1 (row-tap path) or a multiple of 32 channels");
         int klen = (c.kw * CP + 31) / 32 * 32;
         if (c.kh > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': kernel too tall");
-        g.ntaps = c.kh;
-        for (int ky = 0; ky < c.kh; ++ky) g.taps[ky] = ConvTap{ky * c.dh - c.ph, -c.pw * CP, klen, 0};
+        g.nty = c.kh;
+        g.ntx = 1;
+        g.dy0 = -c.ph;
+        g.ddy = c.dh;
+        g.x0 = -c.pw * CP;
+        g.ddx = 0;
+        g.klen = klen;
         g.Ktot = c.kh * klen;
         kgcd = klen;
         l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
@@ -870,12 +876,16 @@ void Net::build_plan() {
                   h[(size_t)co * g.Ktot + ky * klen + kx * CP + ci] = w[(((size_t)co * C + ci) * c.kh + ky) * c.kw + kx];
         });
       } else {
-        if (c.kh * c.kw > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': kernel larger than 7x7");
-        g.ntaps = c.kh * c.kw;
-        for (int ky = 0; ky < c.kh; ++ky)
-          for (int kx = 0; kx < c.kw; ++kx)
-            g.taps[ky * c.kw + kx] = ConvTap{ky * c.dh - c.ph, (kx * c.dw - c.pw) * CP, CP, 0};
-        g.Ktot = g.ntaps * CP;
+        if (c.kh * c.kw > kMaxTaps)
+          throw DcError(DC_EUNSUP, "layer '" + L.name + "': more than " + std::to_string(kMaxTaps) + " kernel taps");
+        g.nty = c.kh;
+        g.ntx = c.kw;
+        g.dy0 = -c.ph;
+        g.ddy = c.dh;
+        g.x0 = -c.pw * CP;
+        g.ddx = c.dw * CP;
+        g.klen = CP;
+        g.Ktot = c.kh * c.kw * CP;
         kgcd = CP;
         l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
           h.assign((size_t)c.num_output * g.Ktot, 0.f);
@@ -945,12 +955,22 @@ void Net::build_plan() {
           g.x_rowlen = W * CP;
           g.sy = 1;
           g.sx = CP;
-          g.ntaps = (int)(tky.size() * tkx.size());
-          if (g.ntaps > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': too many taps");
-          int ti = 0;
-          for (auto& a : tky)
-            for (auto& b : tkx) g.taps[ti++] = ConvTap{a.second + i0, (b.second + j0) * CP, CP, 0};
-          g.Ktot = g.ntaps * CP;
+          const int ntaps = (int)(tky.size() * tkx.size());
+          if (ntaps > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': too many taps");
+          if (ntaps == 0) throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution with kernel smaller than stride");
+          // the taps of a residue class form an arithmetic grid (k advances by s/gcd(s,d))
+          g.nty = (int)tky.size();
+          g.ntx = (int)tkx.size();
+          g.dy0 = tky[0].second + i0;
+          g.ddy = tky.size() > 1 ? tky[1].second - tky[0].second : 0;
+          g.x0 = (tkx[0].second + j0) * CP;
+          g.ddx = tkx.size() > 1 ? (tkx[1].second - tkx[0].second) * CP : 0;
+          for (size_t q = 1; q < tky.size(); ++q)
+            if (tky[q].second - tky[q - 1].second != g.ddy) throw DcError(DC_EUNSUP, "layer '" + L.name + "': irregular tap grid");
+          for (size_t q = 1; q < tkx.size(); ++q)
+            if ((tkx[q].second - tkx[q - 1].second) * CP != g.ddx) throw DcError(DC_EUNSUP, "layer '" + L.name + "': irregular tap grid");
+          g.klen = CP;
+          g.Ktot = ntaps * CP;
           g.NB = N;
           g.OH = nh;
           g.OW = nw;
@@ -963,11 +983,6 @@ void Net::build_plan() {
           g.relu = op.relu;
           g.sigmoid_ch = op.sigmoid ? OC : 0;
           affine_vecs(op, l, OC);
-          if (g.ntaps == 0) {
-            // a class no kernel tap reaches (k < s): output = bias only; run it as a 1-tap GEMM over a
-            // zero-length... not reachable for k >= s; refuse rather than emit garbage
-            throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution with kernel smaller than stride");
-          }
           l.w = get_vec("w:" + std::to_string(op.wl) + ":" + std::to_string(ry) + "," + std::to_string(rx),
                         [&](std::vector<float>& h) {
                           h.assign((size_t)OC * g.Ktot, 0.f);
@@ -982,7 +997,7 @@ void Net::build_plan() {
                               ++t2;
                             }
                         });
-          l.flops = 2.0 * g.M * (double)OC * C * g.ntaps;
+          l.flops = 2.0 * g.M * (double)OC * C * ntaps;
           choose_variant(l, CP);
           plan.push_back(std::move(l));
           any = true;
@@ -1013,6 +1028,7 @@ void Net::build_plan() {
     }
   }
   plan_valid = true;
+  tuned = false;
   plan_input_shape.clear();
   for (int bi : inputs)
     for (int d : blobs[bi]->st->shape) plan_input_shape.push_back(d);
@@ -1032,10 +1048,6 @@ void Net::ensure_device() {
     HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     stream = s;
   }
-  if (!zero_page) {
-    HIPCHECK(hipMalloc((void**)&zero_page, 256));
-    HIPCHECK(hipMemset(zero_page, 0, 256));
-  }
 }
 
 void Net::upload_vecs() {
@@ -1046,6 +1058,51 @@ void Net::upload_vecs() {
       v.uploaded = v.host.size();
       std::vector<float>().swap(v.host);  // the packed image lives in HBM only
     }
+}
+
+// Per-shape tile selection by measurement ("benchmark mode"): every distinct GEMM signature of the plan
+// is timed once per process with each eligible tile variant on the real buffers (all variants compute
+// the same values up to fp32 summation order) and the fastest is kept.  DC_AUTOTUNE=0 keeps the cost
+// model's choice; DC_CONV_VARIANT forces one variant.
+void Net::autotune() {
+  tuned = true;
+  if (env_int("DC_AUTOTUNE", 1) == 0 || env_int("DC_CONV_VARIANT", -1) >= 0) return;
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  const int reps = 3;
+  for (auto& l : plan) {
+    if (l.kind != Launch::CONV) continue;
+    const ConvGemmParams& g = l.cg;
+    char key[160];
+    std::snprintf(key, sizeof key, "%d/%d/%d/%d/%dx%d/%d,%d/%d/%d", g.M, g.Cout, g.Ktot, g.klen, g.nty, g.ntx, g.sy, g.sx,
+                  l.in2 >= 0 ? 1 : 0, g.OW);
+    auto it = tune_cache_.find(key);
+    if (it == tune_cache_.end()) {
+      int best = l.variant;
+      float best_ms = 1e30f;
+      for (int v = 0; v < conv_num_variants(); ++v) {
+        if (g.klen % conv_variant_bk(v) != 0) continue;
+        Launch trial = l;
+        trial.variant = v;
+        run_launch(trial, stream);  // warm
+        HIPCHECK(hipEventRecord(e0, (hipStream_t)stream));
+        for (int r = 0; r < reps; ++r) run_launch(trial, stream);
+        HIPCHECK(hipEventRecord(e1, (hipStream_t)stream));
+        HIPCHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best_ms) best_ms = ms, best = v;
+      }
+      it = tune_cache_.emplace(key, best).first;
+    }
+    l.variant = it->second;
+    l.kernel = std::string("conv_gemm<") + conv_variant(l.variant).name + ">";
+    l.grid = conv_grid(l.cg, l.variant);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  release_graph();
 }
 
 void Net::release_graph() {
@@ -1097,12 +1154,55 @@ void Net::run_launch(const Launch& l, void* s) {
   switch (l.kind) {
     case Launch::CONV: {
       ConvGemmParams g = l.cg;
+      g.dbg = nullptr;
       g.x = X.dev + l.x_off;
       g.y = Y.dev + l.y_off;
       g.resid = l.in2 >= 0 ? storages[l.in2]->dev + l.y_off : nullptr;
       g.w = vecs[l.w].dev;
       g.scale = l.scale >= 0 ? vecs[l.scale].dev : nullptr;
       g.shift = l.shift >= 0 ? vecs[l.shift].dev : nullptr;
+      static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
+      const int my_idx = (int)(&l - plan.data());
+      if (dbg_idx >= 0 && my_idx == dbg_idx) {
+        // device-side phase timestamps of ONE launch (diagnostics only): wall clock (100 MHz) at
+        // start / loop entry / loop exit / end, and the shader cycle counter at the same points
+        const int nwv = conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
+        const long n = l.grid * nwv * 8;
+        long long* d = nullptr;
+        HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
+        HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
+        for (int rep = 0; rep < 3; ++rep) {
+          g.dbg = d;
+          HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+          KCHECK(launch_conv_gemm(g, l.variant, s));
+          HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+        }
+        std::vector<long long> h(n);
+        HIPCHECK(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        long long t0 = h[0];
+        for (long i = 0; i < l.grid * nwv; ++i) t0 = std::min(t0, h[i * 8]);
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, c1 = 0, c2 = 0, c3 = 0, last = 0, first_end = 1e30;
+        for (long i = 0; i < l.grid * nwv; ++i) {
+          const long long* w = &h[i * 8];
+          s0 += (w[0] - t0) * 10e-3;
+          s1 += (w[1] - t0) * 10e-3;
+          s2 += (w[2] - t0) * 10e-3;
+          s3 += (w[3] - t0) * 10e-3;
+          c1 += (double)(w[5] - w[4]);
+          c2 += (double)(w[6] - w[5]);
+          c3 += (double)(w[7] - w[6]);
+          last = std::max(last, (w[3] - t0) * 10e-3);
+          first_end = std::min(first_end, (w[3] - t0) * 10e-3);
+        }
+        const double nw = (double)l.grid * nwv;
+        std::fprintf(stderr,
+                     "[dc timing] launch %d %s %s\n  mean wave: start %.2f us, loop entry %.2f, loop exit %.2f, end %.2f;"
+                     " first wave ends %.2f, last wave ends %.2f us\n  cycles: prologue %.0f, K loop %.0f, epilogue %.0f\n",
+                     my_idx, l.kernel.c_str(), l.label.c_str(), s0 / nw, s1 / nw, s2 / nw, s3 / nw, first_end, last, c1 / nw,
+                     c2 / nw, c3 / nw);
+        g.dbg = nullptr;
+      }
       KCHECK(launch_conv_gemm(g, l.variant, s));
       break;
     }
@@ -1161,6 +1261,7 @@ void Net::forward(int start, int end) {
   bool grew;
   prepare_buffers(*this, grew);
   if (grew) release_graph();
+  if (!tuned) autotune();
   // inputs of the executed range whose host copy is authoritative go up first (SyncedMemory::to_gpu)
   for (auto& l : plan) {
     if (l.last_layer < start || l.first_layer > end) continue;
@@ -1223,6 +1324,7 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   bool grew;
   prepare_buffers(*this, grew);
   if (grew) release_graph();
+  if (!tuned) autotune();
   void* s = user_stream ? user_stream : stream;
   size_t cnt = in.count();
   if (is_device) {
@@ -1290,7 +1392,7 @@ std::string Net::plan_text() {
     const Launch& l = plan[i];
     os << i << "\t" << l.kernel << "\t";
     if (l.kind == Launch::CONV)
-      os << "M=" << l.cg.M << " N=" << l.cg.Cout << " K=" << l.cg.Ktot << " taps=" << l.cg.ntaps << " grid=" << l.grid
+      os << "M=" << l.cg.M << " N=" << l.cg.Cout << " K=" << l.cg.Ktot << " taps=" << l.cg.nty * l.cg.ntx << " grid=" << l.grid
          << (l.in2 >= 0 ? " +resid" : "") << (l.relu ? " +relu" : "") << (l.cg.sigmoid_ch ? " +sigmoid" : "");
     os << "\t" << l.label << "\n";
   }

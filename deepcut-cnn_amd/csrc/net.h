@@ -135,7 +135,8 @@ struct Net {
   void* stream = nullptr;
   int device = -1;
   void* graph_exec = nullptr;
-  float* zero_page = nullptr;  // device zeros read by masked loads
+  bool tuned = false;                       // tile variants of the current plan were timed on the device
+  std::map<std::string, int> tune_cache_;   // GEMM signature -> fastest variant (per process)
   std::string text_buf;
 
   ~Net();
@@ -162,6 +163,7 @@ struct Net {
   void run_launch(const Launch& l, void* s);
   void run_plan(int start, int end, void* s);
   void release_graph();
+  void autotune();
 };
 
 // stand-alone layer forward on the device (Layer::Forward_gpu surface), host NCHW in/out
