@@ -244,12 +244,18 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev, int* pitch) {
   return guard([&] {
     Storage& s = *B(b)->st;
     if (s.is_param) throw DcError(DC_EUNSUP, "parameters are packed per kernel on the device; no NHWC image exists");
-    if (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED) {
+    if (s.view_of < 0 && (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED)) {
       if (!s.owner) throw DcError(DC_EINVAL, "orphan blob");
       s.owner->sync_to_device(s);
     }
-    *dev = s.dev;
-    if (pitch) *pitch = s.cp();
+    if (s.view_of >= 0) {  // channel slice of a concatenated head tensor
+      Storage& base = *s.owner->storages[s.view_of];
+      *dev = base.dev + s.view_c0;
+      if (pitch) *pitch = base.cp();
+    } else {
+      *dev = s.dev;
+      if (pitch) *pitch = s.cp();
+    }
   });
 }
 

@@ -552,7 +552,9 @@ struct LOp {
   std::vector<int> lids;
   int in = -1, in2 = -1, out = -1;
   int wl = -1;
+  std::vector<int> wls;      // weight layers when several sibling layers are concatenated along Cout
   std::vector<double> a, b;  // folded per-channel affine (empty = identity)
+  int sigmoid_ch = -1;       // >= 0: logistic on the first sigmoid_ch output channels only
   bool relu = false, sigmoid = false;
   int oh = 0, ow = 0;
   bool fused_crop = false;
@@ -737,6 +739,159 @@ void Net::build_plan() {
     }
   }
 
+
+  // pass 3 (DC_OPT_FUSE >= 2): sibling heads.  The three DeeperCut heads (part scores, location refinement,
+  // pairwise regression) are the same Deconvolution on res5c + the same 1x1 skip convolution on res3's
+  // last block, differing only in Cout (14 / 28 / 364): run them as ONE 406-channel skip GEMM and ONE
+  // 406-channel deconvolution (res5c's 2048-deep rows are read once instead of three times, and the
+  // 14/28-channel GEMMs no longer pad to 32-wide MFMA tiles).  The named output blobs become channel
+  // views of the concatenated tensor; the Sigmoid of the score head moves into the epilogue.
+  for (auto& st : storages) {
+    st->view_of = -1;
+    st->view_c0 = 0;
+    st->view_cp = 0;
+  }
+  plan_views_.clear();
+  if (fuse >= 2) {
+    const int nS0 = (int)storages.size();
+    std::vector<int> prod(nS0, -1);
+    std::vector<std::vector<int>> cons(nS0);
+    for (int k = 0; k < (int)ops.size(); ++k) {
+      if (ops[k].dead) continue;
+      cons[ops[k].in].push_back(k);
+      if (ops[k].in2 >= 0) cons[ops[k].in2].push_back(k);
+      prod[ops[k].out] = k;
+    }
+    auto same_geom = [&](int la, int lb) {
+      const ConvSpec &x = layers[la].conv, &y = layers[lb].conv;
+      return x.kh == y.kh && x.kw == y.kw && x.sh == y.sh && x.sw == y.sw && x.ph == y.ph && x.pw == y.pw && x.dh == y.dh &&
+             x.dw == y.dw;
+    };
+    std::vector<char> used(ops.size(), 0);
+    for (int f0 = 0; f0 < (int)ops.size(); ++f0) {
+      if (used[f0] || ops[f0].dead || ops[f0].kind != LOp::DECONV || !ops[f0].fused_crop || ops[f0].in2 < 0 || ops[f0].relu ||
+          ops[f0].sigmoid || !ops[f0].wls.empty())
+        continue;
+      std::vector<int> grp;  // deconv ops
+      for (int f = f0; f < (int)ops.size(); ++f) {
+        const LOp& F = ops[f];
+        if (used[f] || F.dead || F.kind != LOp::DECONV || !F.fused_crop || F.in2 < 0 || F.relu || F.sigmoid || !F.wls.empty()) continue;
+        if (F.in != ops[f0].in || F.oh != ops[f0].oh || F.ow != ops[f0].ow || !same_geom(F.wl, ops[f0].wl)) continue;
+        const int ck = prod[F.in2];
+        if (ck < 0 || cons[F.in2].size() != 1) continue;
+        const LOp& Cq = ops[ck];
+        const int c0k = prod[ops[f0].in2];
+        if (Cq.kind != LOp::CONV || Cq.relu || Cq.sigmoid || Cq.in2 >= 0 || !Cq.wls.empty() || c0k < 0 || Cq.in != ops[c0k].in ||
+            !same_geom(Cq.wl, ops[c0k].wl))
+          continue;
+        if (storages[F.out]->shape[2] != storages[ops[f0].out]->shape[2] || storages[F.out]->shape[3] != storages[ops[f0].out]->shape[3])
+          continue;
+        grp.push_back(f);
+      }
+      if (grp.size() < 2) continue;
+      // sigmoid folding: a head whose only consumer is an out-of-place Sigmoid
+      struct Member {
+        int f, c, sig_elt, final_out;
+      };
+      std::vector<Member> mem;
+      for (int f : grp) {
+        Member m{f, prod[ops[f].in2], -1, ops[f].out};
+        const auto& cs = cons[ops[f].out];
+        if (cs.size() == 1) {
+          const LOp& E = ops[cs[0]];
+          if (E.kind == LOp::ELT && E.in2 < 0 && E.a.empty() && E.sigmoid && !E.relu && E.in != E.out) {
+            m.sig_elt = cs[0];
+            m.final_out = E.out;
+          }
+        }
+        if (m.sig_elt < 0 && !cs.empty()) {  // some other kernel reads this head: it cannot become a strided view
+          m.f = -1;
+        }
+        mem.push_back(m);
+      }
+      mem.erase(std::remove_if(mem.begin(), mem.end(), [](const Member& m) { return m.f < 0; }), mem.end());
+      if (mem.size() < 2) continue;
+      std::stable_sort(mem.begin(), mem.end(), [](const Member& x, const Member& y) { return (x.sig_elt >= 0) > (y.sig_elt >= 0); });
+      int ctot = 0, sig_ch = 0;
+      for (auto& m : mem) {
+        const int c = layers[ops[m.f].wl].conv.num_output;
+        if (m.sig_elt >= 0) sig_ch += c;
+        ctot += c;
+      }
+      auto aux = [&](const std::string& key, std::vector<int> shape) {
+        auto it = aux_index_.find(key);
+        int id;
+        if (it == aux_index_.end()) {
+          auto st = std::make_shared<Storage>();
+          st->id = (int)storages.size();
+          st->owner = this;
+          storages.push_back(st);
+          id = st->id;
+          aux_index_[key] = id;
+        } else {
+          id = it->second;
+        }
+        storages[id]->reshape(shape);
+        return id;
+      };
+      const Storage& o0 = *storages[ops[mem[0].f].out];
+      const std::string gkey = std::to_string(ops[mem[0].f].lids.front());
+      const int T1 = aux("heads_skip:" + gkey, {o0.dim(0), ctot, o0.dim(2), o0.dim(3)});
+      const int T2 = aux("heads_out:" + gkey, {o0.dim(0), ctot, o0.dim(2), o0.dim(3)});
+      LOp MC = ops[mem[0].c], MF = ops[mem[0].f];
+      MC.wls.clear();
+      MF.wls.clear();
+      MC.lids.clear();
+      MF.lids.clear();
+      MC.a.clear();
+      MC.b.clear();
+      MF.a.clear();
+      MF.b.clear();
+      int c0 = 0;
+      for (auto& m : mem) {
+        const LOp &Cm = ops[m.c], &Fm = ops[m.f];
+        const int c = layers[Fm.wl].conv.num_output;
+        MC.wls.push_back(Cm.wl);
+        MF.wls.push_back(Fm.wl);
+        MC.lids.insert(MC.lids.end(), Cm.lids.begin(), Cm.lids.end());
+        MF.lids.insert(MF.lids.end(), Fm.lids.begin(), Fm.lids.end());
+        if (m.sig_elt >= 0) MF.lids.insert(MF.lids.end(), ops[m.sig_elt].lids.begin(), ops[m.sig_elt].lids.end());
+        for (int k = 0; k < c; ++k) {
+          MC.a.push_back(Cm.a.empty() ? 1.0 : Cm.a[k]);
+          MC.b.push_back(Cm.b.empty() ? 0.0 : Cm.b[k]);
+          MF.a.push_back(Fm.a.empty() ? 1.0 : Fm.a[k]);
+          MF.b.push_back(Fm.b.empty() ? 0.0 : Fm.b[k]);
+        }
+        Storage& v = *storages[m.final_out];
+        v.view_of = T2;
+        v.view_c0 = c0;
+        plan_views_.push_back(m.final_out);
+        c0 += c;
+      }
+      MC.out = T1;
+      MF.in2 = T1;
+      MF.out = T2;
+      MF.sigmoid_ch = sig_ch;
+      // the merged ops execute where the LAST member deconvolution stood (all operands are ready there)
+      int last_f = 0;
+      for (auto& m : mem) {
+        last_f = std::max(last_f, m.f);
+        ops[m.c].dead = true;
+        ops[m.f].dead = true;
+        used[m.f] = 1;
+        if (m.sig_elt >= 0) ops[m.sig_elt].dead = true;
+      }
+      for (auto& m : mem)
+        if (m.sig_elt >= 0 && m.sig_elt < last_f) { /* sigmoid stood before the last head: fine, it is folded */ }
+      ops[last_f] = MF;
+      ops[last_f].dead = false;
+      used[last_f] = 1;
+      ops.insert(ops.begin() + last_f, MC);  // skip GEMM right before it
+      used.insert(used.begin() + last_f, 1);
+      break;  // one head group per net is all the path has; indices moved, stop scanning
+    }
+  }
+
   // tensors combined element-wise / pooled / cropped must agree on channel pitch: propagate before any
   // launch parameters are derived from cp()
   for (bool changed = true; changed;) {
@@ -754,7 +909,7 @@ void Net::build_plan() {
     for (int bi : inputs) live[blobs[bi]->st->id] = 1;
     for (auto& op : ops)
       if (!op.dead) live[op.out] = 1;
-    for (auto& st : storages) st->elided = !live[st->id];
+    for (auto& st : storages) st->elided = !live[st->id] && st->view_of < 0;
   }
 
   // finalize: launches
@@ -789,7 +944,7 @@ void Net::build_plan() {
 
   auto affine_vecs = [&](const LOp& op, Launch& l, int C) {
     if (op.a.empty()) return;
-    std::string key = std::to_string(op.lids.front()) + ":" + std::to_string(op.lids.size());
+    std::string key = std::to_string(op.lids.front()) + ":" + std::to_string(op.lids.size()) + ":" + std::to_string(op.wls.size());
     l.scale = get_vec("a:" + key, [&](std::vector<float>& h) {
       h.resize(C);
       for (int c = 0; c < C; ++c) h[c] = (float)op.a[c];
@@ -887,16 +1042,22 @@ void Net::build_plan() {
         g.klen = CP;
         g.Ktot = c.kh * c.kw * CP;
         kgcd = CP;
-        l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
-          h.assign((size_t)c.num_output * g.Ktot, 0.f);
-          const float* w = L.params[0]->st->host_ptr();
+        const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
+        l.w = get_vec("w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()), [&](std::vector<float>& h) {
+          h.assign((size_t)OC * g.Ktot, 0.f);
           const int taps = c.kh * c.kw;
-          for (int co = 0; co < c.num_output; ++co)
-            for (int ci = 0; ci < C; ++ci) {
-              const float* src = w + ((size_t)co * C + ci) * taps;
-              float* dst = h.data() + (size_t)co * g.Ktot + ci;
-              for (int tp = 0; tp < taps; ++tp) dst[(size_t)tp * CP] = src[tp];
-            }
+          int cbase = 0;
+          for (int ml : members) {  // sibling layers concatenated along Cout
+            const float* w = layers[ml].params[0]->st->host_ptr();
+            const int cm = layers[ml].conv.num_output;
+            for (int co = 0; co < cm; ++co)
+              for (int ci = 0; ci < C; ++ci) {
+                const float* src = w + ((size_t)co * C + ci) * taps;
+                float* dst = h.data() + (size_t)(cbase + co) * g.Ktot + ci;
+                for (int tp = 0; tp < taps; ++tp) dst[(size_t)tp * CP] = src[tp];
+              }
+            cbase += cm;
+          }
         });
       }
       g.NB = N;
@@ -924,7 +1085,7 @@ void Net::build_plan() {
       const int DH = c.sh * (H - 1) + c.dh * (c.kh - 1) + 1 - 2 * c.ph;  // full deconv output
       const int DW = c.sw * (W - 1) + c.dw * (c.kw - 1) + 1 - 2 * c.pw;
       const int oh = op.fused_crop ? op.oh : 0, ow = op.fused_crop ? op.ow : 0;
-      plan_flops += 2.0 * (double)C * H * W * N * OC * c.kh * c.kw;  // SURVEY §8(d) definition
+      plan_flops += 2.0 * (double)C * H * W * N * OC * c.kh * c.kw;  // SURVEY §8(d) definition (OC = all member heads)
       bool any = false;
       for (int ry = 0; ry < c.sh; ++ry)
         for (int rx = 0; rx < c.sw; ++rx) {
@@ -981,21 +1142,28 @@ void Net::build_plan() {
           g.y_pix_stride = c.sw * OCP;
           l.y_off = ((long)(c.sh * i0 + ry - oh) * OWt + (c.sw * j0 + rx - ow)) * OCP;
           g.relu = op.relu;
-          g.sigmoid_ch = op.sigmoid ? OC : 0;
+          g.sigmoid_ch = op.sigmoid_ch >= 0 ? op.sigmoid_ch : (op.sigmoid ? OC : 0);
           affine_vecs(op, l, OC);
-          l.w = get_vec("w:" + std::to_string(op.wl) + ":" + std::to_string(ry) + "," + std::to_string(rx),
+          const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
+          l.w = get_vec("w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()) + ":" + std::to_string(ry) +
+                            "," + std::to_string(rx),
                         [&](std::vector<float>& h) {
                           h.assign((size_t)OC * g.Ktot, 0.f);
-                          const float* w = L.params[0]->st->host_ptr();  // [Cin][Cout][kh][kw]
-                          int t2 = 0;
-                          for (auto& a : tky)
-                            for (auto& b : tkx) {
-                              for (int co = 0; co < OC; ++co)
-                                for (int ci = 0; ci < C; ++ci)
-                                  h[(size_t)co * g.Ktot + (size_t)t2 * CP + ci] =
-                                      w[(((size_t)ci * OC + co) * c.kh + a.first) * c.kw + b.first];
-                              ++t2;
-                            }
+                          int cbase = 0;
+                          for (int ml : members) {  // sibling layers concatenated along Cout
+                            const float* w = layers[ml].params[0]->st->host_ptr();  // [Cin][Cout][kh][kw]
+                            const int cm = layers[ml].conv.num_output;
+                            int t2 = 0;
+                            for (auto& a : tky)
+                              for (auto& b : tkx) {
+                                for (int co = 0; co < cm; ++co)
+                                  for (int ci = 0; ci < C; ++ci)
+                                    h[(size_t)(cbase + co) * g.Ktot + (size_t)t2 * CP + ci] =
+                                        w[(((size_t)ci * cm + co) * c.kh + a.first) * c.kw + b.first];
+                                ++t2;
+                              }
+                            cbase += cm;
+                          }
                         });
           l.flops = 2.0 * g.M * (double)OC * C * ntaps;
           choose_variant(l, CP);
@@ -1137,7 +1305,12 @@ void Net::sync_to_host(Storage& s) {
   ensure_device();
   size_t n = s.count();
   float* h = s.host_ptr();
-  if (s.shape.size() == 4) {
+  if (s.view_of >= 0) {  // channel slice of a concatenated tensor
+    Storage& base = *storages[s.view_of];
+    s.ensure_stage(n);
+    KCHECK(launch_nhwc_to_nchw(base.dev, s.stage, s.dim(0), s.dim(1), s.dim(2), s.dim(3), base.cp(), s.view_c0, stream));
+    HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  } else if (s.shape.size() == 4) {
     s.ensure_stage(n);
     KCHECK(launch_nhwc_to_nchw(s.dev, s.stage, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), 0, stream));
     HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1305,6 +1478,7 @@ void Net::forward(int start, int end) {
     if (l.last_layer < start || l.first_layer > end) continue;
     storages[l.out]->head = HEAD_AT_GPU;
   }
+  for (int v : plan_views_) storages[v]->head = HEAD_AT_GPU;
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
 }
 
@@ -1336,18 +1510,20 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   }
   in.head = HEAD_AT_GPU;
   const int last = (int)layers.size() - 1;
-  if (use_graph && s == stream) {
+  if (use_graph) {
+    // the launch sequence is captured once on the net's own stream and replayed on whichever stream
+    // the caller works on (a graph is not tied to its capture stream)
     if (!graph_exec) {
       hipGraph_t graph;
-      HIPCHECK(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+      HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
       try {
-        run_plan(0, last, s);
+        run_plan(0, last, stream);
       } catch (...) {
         hipGraph_t g2;
-        (void)hipStreamEndCapture((hipStream_t)s, &g2);
+        (void)hipStreamEndCapture((hipStream_t)stream, &g2);
         throw;
       }
-      HIPCHECK(hipStreamEndCapture((hipStream_t)s, &graph));
+      HIPCHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
       hipGraphExec_t ge;
       HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
@@ -1358,6 +1534,7 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
     run_plan(0, last, s);
   }
   for (auto& l : plan) storages[l.out]->head = HEAD_AT_GPU;
+  for (int v : plan_views_) storages[v]->head = HEAD_AT_GPU;
   struct Out {
     const char* name;
     float* dst;
@@ -1368,11 +1545,14 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
     if (it == blob_index.end()) throw DcError(DC_EINVAL, std::string("net has no blob '") + o.name + "'");
     Storage& st = *blobs[it->second]->st;
     size_t m = st.count();
+    const float* src = st.view_of >= 0 ? storages[st.view_of]->dev : st.dev;
+    const int scp = st.view_of >= 0 ? storages[st.view_of]->cp() : st.cp();
+    const int sc0 = st.view_of >= 0 ? st.view_c0 : 0;
     if (is_device) {
-      KCHECK(launch_nhwc_to_nchw(st.dev, o.dst, st.dim(0), st.dim(1), st.dim(2), st.dim(3), st.cp(), 0, s));
+      KCHECK(launch_nhwc_to_nchw(src, o.dst, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
     } else {
       st.ensure_stage(m);
-      KCHECK(launch_nhwc_to_nchw(st.dev, st.stage, st.dim(0), st.dim(1), st.dim(2), st.dim(3), st.cp(), 0, s));
+      KCHECK(launch_nhwc_to_nchw(src, st.stage, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
       HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
     }
   }

@@ -47,6 +47,8 @@ struct Storage {
   bool pad4 = false;   // channel pitch rounded up to 4 (tensors read by the gather-GEMM)
   bool is_param = false;
   bool elided = false;  // absorbed by fusion in the current plan: never materialised
+  int view_of = -1;     // >= 0: this blob is channels [view_c0, view_c0+C) of storage `view_of` (merged heads)
+  int view_c0 = 0, view_cp = 0;
   Net* owner = nullptr;  // params: owning net (marks packed weights stale on mutable access)
   int id = -1;
 
@@ -123,7 +125,7 @@ struct Net {
   std::vector<std::shared_ptr<Storage>> storages;
   std::vector<int> inputs, outputs;  // blob indices
 
-  int fuse = 1;
+  int fuse = 2;
   int use_graph = 0;
   bool weights_dirty = true;
   bool plan_valid = false;
@@ -131,6 +133,8 @@ struct Net {
   std::vector<Launch> plan;
   std::vector<DevVec> vecs;
   std::map<std::string, int> vec_keys_;  // packed-weight cache: key -> index in vecs
+  std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
+  std::vector<int> plan_views_;          // storages that are channel views in the current plan
   double plan_flops = 0;
   void* stream = nullptr;
   int device = -1;

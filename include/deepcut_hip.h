@@ -46,7 +46,8 @@ extern "C" {
 
 /* dc_net_set_option keys */
 #define DC_OPT_FUSE 1       /* 0: every named blob materialised (Caffe-visible semantics);
-                               1 (default): residual-add and head fusion                     */
+                               1: + residual-add and Deconvolution+Crop+Eltwise head fusion;
+                               2 (default): + the sibling heads run as one concatenated GEMM     */
 #define DC_OPT_HIPGRAPH 2   /* 1: replay the per-shape launch sequence as a hipGraph        */
 
 typedef struct dc_net dc_net;

@@ -47,14 +47,17 @@ def test_unfused_every_blob_matches_oracle(gpu_caffe, synth152, hw):
     print("worst blob", worst)
 
 
+@pytest.mark.parametrize("fuse", [1, 2])
 @pytest.mark.parametrize("hw", [(64, 64), (104, 136), (240, 320)])
-def test_fused_outputs_match_oracle(gpu_caffe, synth152, hw):
+def test_fused_outputs_match_oracle(gpu_caffe, synth152, hw, fuse):
+    """fuse 1: residual + head fusion; fuse 2 (default): + the three heads as one concatenated GEMM whose
+    outputs are channel views (prob carries the folded sigmoid)."""
     from deepcut_tools import deepercut_prototxt
 
     path, layers = synth152
     h, w = hw
     proto = deepercut_prototxt(152, h, w)
-    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, fuse=fuse)
     img = rand_image(2, h, w)
     net.blobs["data"].data[...] = img
     out = net.forward()
@@ -65,3 +68,52 @@ def test_fused_outputs_match_oracle(gpu_caffe, synth152, hw):
         err = float(np.abs(out[k] - ref[k]).max())
         print(k, out[k].shape, "max abs err", err, "range", float(np.abs(ref[k]).max()))
         assert err <= TOL, k
+
+
+def test_elided_blobs_raise_instead_of_returning_stale_memory(gpu_caffe, synth152):
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
+    net.blobs["data"].data[...] = rand_image(3, 64, 64)
+    net.forward()
+    for name in ("res2a_branch2c", "fc_pose", "res5c_up_next", "res3d_locref"):
+        with pytest.raises(gpu_caffe.DeepcutError) as e:
+            net.blobs[name].data
+        assert "DC_OPT_FUSE 0" in str(e.value)
+    assert net.blobs["res5c"].data.shape == (1, 2048, 4, 4)  # still materialised
+
+
+def test_reshape_between_forwards_and_determinism(gpu_caffe, synth152):
+    """Layer::Forward re-runs Reshape (layer.hpp:451-456; test_net.cpp:2262-2332 TestReshape): a new input
+    size needs no net.reshape(); going back to the first size reproduces the first result bit for bit."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
+    a = rand_image(4, 64, 64)
+    b = rand_image(5, 88, 120)
+    net.blobs["data"].data[...] = a
+    o1 = {k: v.copy() for k, v in net.forward().items()}
+    net.blobs["data"].reshape(1, 3, 88, 120)
+    net.blobs["data"].data[...] = b
+    o2 = net.forward()
+    assert o2["prob"].shape == (1, 14, 11, 15)
+    net.blobs["data"].reshape(1, 3, 64, 64)
+    net.blobs["data"].data[...] = a
+    o3 = net.forward()
+    for k in o1:
+        assert np.array_equal(o1[k], o3[k]), k
+
+
+def test_batched_forward_equals_single_images(gpu_caffe, synth152):
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 72, 104), path, gpu_caffe.TEST, from_text=True)
+    imgs = rand_image(6, 72, 104, n=3)
+    batched = net.forward_batch(imgs)
+    for i in range(3):
+        single = net.forward_batch(imgs[i:i + 1])
+        for k in batched:
+            assert np.abs(batched[k][i] - single[k][0]).max() <= 1e-5, k

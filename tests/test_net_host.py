@@ -73,13 +73,20 @@ def test_lowering_fuses_the_whole_graph_into_gemm_launches(net152):
     assert any(l.endswith("conv1+bn_conv1+scale_conv1+conv1_relu") for l in lines)
     assert any("res2a_branch2c+bn2a_branch2c+scale2a_branch2c+res2a+res2a_relu" in l for l in lines)
     assert any("res5c_up_next+crop_next+next_pred [class 1,1]" in l for l in lines)
+    # level 2: the three sibling heads run as one 406-channel skip GEMM + one 406-channel deconvolution
+    net152.set_option(1, 2)
+    lines2 = [l for l in net152.plan_text().splitlines() if not l.startswith("#")]
+    assert len(lines2) == 172 - 2 - 8 - 1  # 3 skip convs -> 1, 12 deconv classes -> 4, sigmoid folded
+    assert sum("N=406" in l for l in lines2) == 5 and sum("+sigmoid" in l for l in lines2) == 4
+    assert any(l.endswith("res3d_pose+res3d_locref+res3d_next") for l in lines2)
+    assert abs(net152.flops() / 1e9 - 46.24) < 0.01  # algorithmic FLOPs do not depend on the fusion level
     net152.set_option(1, 0)
     lines0 = [l for l in net152.plan_text().splitlines() if not l.startswith("#")]
     # unfused: + 53 eltwise, 3 crop; every Caffe-visible blob materialised
     assert len(lines0) == 172 + 50 + 3 + 3
     assert sum("eltwise" in l for l in lines0) == 54
     assert sum("crop" in l.split("\t")[1] for l in lines0) == 3
-    net152.set_option(1, 1)
+    net152.set_option(1, 2)
 
 
 def test_forward_without_gpu_fails_loudly(net152):
