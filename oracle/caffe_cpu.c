@@ -45,58 +45,107 @@ int oracle_max_threads(void) {
 }
 
 /* ---- SGEMM: C[M,N] = op(A)[M,K] * B[K,N] + beta*C, row-major (caffe_cpu_gemm, math_functions.cpp:12-21;
- * call sites base_conv_layer.cpp:267-270 (CblasNoTrans) and :290-293 (CblasTrans)). ------------------- */
+ * call sites base_conv_layer.cpp:267-270 (CblasNoTrans) and :290-293 (CblasTrans)).  Stands for the
+ * reference's external BLAS: a register-blocked 6x16 micro-kernel (float32 FMA, k-ordered accumulation
+ * per output) over MC x NC cache blocks, OpenMP over the blocks. ------------------------------------- */
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
+
+#define GEMM_MR 6
+#define GEMM_NR 16
+#define GEMM_KC 384
+#define GEMM_MC 48
+#define GEMM_NC 256
+
+/* one MC x NC block of C: B is packed per KC slab into NR-wide panels (contiguous per k), then the 6x16
+ * micro-kernel runs with its accumulators in registers. */
 __attribute__((target_clones("avx2,fma", "default")))
-static void gemm_rows_f32(int i0, int i1, int transA, int M, int N, int K, const float* A, const float* B,
-                          float beta, float* C) {
-  enum { KB = 256, NBK = 1024 };
-  for (int i = i0; i < i1; ++i) {
-    float* c = C + (size_t)i * N;
-    if (beta == 0.f) memset(c, 0, (size_t)N * sizeof(float));
-    else if (beta != 1.f)
-      for (int j = 0; j < N; ++j) c[j] *= beta;
-  }
-  for (int j0 = 0; j0 < N; j0 += NBK) {
-    int j1 = j0 + NBK < N ? j0 + NBK : N;
-    for (int k0 = 0; k0 < K; k0 += KB) {
-      int k1 = k0 + KB < K ? k0 + KB : K;
-      for (int i = i0; i < i1; ++i) {
-        float* c = C + (size_t)i * N;
-        for (int k = k0; k < k1; ++k) {
-          float a = transA ? A[(size_t)k * M + i] : A[(size_t)i * K + k];
-          const float* b = B + (size_t)k * N;
-          for (int j = j0; j < j1; ++j) c[j] += a * b[j];
+static void gemm_block_f32(int transA, int M, int N, int K, const float* A, const float* B, float beta, float* C, int i0,
+                           int i1, int j0, int j1, float* bp) {
+  const int npan = (j1 - j0 + GEMM_NR - 1) / GEMM_NR;
+  for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
+    const int kc = K - k0 < GEMM_KC ? K - k0 : GEMM_KC;
+    const float bk = k0 == 0 ? beta : 1.f;
+    for (int pn = 0; pn < npan; ++pn) { /* pack */
+      const int j = j0 + pn * GEMM_NR;
+      const int nr = j1 - j < GEMM_NR ? j1 - j : GEMM_NR;
+      float* dst = bp + (size_t)pn * GEMM_KC * GEMM_NR;
+      for (int k = 0; k < kc; ++k) {
+        const float* src = B + (size_t)(k0 + k) * N + j;
+        for (int q = 0; q < nr; ++q) dst[k * GEMM_NR + q] = src[q];
+        for (int q = nr; q < GEMM_NR; ++q) dst[k * GEMM_NR + q] = 0.f;
+      }
+    }
+    for (int i = i0; i < i1; i += GEMM_MR) {
+      const int mr = i1 - i < GEMM_MR ? i1 - i : GEMM_MR;
+      for (int pn = 0; pn < npan; ++pn) {
+        const int j = j0 + pn * GEMM_NR;
+        const int nr = j1 - j < GEMM_NR ? j1 - j : GEMM_NR;
+        const float* b = bp + (size_t)pn * GEMM_KC * GEMM_NR;
+        v8f acc[GEMM_MR][2];
+        for (int r = 0; r < GEMM_MR; ++r) acc[r][0] = acc[r][1] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+        if (mr == GEMM_MR) {
+          for (int k = 0; k < kc; ++k) {
+            const v8f b0 = *(const v8f*)(b + k * GEMM_NR), b1 = *(const v8f*)(b + k * GEMM_NR + 8);
+            for (int r = 0; r < GEMM_MR; ++r) {
+              const float a = transA ? A[(size_t)(k0 + k) * M + i + r] : A[(size_t)(i + r) * K + k0 + k];
+              const v8f av = {a, a, a, a, a, a, a, a};
+              acc[r][0] += av * b0;
+              acc[r][1] += av * b1;
+            }
+          }
+        } else {
+          for (int k = 0; k < kc; ++k) {
+            const v8f b0 = *(const v8f*)(b + k * GEMM_NR), b1 = *(const v8f*)(b + k * GEMM_NR + 8);
+            for (int r = 0; r < mr; ++r) {
+              const float a = transA ? A[(size_t)(k0 + k) * M + i + r] : A[(size_t)(i + r) * K + k0 + k];
+              const v8f av = {a, a, a, a, a, a, a, a};
+              acc[r][0] += av * b0;
+              acc[r][1] += av * b1;
+            }
+          }
+        }
+        for (int r = 0; r < mr; ++r) {
+          float* c = C + (size_t)(i + r) * N + j;
+          float tmp[GEMM_NR];
+          *(v8f*)tmp = acc[r][0];
+          *(v8f*)(tmp + 8) = acc[r][1];
+          if (bk == 0.f)
+            for (int q = 0; q < nr; ++q) c[q] = tmp[q];
+          else
+            for (int q = 0; q < nr; ++q) c[q] = bk * c[q] + tmp[q];
         }
       }
     }
   }
 }
 
-static void gemm_rows_f64(int i0, int i1, int transA, int M, int N, int K, const float* A, const float* B,
-                          float beta, float* C) {
-  double* acc = (double*)malloc((size_t)N * sizeof(double));
-  for (int i = i0; i < i1; ++i) {
-    float* c = C + (size_t)i * N;
-    for (int j = 0; j < N; ++j) acc[j] = beta == 0.f ? 0.0 : (double)beta * c[j];
-    for (int k = 0; k < K; ++k) {
-      double a = transA ? A[(size_t)k * M + i] : A[(size_t)i * K + k];
-      const float* b = B + (size_t)k * N;
-      for (int j = 0; j < N; ++j) acc[j] += a * (double)b[j];
+static void gemm_block_f64(int transA, int M, int N, int K, const float* A, const float* B, float beta, float* C, int i0,
+                           int i1, int j0, int j1) {
+  for (int i = i0; i < i1; ++i)
+    for (int j = j0; j < j1; ++j) {
+      double acc = beta == 0.f ? 0.0 : (double)beta * C[(size_t)i * N + j];
+      for (int k = 0; k < K; ++k)
+        acc += (double)(transA ? A[(size_t)k * M + i] : A[(size_t)i * K + k]) * (double)B[(size_t)k * N + j];
+      C[(size_t)i * N + j] = (float)acc;
     }
-    for (int j = 0; j < N; ++j) c[j] = (float)acc[j];
-  }
-  free(acc);
 }
 
 void oracle_sgemm(int transA, int M, int N, int K, const float* A, const float* B, float beta, float* C) {
-  int nt = g_threads;
-  if (nt > M) nt = M;
+  const int bm = (M + GEMM_MC - 1) / GEMM_MC, bn = (N + GEMM_NC - 1) / GEMM_NC;
+  const int nblk = bm * bn;
+  int nt = g_threads < nblk ? g_threads : nblk;
   if (nt < 1) nt = 1;
-#pragma omp parallel for num_threads(nt) schedule(static)
-  for (int t = 0; t < nt; ++t) {
-    int i0 = (int)((long)M * t / nt), i1 = (int)((long)M * (t + 1) / nt);
-    if (g_double_acc) gemm_rows_f64(i0, i1, transA, M, N, K, A, B, beta, C);
-    else gemm_rows_f32(i0, i1, transA, M, N, K, A, B, beta, C);
+#pragma omp parallel num_threads(nt)
+  {
+    float* bp = g_double_acc ? NULL : (float*)aligned_alloc(64, (size_t)GEMM_KC * GEMM_NC * sizeof(float));
+#pragma omp for schedule(dynamic, 1)
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int i0 = (blk / bn) * GEMM_MC, j0 = (blk % bn) * GEMM_NC;
+      const int i1 = i0 + GEMM_MC < M ? i0 + GEMM_MC : M, j1 = j0 + GEMM_NC < N ? j0 + GEMM_NC : N;
+      if (g_double_acc) gemm_block_f64(transA, M, N, K, A, B, beta, C, i0, i1, j0, j1);
+      else gemm_block_f32(transA, M, N, K, A, B, beta, C, i0, i1, j0, j1, bp);
+    }
+    free(bp);
   }
 }
 
@@ -108,6 +157,7 @@ static int conv_out(int in, int k, int p, int s, int d) { return (in + 2 * p - (
 void oracle_im2col(const float* im, int C, int H, int W, int kh, int kw, int ph, int pw, int sh, int sw, int dh,
                    int dw, float* col) {
   const int OH = conv_out(H, kh, ph, sh, dh), OW = conv_out(W, kw, pw, sw, dw);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int c = 0; c < C; ++c)
     for (int ky = 0; ky < kh; ++ky)
       for (int kx = 0; kx < kw; ++kx) {
@@ -129,6 +179,7 @@ void oracle_col2im(const float* col, int C, int H, int W, int kh, int kw, int ph
                    int dw, float* im) {
   const int OH = conv_out(H, kh, ph, sh, dh), OW = conv_out(W, kw, pw, sw, dw);
   memset(im, 0, (size_t)C * H * W * sizeof(float));
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int c = 0; c < C; ++c)
     for (int ky = 0; ky < kh; ++ky)
       for (int kx = 0; kx < kw; ++kx) {
@@ -201,6 +252,7 @@ void oracle_deconv_forward(const float* x, int N, int C, int H, int W, const flo
 void oracle_batchnorm_forward(float* x, int N, int C, int S, const float* b0, const float* b1, const float* b2,
                               float eps) {
   const float sf = b2[0] == 0.f ? 0.f : 1.f / b2[0];
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int c = 0; c < C; ++c) {
     const float mean = b0[c] * sf;
     float var = b1[c] * sf;
@@ -216,6 +268,7 @@ void oracle_batchnorm_forward(float* x, int N, int C, int S, const float* b0, co
 /* ---- Scale with bias along the channel axis (scale_layer.cpp:109-134; bias_layer.cpp:72-87) ------------ */
 void oracle_scale_forward(float* x, int N, int C, int S, const float* gamma, const float* beta) {
   for (int n = 0; n < N; ++n)
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int c = 0; c < C; ++c) {
       float* p = x + ((size_t)n * C + c) * S;
       const float g = gamma[c];
