@@ -1,0 +1,134 @@
+"""Single-person pose estimation on top of the MI355X DeeperCut forward path.
+
+Same entry point and return layout as the reference's python/pose/estimate_pose.py
+(`estimate_pose(image, model_def, model_bin, scales)` -> 5x14 array: x, y, confidence and the two
+location-refinement components per joint), written against the `caffe` shim of this package
+(libdeepcut_hip.so).  What is kept from the reference, with the lines it mirrors:
+
+* pre-processing (estimate_pose.py:83-103): replicate the last row / column 64 px, rescale the uint8
+  image bilinearly (scipy.misc.imresize == PIL resize to int(dim*scale); identity at scale 1), subtract
+  the BGR mean [104, 117, 123], paste into a zero canvas whose sides are rounded up to the stride 8;
+* decoding (:131-143): per joint the arg-max cell of the score map, position = cell*8 + 4 + the
+  location-refinement vector at that cell * sqrt(53), everything divided by the scale; rows 3 and 4 hold
+  the refinement vector in the reference's (row-offset, column-offset) order;
+* scale selection (:119-126): the scale whose minimum joint confidence is highest (strict >, start 0).
+
+What differs: the reference tiles inputs wider than 700 px "to fit GPU memory" with a port of 1-based
+MATLAB indexing that trims the wrong seams and raises TypeError on current NumPy.  288 GB of
+HBM need no tiling: the whole image is one forward.  `num_tiles()` reproduces the reference's tile-count
+rule for callers that want to know what the reference would have done.
+"""
+import logging as _logging
+
+import numpy as _np
+
+_LOGGER = _logging.getLogger(__name__)
+
+MEAN_BGR = _np.array([104.0, 117.0, 123.0])
+LOCREF_SCALE = _np.sqrt(53.0)
+STRIDE = 8
+PAD = 64
+NUM_JOINTS = 14
+
+_MODEL = {}
+
+
+def num_tiles(length, max_size=700, rf=224):
+    """Tiles the reference would cut a side of `length` px into (estimate_pose.py:146-156)."""
+    if length <= max_size:
+        return 1
+    k = 0
+    while (max_size - rf) * 2 + (max_size - 2 * rf) * k <= length:
+        k += 1
+    return 2 + k
+
+
+def _resize_bilinear_u8(image, scale):
+    """scipy.misc.imresize(image, scale, interp='bilinear') for a uint8 HxWx3 image: PIL resize to
+    (int(W*scale), int(H*scale)); the identity when scale == 1."""
+    if scale == 1.0:
+        return image
+    from PIL import Image
+
+    h, w = image.shape[:2]
+    size = (int(w * scale), int(h * scale))
+    return _np.asarray(Image.fromarray(image).resize(size, Image.BILINEAR))
+
+
+def preprocess(image, scale):
+    """HxWx3 BGR uint8 -> float32 net input HxWx3 (mean-subtracted, zero-padded to a multiple of 8)."""
+    image = _np.asarray(image)
+    h, w = image.shape[:2]
+    out_h = int(_np.ceil(float(h) * scale / STRIDE) * STRIDE)
+    out_w = int(_np.ceil(float(w) * scale / STRIDE) * STRIDE)
+    padded = _np.pad(image, ((0, PAD), (0, PAD), (0, 0)), mode="edge")
+    scaled = _resize_bilinear_u8(padded, scale).astype(_np.float32) - MEAN_BGR.astype(_np.float32)
+    canvas = _np.zeros((out_h, out_w, 3), _np.float32)
+    hh, ww = min(out_h, scaled.shape[0]), min(out_w, scaled.shape[1])
+    canvas[:hh, :ww] = scaled[:hh, :ww]
+    return canvas
+
+
+def pose_from_maps(prob, loc_pred, scale=1.0):
+    """prob [14,h,w], loc_pred [28,h,w] (channel 2j / 2j+1 = x / y refinement of joint j in units of
+    sqrt(53) px) -> 5x14 float64, exactly the reference's `_pose_from_mats` arithmetic."""
+    prob = _np.asarray(prob)
+    loc = _np.asarray(loc_pred)
+    j, h, w = prob.shape
+    flat = prob.reshape(j, -1)
+    idx = flat.argmax(axis=1)  # first maximum in row-major order, as numpy.argmax on the 2-D map
+    rows, cols = _np.divmod(idx, w)
+    jj = _np.arange(j)
+    conf = flat[jj, idx]
+    off_x = loc[2 * jj, rows, cols].astype(_np.float64)
+    off_y = loc[2 * jj + 1, rows, cols].astype(_np.float64)
+    pose = _np.empty((5, j), _np.float64)
+    pose[0] = (cols.astype(_np.float64) * STRIDE + 0.5 * STRIDE + off_x * LOCREF_SCALE) / scale
+    pose[1] = (rows.astype(_np.float64) * STRIDE + 0.5 * STRIDE + off_y * LOCREF_SCALE) / scale
+    pose[2] = conf
+    pose[3] = off_y * LOCREF_SCALE / scale
+    pose[4] = off_x * LOCREF_SCALE / scale
+    return pose
+
+
+def select_best(poses):
+    """Keep the pose whose minimum joint confidence is highest (strict >, initial 0): None if no scale
+    reaches a positive minimum, like the reference."""
+    best, best_conf = None, 0.0
+    for p in poses:
+        c = float(p[2].min())
+        if c > best_conf:
+            best, best_conf = p, c
+    return best
+
+
+def _get_model(model_def, model_bin):
+    import caffe as _caffe
+
+    key = (model_def, model_bin)
+    if key not in _MODEL:
+        _LOGGER.info("Loading pose model...")
+        _MODEL[key] = _caffe.Net(model_def, model_bin, _caffe.TEST)
+    return _MODEL[key]
+
+
+def forward_maps(net, net_input):
+    """HxWx3 float32 -> (prob [14,h,w], loc_pred [28,h,w]) through net.forward()."""
+    chw = _np.ascontiguousarray(net_input.transpose((2, 0, 1)), dtype=_np.float32)
+    net.blobs["data"].reshape(1, 3, chw.shape[1], chw.shape[2])
+    net.blobs["data"].data[0, ...] = chw
+    net.forward()
+    return net.blobs["prob"].data[0].copy(), net.blobs["loc_pred"].data[0].copy()
+
+
+def estimate_pose(image, model_def, model_bin, scales=None, net=None):
+    """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring)."""
+    if scales is None:
+        scales = [1.0]
+    if net is None:
+        net = _get_model(model_def, model_bin)
+    poses = []
+    for s in scales:
+        prob, loc = forward_maps(net, preprocess(image, s))
+        poses.append(pose_from_maps(prob, loc, s))
+    return select_best(poses)
