@@ -80,6 +80,16 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
     }
 
 
+def hbm_traffic_from_profile():
+    """HBM bytes per conv_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes) — counters cannot be read inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        return json.load(open(path))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,7 +260,9 @@ def main():
                 "flops_per_launch": per_launch_flops,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_image": conv_launches,
-                "traffic": None,
+                "traffic": hbm_traffic_from_profile(),
+                "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json); "
+                                "algorithmic minimum %.1f MB" % ((2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) / conv_launches / 1e6),
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
             },
         }

@@ -1235,6 +1235,19 @@ void Net::upload_vecs() {
 void Net::autotune() {
   tuned = true;
   if (env_int("DC_AUTOTUNE", 1) == 0 || env_int("DC_CONV_VARIANT", -1) >= 0) return;
+  // DC_TUNE_CACHE=<file>: tuning results persist across processes ("signature variant-name" per line), so
+  // a service (or a profiling run) starts without the timing launches
+  const char* cache_path = std::getenv("DC_TUNE_CACHE");
+  if (cache_path && tune_cache_.empty()) {
+    if (FILE* f = std::fopen(cache_path, "r")) {
+      char key[200], vname[64];
+      while (std::fscanf(f, "%199s %63s", key, vname) == 2)
+        for (int v = 0; v < conv_num_variants(); ++v)
+          if (std::string(conv_variant(v).name) == vname) tune_cache_[key] = v;
+      std::fclose(f);
+    }
+  }
+  size_t cached_before = tune_cache_.size();
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
@@ -1270,6 +1283,12 @@ void Net::autotune() {
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (cache_path && tune_cache_.size() != cached_before) {
+    if (FILE* f = std::fopen(cache_path, "w")) {
+      for (auto& kv : tune_cache_) std::fprintf(f, "%s %s\n", kv.first.c_str(), conv_variant(kv.second).name);
+      std::fclose(f);
+    }
+  }
   release_graph();
 }
 

@@ -117,3 +117,26 @@ def test_batched_forward_equals_single_images(gpu_caffe, synth152):
         single = net.forward_batch(imgs[i:i + 1])
         for k in batched:
             assert np.abs(batched[k][i] - single[k][0]).max() <= 1e-5, k
+
+
+def test_pose_demo_pipeline_config0(gpu_caffe, synth152):
+    """BASELINE configs[0]: one 320x240 uint8 image through pre-processing -> net.forward() -> pose decode,
+    against the same pipeline run on the CPU oracle's maps (single tile, scale 1)."""
+    from deepcut_tools import deepercut_prototxt
+    from pose import estimate_pose as ep
+
+    path, layers = synth152
+    img = np.random.RandomState(0).randint(0, 256, (240, 320, 3)).astype(np.uint8)
+    net = gpu_caffe.Net(deepercut_prototxt(152, 240, 320), path, gpu_caffe.TEST, from_text=True)
+    pose = ep.estimate_pose(img, None, None, [1.0], net=net)
+    x = ep.preprocess(img, 1.0)
+    ref = _oracle(deepercut_prototxt(152, 240, 320), layers, x.transpose(2, 0, 1)[None])
+    assert float(np.abs(net.blobs["prob"].data - ref["prob"]).max()) <= TOL
+    assert float(np.abs(net.blobs["loc_pred"].data - ref["loc_pred"]).max()) <= TOL
+    ref_pose = ep.select_best([ep.pose_from_maps(ref["prob"][0], ref["loc_pred"][0], 1.0)])
+    assert pose is not None and pose.shape == (5, 14) and np.isfinite(pose).all()
+    # same arg-max cells unless two cells tie within the tolerance; positions agree to sqrt(53)*1e-3 px
+    assert np.abs(pose - ref_pose).max() <= 8.0 + 1e-2
+    same = np.abs(pose[:2] - ref_pose[:2]).max(axis=0) < 1.0
+    assert same.sum() >= 13
+    assert np.abs(pose[:, same] - ref_pose[:, same]).max() <= 1e-2
