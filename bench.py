@@ -156,9 +156,9 @@ def main():
     xs = [(torch.randn(B, 3, H, W, generator=g) * 50).to(dev) for _ in range(S)]
     outs = [torch.empty(sum(nel.values()), dtype=torch.float32, device=dev) for _ in range(S)]
     a, b = nel["prob"], nel["prob"] + nel["loc_pred"]
-    recv = None
-    if world > 1 and rank == 0:
-        recv = [torch.empty_like(outs[0]) for _ in range(world)]
+    recvs = [None] * S
+    if world > 1 and rank == 0:  # one set of receive buffers per in-flight forward
+        recvs = [[torch.empty_like(outs[0]) for _ in range(world)] for _ in range(S)]
     sizes = [outs[0].numel()] * world
 
     def step(i, nstreams):
@@ -169,7 +169,7 @@ def main():
                                st.cuda_stream)
         if world > 1:
             with torch.cuda.stream(st):
-                gather_maps_known(out, sizes, 0, None, out=recv)
+                gather_maps_known(out, sizes, 0, None, out=recvs[k])
 
     def fence():
         if world > 1:
