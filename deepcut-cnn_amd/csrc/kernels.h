@@ -42,6 +42,7 @@ struct ConvGemmParams {
   const float* shift;  // [Cout] or null (=0)
   int relu;
   int sigmoid_ch;  // channels [0, sigmoid_ch) get the logistic
+  int xcd_gx;      // XCD-aware tile map: rectangles along n (0 = linear map); filled by launch_conv_gemm
   long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
 };
 

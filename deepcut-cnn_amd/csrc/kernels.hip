@@ -73,9 +73,28 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   const int wc = (wave / WK) % WC;
   const int wr = wave / (WK * WC);
 
+  // Tile <- block map.  Blocks are observed to land on XCD (blockIdx % 8), each XCD with its own 4 MB L2.
+  // The default n-fastest order makes every XCD touch every filter row AND every pixel row; instead the
+  // tile grid is cut into 8 rectangles (gx x gy chosen on the host to minimise filters*gy + pixels*gx)
+  // and XCD q walks rectangle q, so an L2 only fetches its rectangle's share of both operands.
+  // Correctness does not depend on the placement (it is only a locality hint).
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int tile_n = blockIdx.x % tiles_n;
-  const int tile_m = blockIdx.x / tiles_n;
+  int tile_n, tile_m;
+  if (p.xcd_gx > 0) {
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int gx = p.xcd_gx, gy = 8 / gx;                 // rectangles along n / along m
+    const int q = blockIdx.x & 7, slot = blockIdx.x >> 3; // XCD, position inside its rectangle
+    const int qx = q % gx, qy = q / gx;
+    const int n_lo = (tiles_n * qx) / gx, n_hi = (tiles_n * (qx + 1)) / gx;
+    const int m_lo = (tiles_m * qy) / gy, m_hi = (tiles_m * (qy + 1)) / gy;
+    const int rw = n_hi - n_lo, rh = m_hi - m_lo;
+    if (slot >= rw * rh) return;  // grid is padded to 8 x the largest rectangle
+    tile_n = n_lo + slot % rw;
+    tile_m = m_lo + slot / rw;
+  } else {
+    tile_n = blockIdx.x % tiles_n;
+    tile_m = blockIdx.x / tiles_n;
+  }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
   const int T = p.Ktot / BK;
@@ -433,6 +452,32 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   p.x_bias = bias;
   long grid = conv_grid(p, variant);
   if (grid <= 0) return 0;
+  static const int xcd_map = getenv("DC_XCD_MAP") ? atoi(getenv("DC_XCD_MAP")) : 1;
+  p.xcd_gx = 0;
+  if (xcd_map && grid >= 16) {
+    const long tn = (p.Cout + e.v.BN - 1) / e.v.BN, tm = (p.M + e.v.BM - 1) / e.v.BM;
+    // bytes an XCD's L2 must fetch for its rectangle: filters of its n-range + pixels (x taps) of its m-range
+    double best = 1e300;
+    int best_gx = 0;
+    long best_grid = 0;
+    for (int gx : {1, 2, 4, 8}) {
+      const int gy = 8 / gx;
+      if (gx > tn || gy > tm) continue;
+      long maxrect = 0;
+      for (int q = 0; q < 8; ++q) {
+        const int qx = q % gx, qy = q / gx;
+        const long rw = (tn * (qx + 1)) / gx - (tn * qx) / gx, rh = (tm * (qy + 1)) / gy - (tm * qy) / gy;
+        maxrect = std::max(maxrect, rw * rh);
+      }
+      const double w_bytes = (double)p.Cout * p.Ktot / gx, a_bytes = (double)p.M * p.klen * p.nty / gy;
+      const double cost = (w_bytes + a_bytes) * (1.0 + 0.02 * (maxrect * 8 - grid) / (double)grid);
+      if (cost < best) best = cost, best_gx = gx, best_grid = maxrect * 8;
+    }
+    if (best_gx) {
+      p.xcd_gx = best_gx;
+      grid = best_grid;
+    }
+  }
   const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
   hipLaunchKernelGGL(e.kernel, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, p);
   return (int)hipGetLastError();
