@@ -267,6 +267,13 @@ int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, i
   return guard([&] { N(net)->forward_batch(input, n, h, w, is_device != 0, prob, loc_pred, next_pred, stream); });
 }
 
+int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, void* stream) {
+  REQUIRE(net);
+  REQUIRE(pose);
+  if (!(scale > 0)) return fail(DC_EINVAL, "scale must be positive");
+  return guard([&] { N(net)->decode_pose(scale, pose, is_device != 0, stream); });
+}
+
 int dc_net_flops(dc_net* net, double* flops) {
   REQUIRE(net);
   REQUIRE(flops);

@@ -80,4 +80,8 @@ int launch_nchw_to_nhwc(const float* src, float* dst, int NB, int C, int H, int 
 int launch_nhwc_to_nchw(const float* src, float* dst, int NB, int C, int H, int W, int CP, int c0,
                         void* stream);
 
+// pose decode (estimate_pose.py:131-143) from NHWC score / refinement maps (channel pitch + first channel)
+int launch_pose_decode(const float* prob, int pcp, int pc0, const float* loc, int lcp, int lc0, int NB, int H, int W,
+                       int J, double scale, double* out, void* stream);
+
 }  // namespace dc

@@ -698,6 +698,60 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pose decode on the device (estimate_pose.py:131-143 `_pose_from_mats`): per joint the FIRST maximum of
+// the score map in row-major order, refined by the location-regression vector at that cell.  One block
+// per (image, joint); only 5 x J doubles per image leave the GPU instead of the maps.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_decode_kernel(const float* __restrict__ prob, int pcp, int pc0,
+                                                          const float* __restrict__ loc, int lcp, int lc0, int H,
+                                                          int W, int J, double scale, double* __restrict__ out) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int j = blockIdx.x, n = blockIdx.y, HW = H * W;
+  float best = -3.402823466e+38f;
+  int bi = 0x7fffffff;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const float v = prob[((long)n * HW + p) * pcp + pc0 + j];
+    if (v > best) best = v, bi = p;  // strided scan keeps the smallest index per thread
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const float v2 = sv[threadIdx.x + s];
+      const int i2 = si[threadIdx.x + s];
+      if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) {
+        sv[threadIdx.x] = v2;
+        si[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int p = si[0] == 0x7fffffff ? 0 : si[0];
+    const int row = p / W, col = p - row * W;
+    const double kLoc = 7.280109889280518;  // sqrt(53)  (_LOCREF_SCALE_MUL, estimate_pose.py:27)
+    const double ox = (double)loc[((long)n * HW + p) * lcp + lc0 + 2 * j];
+    const double oy = (double)loc[((long)n * HW + p) * lcp + lc0 + 2 * j + 1];
+    double* o = out + (long)n * 5 * J;
+    o[0 * J + j] = ((double)col * 8.0 + 4.0 + ox * kLoc) / scale;
+    o[1 * J + j] = ((double)row * 8.0 + 4.0 + oy * kLoc) / scale;
+    o[2 * J + j] = (double)prob[((long)n * HW + p) * pcp + pc0 + j];
+    o[3 * J + j] = oy * kLoc / scale;
+    o[4 * J + j] = ox * kLoc / scale;
+  }
+}
+
+int launch_pose_decode(const float* prob, int pcp, int pc0, const float* loc, int lcp, int lc0, int NB, int H, int W,
+                       int J, double scale, double* out, void* stream) {
+  if (NB <= 0 || J <= 0) return 0;
+  hipLaunchKernelGGL(pose_decode_kernel, dim3(J, NB), dim3(256), 0, (hipStream_t)stream, prob, pcp, pc0, loc, lcp, lc0,
+                     H, W, J, scale, out);
+  return (int)hipGetLastError();
+}
+
 int launch_nchw_to_nhwc(const float* src, float* dst, int NB, int C, int H, int W, int CP, void* stream) {
   int HW = H * W;
   if (NB <= 0 || HW <= 0) return 0;

@@ -203,6 +203,7 @@ Net::~Net() {
   for (auto& v : vecs)
     if (v.dev) (void)hipFree(v.dev);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+  if (pose_dev) (void)hipFree(pose_dev);
 }
 
 Net* Net::create(const std::string& text, int phase) {
@@ -1576,6 +1577,54 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
     }
   }
   if (!(is_device && user_stream)) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+// _pose_from_mats (python/pose/estimate_pose.py:131-143) on the device: reads the `prob` and `loc_pred`
+// images of the last forward where they live (channel views of the merged head tensor included) and
+// returns 5 x J doubles per image — the 10 MB of maps need not cross PCIe for single-person decoding.
+void Net::decode_pose(double scale, double* out, bool is_device, void* user_stream) {
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "decode_pose() in CPU mode");
+  auto ip = blob_index.find("prob"), il = blob_index.find("loc_pred");
+  if (ip == blob_index.end() || il == blob_index.end()) throw DcError(DC_EINVAL, "net has no 'prob' / 'loc_pred' blobs");
+  Storage& P = *blobs[ip->second]->st;
+  Storage& L = *blobs[il->second]->st;
+  if (P.head == UNINITIALIZED || L.head == UNINITIALIZED) throw DcError(DC_EINVAL, "decode_pose: run forward() first");
+  if (L.dim(1) != 2 * P.dim(1) || L.dim(2) != P.dim(2) || L.dim(3) != P.dim(3) || L.dim(0) != P.dim(0))
+    throw DcError(DC_ESHAPE, "decode_pose: loc_pred must have 2 channels per joint and the score map's size");
+  ensure_device();
+  auto img = [&](Storage& s, const float*& ptr, int& cp, int& c0) {
+    if (s.view_of >= 0) {
+      ptr = storages[s.view_of]->dev;
+      cp = storages[s.view_of]->cp();
+      c0 = s.view_c0;
+    } else {
+      if (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED) sync_to_device(s);
+      ptr = s.dev;
+      cp = s.cp();
+      c0 = 0;
+    }
+  };
+  const float *pp, *lp;
+  int pcp, pc0, lcp, lc0;
+  img(P, pp, pcp, pc0);
+  img(L, lp, lcp, lc0);
+  const int NB = P.dim(0), J = P.dim(1), H = P.dim(2), W = P.dim(3);
+  void* s = user_stream ? user_stream : stream;
+  const size_t cnt = (size_t)NB * 5 * J;
+  if (is_device) {
+    KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, NB, H, W, J, scale, out, s));
+    if (!user_stream) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+    return;
+  }
+  if (cnt > pose_cap) {
+    if (pose_dev) HIPCHECK(hipFree(pose_dev));
+    pose_dev = nullptr;
+    HIPCHECK(hipMalloc((void**)&pose_dev, cnt * sizeof(double)));
+    pose_cap = cnt;
+  }
+  KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, NB, H, W, J, scale, pose_dev, s));
+  HIPCHECK(hipMemcpyAsync(out, pose_dev, cnt * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s));
+  HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
 std::string Net::plan_text() {

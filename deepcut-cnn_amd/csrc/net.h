@@ -139,6 +139,8 @@ struct Net {
   void* stream = nullptr;
   int device = -1;
   void* graph_exec = nullptr;
+  double* pose_dev = nullptr;
+  size_t pose_cap = 0;
   bool tuned = false;                       // tile variants of the current plan were timed on the device
   std::map<std::string, int> tune_cache_;   // GEMM signature -> fastest variant (per process)
   std::string text_buf;
@@ -154,6 +156,7 @@ struct Net {
                      float* next, void* user_stream);
   void sync_to_host(Storage& s);       // SyncedMemory::to_cpu
   void sync_to_device(Storage& s);     // SyncedMemory::to_gpu
+  void decode_pose(double scale, double* out, bool is_device, void* user_stream);  // after a forward
   std::string plan_text();
   std::string profile_text(int iters);
   int layer_index(const std::string& name) const;

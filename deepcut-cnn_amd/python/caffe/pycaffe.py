@@ -76,6 +76,7 @@ def _load():
         "dc_blob_head": (ci, [vp]),
         "dc_blob_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
         "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
+        "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
         "dc_net_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_net_num_launches": (ci, [vp]),
         "dc_net_plan_text": (cp, [vp]),
@@ -313,6 +314,13 @@ class Net(object):
         `stream` when given."""
         _check(_lib.dc_net_forward_batch(self._h, C.c_void_p(in_ptr), n, h, w, 1, C.c_void_p(prob_ptr or 0),
                                          C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(stream or 0)))
+
+    def decode_pose(self, scale=1.0):
+        """-> float64 [n, 5, J]: `_pose_from_mats` of the last forward, computed on the device."""
+        n, j = self.blobs["prob"].shape[:2]
+        out = np.empty((n, 5, j), np.float64)
+        _check(_lib.dc_net_decode_pose(self._h, float(scale), out.ctypes.data_as(C.c_void_p), 0, None))
+        return out
 
     def flops(self):
         v = C.c_double()

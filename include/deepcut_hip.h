@@ -140,6 +140,11 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev_ptr, int* channel_pitch);
 int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
                          float* prob, float* loc_pred, float* next_pred, void* stream);
 
+/* ---- pose decoding on the device (python/pose/estimate_pose.py:131-143 `_pose_from_mats`): after a
+ * forward, writes pose[n][5][J] doubles (x, y, confidence, and the refinement vector in the reference's
+ * (row, column) order, all divided by `scale`) to a host buffer (is_device=0) or a device buffer.        */
+int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, void* stream);
+
 /* ---- Layer::Forward_gpu surface ---------------------------------------------------------
  * One reference layer stand-alone = a one-layer prototxt given to dc_net_create_from_text with
  * DC_OPT_FUSE 0, weights injected through dc_net_param + dc_blob_mutable_cpu_data: the CDNA4

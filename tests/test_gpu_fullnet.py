@@ -140,3 +140,23 @@ def test_pose_demo_pipeline_config0(gpu_caffe, synth152):
     same = np.abs(pose[:2] - ref_pose[:2]).max(axis=0) < 1.0
     assert same.sum() >= 13
     assert np.abs(pose[:, same] - ref_pose[:, same]).max() <= 1e-2
+
+
+@pytest.mark.parametrize("fuse", [0, 2])
+def test_device_pose_decode_equals_host_decode(gpu_caffe, synth152, fuse):
+    """dc_net_decode_pose (arg-max + refinement on the GPU) == pose_from_maps on the downloaded maps, which
+    is pinned to the reference's _pose_from_mats by tests/test_pose.py; channel views (fuse 2) and plain
+    tensors (fuse 0) alike; batch of 2."""
+    from deepcut_tools import deepercut_prototxt
+    from pose import estimate_pose as ep
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 104, 136, 2), path, gpu_caffe.TEST, from_text=True, fuse=fuse)
+    net.blobs["data"].data[...] = rand_image(8, 104, 136, n=2)
+    net.forward()
+    for scale in (1.0, 0.75):
+        got = net.decode_pose(scale)
+        assert got.shape == (2, 5, 14)
+        for i in range(2):
+            ref = ep.pose_from_maps(net.blobs["prob"].data[i], net.blobs["loc_pred"].data[i], scale)
+            assert np.allclose(got[i], ref, rtol=0, atol=1e-9)
