@@ -160,3 +160,45 @@ def test_device_pose_decode_equals_host_decode(gpu_caffe, synth152, fuse):
         for i in range(2):
             ref = ep.pose_from_maps(net.blobs["prob"].data[i], net.blobs["loc_pred"].data[i], scale)
             assert np.allclose(got[i], ref, rtol=0, atol=1e-9)
+
+
+def test_benchmark_config_fullsize_matches_oracle(gpu_caffe, synth152):
+    """BASELINE configs[1] itself: 1x3x544x736, fp32, all fusion on — every output map within 1e-3 of the CPU
+    oracle (input RandomState(1).randn*50)."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, layers = synth152
+    proto = deepercut_prototxt(152, 544, 736)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True)
+    img = (np.random.RandomState(1).randn(1, 3, 544, 736) * 50).astype(np.float32)
+    net.blobs["data"].data[...] = img
+    out = net.forward()
+    assert abs(net.flops() / 1e9 - 241.09) < 0.01
+    ref = _oracle(proto, layers, img)
+    for k in ("prob", "loc_pred", "next_pred"):
+        assert out[k].shape == ref[k].shape == (1, {"prob": 14, "loc_pred": 28, "next_pred": 364}[k], 68, 92)
+        err = float(np.abs(out[k] - ref[k]).max())
+        print(k, "max abs err", err)
+        assert err <= TOL, k
+
+
+@pytest.mark.parametrize("scale_hw", [(272, 368), (408, 552), (680, 920)])
+def test_pyramid_scales_batched(gpu_caffe, synth152, scale_hw):
+    """BASELINE configs[2] shapes (736x544 at scales 0.5 / 0.75 / 1.25; fp32 here): a batch of 2 through one
+    plan.  Checked through size-independent properties: the batch equals its images forwarded alone, a
+    second forward is bit-identical, and prob stays a probability."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    h, w = scale_hw
+    net = gpu_caffe.Net(deepercut_prototxt(152, h, w, 2), path, gpu_caffe.TEST, from_text=True)
+    imgs = rand_image(11, h, w, n=2)
+    a = net.forward_batch(imgs)
+    b = net.forward_batch(imgs)
+    one = net.forward_batch(imgs[1:2])
+    for k in a:
+        assert a[k].shape[2:] == (h // 8, w // 8)
+        assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k][1] - one[k][0]).max() <= 1e-5, k
+        assert np.isfinite(a[k]).all()
+    assert (a["prob"] > 0).all() and (a["prob"] < 1).all()
