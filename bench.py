@@ -138,14 +138,13 @@ def main():
     layers = synth_weights(args.depth, seed=0)
     S = max(1, args.streams)
     proto = deepercut_prototxt(args.depth, H, W, B)
-    nets = []
-    for _ in range(S):  # one Net (own activations, own weight image) per in-flight forward
-        n_ = caffe.Net(proto, caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1)
-        inject_weights(n_, layers)
-        n_.blobs["data"].reshape(B, 3, H, W)
-        n_.reshape()
-        nets.append(n_)
-    net = nets[0]
+    net = caffe.Net(proto, caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1)
+    inject_weights(net, layers)
+    net.blobs["data"].reshape(B, 3, H, W)
+    net.reshape()
+    # one executor per in-flight forward: clones own their activations / stream / graph and share the
+    # parameters and the packed weights in HBM with `net`
+    nets = [net] + [net.clone() for _ in range(S - 1)]
     flops_img = net.flops() / B
     shp = {k: net.blobs[k].shape for k in ("prob", "loc_pred", "next_pred")}
     nel = {k: int(np.prod(s)) for k, s in shp.items()}

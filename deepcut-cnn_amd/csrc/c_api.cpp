@@ -87,6 +87,16 @@ int dc_net_create(const char* proto, const char* model, int phase, dc_net** out)
     *out = reinterpret_cast<dc_net*>(n.release());
   });
 }
+int dc_net_clone(dc_net* net, dc_net** out) {
+  REQUIRE(net);
+  REQUIRE(out);
+  *out = nullptr;
+  return guard([&] { *out = reinterpret_cast<dc_net*>(N(net)->clone()); });
+}
+int dc_net_synchronize(dc_net* net) {
+  REQUIRE(net);
+  return guard([&] { N(net)->synchronize(); });
+}
 int dc_net_destroy(dc_net* net) {
   if (net) delete N(net);
   return DC_OK;

@@ -198,10 +198,12 @@ int pair_or(const TextMsg* m, const char* rep, const char* single, int idx, int 
 }  // namespace
 
 // ---- Net: construction ----------------------------------------------------------------------------
+DevVec::~DevVec() {
+  if (dev) (void)hipFree(dev);
+}
+
 Net::~Net() {
   release_graph();
-  for (auto& v : vecs)
-    if (v.dev) (void)hipFree(v.dev);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
   if (pose_dev) (void)hipFree(pose_dev);
 }
@@ -209,9 +211,38 @@ Net::~Net() {
 Net* Net::create(const std::string& text, int phase) {
   std::unique_ptr<Net> n(new Net());
   n->phase = phase;
+  n->proto_text = text;
   TextMsg root = parse_text_proto(text);
   n->init_from(root);
   return n.release();
+}
+
+// A clone runs the same model concurrently with its parent (own activations, own stream, own graph) while
+// sharing the parameter blobs and the packed filter images in HBM: this is how several independent forwards
+// are kept in flight on one GPU without paying 263 MB per copy (deepcut_tools.Pipeline, bench.py).
+Net* Net::clone() {
+  reshape();
+  std::vector<int> sig;
+  for (int bi : inputs)
+    for (int d : blobs[bi]->st->shape) sig.push_back(d);
+  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();  // host-side packing, shared below
+  std::unique_ptr<Net> c(Net::create(proto_text, phase));
+  if (c->layers.size() != layers.size()) throw DcError(DC_EINVAL, "clone: graph mismatch");
+  for (size_t i = 0; i < layers.size(); ++i) c->layers[i].params = layers[i].params;  // shared host parameters
+  for (size_t i = 0; i < inputs.size(); ++i) c->blobs[c->inputs[i]]->st->reshape(blobs[inputs[i]]->st->shape);
+  c->fuse = fuse;
+  c->use_graph = use_graph;
+  c->vecs = vecs;
+  c->vec_keys_ = vec_keys_;
+  c->tune_cache_ = tune_cache_;
+  c->weights_dirty = false;
+  c->device = device;
+  c->reshape();
+  return c.release();
+}
+
+void Net::synchronize() {
+  if (stream) HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
 }
 
 int Net::layer_index(const std::string& nm) const {
@@ -917,9 +948,7 @@ void Net::build_plan() {
   plan.clear();
   plan_flops = 0;
   if (weights_dirty) {
-    for (auto& v : vecs)
-      if (v.dev) (void)hipFree(v.dev);
-    vecs.clear();
+    vecs.clear();  // shared images stay alive in clones that still reference them
     vec_keys_.clear();
     weights_dirty = false;
     release_graph();
@@ -927,8 +956,8 @@ void Net::build_plan() {
   auto get_vec = [&](const std::string& key, const std::function<void(std::vector<float>&)>& fill) {
     auto it = vec_keys_.find(key);
     if (it != vec_keys_.end()) return it->second;
-    DevVec v;
-    fill(v.host);
+    auto v = std::make_shared<DevVec>();
+    fill(v->host);
     vecs.push_back(std::move(v));
     vec_keys_[key] = (int)vecs.size() - 1;
     return (int)vecs.size() - 1;
@@ -1220,13 +1249,15 @@ void Net::ensure_device() {
 }
 
 void Net::upload_vecs() {
-  for (auto& v : vecs)
+  for (auto& vp : vecs) {
+    DevVec& v = *vp;
     if (!v.dev && !v.host.empty()) {
       HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * sizeof(float)));
       HIPCHECK(hipMemcpy(v.dev, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
       v.uploaded = v.host.size();
       std::vector<float>().swap(v.host);  // the packed image lives in HBM only
     }
+  }
 }
 
 // Per-shape tile selection by measurement ("benchmark mode"): every distinct GEMM signature of the plan
@@ -1351,9 +1382,9 @@ void Net::run_launch(const Launch& l, void* s) {
       g.x = X.dev + l.x_off;
       g.y = Y.dev + l.y_off;
       g.resid = l.in2 >= 0 ? storages[l.in2]->dev + l.y_off : nullptr;
-      g.w = vecs[l.w].dev;
-      g.scale = l.scale >= 0 ? vecs[l.scale].dev : nullptr;
-      g.shift = l.shift >= 0 ? vecs[l.shift].dev : nullptr;
+      g.w = vecs[l.w]->dev;
+      g.scale = l.scale >= 0 ? vecs[l.scale]->dev : nullptr;
+      g.shift = l.shift >= 0 ? vecs[l.shift]->dev : nullptr;
       static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
       const int my_idx = (int)(&l - plan.data());
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
@@ -1403,8 +1434,8 @@ void Net::run_launch(const Launch& l, void* s) {
       KCHECK(launch_maxpool(X.dev, Y.dev, X.dim(0), X.dim(2), X.dim(3), X.cp(), Y.dim(2), Y.dim(3), l.pk, l.ps, l.pp, s));
       break;
     case Launch::ELT:
-      KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale >= 0 ? vecs[l.scale].dev : nullptr,
-                            l.shift >= 0 ? vecs[l.shift].dev : nullptr, Y.dev, (long)Y.dev_count(), Y.cp(), l.relu,
+      KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale >= 0 ? vecs[l.scale]->dev : nullptr,
+                            l.shift >= 0 ? vecs[l.shift]->dev : nullptr, Y.dev, (long)Y.dev_count(), Y.cp(), l.relu,
                             l.sigmoid, s));
       break;
     case Launch::CROP:
@@ -1519,6 +1550,8 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   prepare_buffers(*this, grew);
   if (grew) release_graph();
   if (!tuned) autotune();
+  const bool own_async = user_stream == (void*)-1;  // DC_STREAM_OWN: the net's stream, no final sync
+  if (own_async) user_stream = nullptr;
   void* s = user_stream ? user_stream : stream;
   size_t cnt = in.count();
   if (is_device) {
@@ -1576,7 +1609,7 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
       HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
     }
   }
-  if (!(is_device && user_stream)) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
 // _pose_from_mats (python/pose/estimate_pose.py:131-143) on the device: reads the `prob` and `loc_pred`

@@ -89,10 +89,14 @@ struct LayerRec {
 };
 
 // ---- lowered plan -----------------------------------------------------------------------------------
-struct DevVec {
+struct DevVec {  // a packed filter / affine vector; shared between a Net and its clones
   std::vector<float> host;
   float* dev = nullptr;
   size_t uploaded = 0;
+  DevVec() = default;
+  DevVec(const DevVec&) = delete;
+  DevVec& operator=(const DevVec&) = delete;
+  ~DevVec();
 };
 
 struct Launch {
@@ -131,7 +135,7 @@ struct Net {
   bool plan_valid = false;
   std::vector<int> plan_input_shape;
   std::vector<Launch> plan;
-  std::vector<DevVec> vecs;
+  std::vector<std::shared_ptr<DevVec>> vecs;
   std::map<std::string, int> vec_keys_;  // packed-weight cache: key -> index in vecs
   std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
   std::vector<int> plan_views_;          // storages that are channel views in the current plan
@@ -144,9 +148,12 @@ struct Net {
   bool tuned = false;                       // tile variants of the current plan were timed on the device
   std::map<std::string, int> tune_cache_;   // GEMM signature -> fastest variant (per process)
   std::string text_buf;
+  std::string proto_text;  // kept for clone()
 
   ~Net();
   static Net* create(const std::string& prototxt_text, int phase);
+  Net* clone();           // same graph and input shape, SHARED parameters and packed device weights
+  void synchronize();     // wait for everything enqueued on the net's own stream
   void copy_from(const std::string& path);
   void save(const std::string& path);
   void reshape();         // propagate input shapes through every layer (Net::Reshape)

@@ -35,6 +35,15 @@ def lib_path():
 
 
 def _load():
+    # PyTorch-ROCm wheels bundle their own HIP runtime under the same SONAME as /opt/rocm's.  Whichever is
+    # loaded first serves the whole process; if ours comes first torch later reports "No HIP GPUs".  When
+    # torch is installed, let it load first so both sides share one runtime (and torch streams / tensors can
+    # be handed to dc_net_forward_batch).  DEEPCUT_NO_TORCH_PRELOAD=1 skips this.
+    if not os.environ.get("DEEPCUT_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: plain ROCm runtime
+            pass
     lib = C.CDLL(lib_path())
     vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
     sig = {
@@ -48,6 +57,8 @@ def _load():
         "dc_net_create": (ci, [cp, cp, ci, C.POINTER(vp)]),
         "dc_net_create_from_text": (ci, [cp, cp, ci, C.POINTER(vp)]),
         "dc_net_destroy": (ci, [vp]),
+        "dc_net_clone": (ci, [vp, C.POINTER(vp)]),
+        "dc_net_synchronize": (ci, [vp]),
         "dc_net_set_option": (ci, [vp, ci, ci]),
         "dc_net_copy_from": (ci, [vp, cp]),
         "dc_net_save": (ci, [vp, cp]),
@@ -181,6 +192,12 @@ class Net(object):
     """caffe.Net(model_def, model_bin, phase) / caffe.Net(model_def, phase)  (_caffe.cpp:76-96,227-228)."""
 
     def __init__(self, model_def, *args, **kw):
+        if "_handle" in kw:  # clone()
+            self._h = kw["_handle"]
+            self._handle = _NetHandle(self._h)
+            self._blobs = None
+            self._params = None
+            return
         if len(args) == 2:
             weights, phase = args
         elif len(args) == 1:
@@ -312,6 +329,8 @@ class Net(object):
     def forward_device(self, in_ptr, n, h, w, prob_ptr=None, loc_ptr=None, next_ptr=None, stream=None):
         """Device-resident batch: raw device pointers (e.g. torch tensor .data_ptr()), asynchronous on
         `stream` when given."""
+        if stream == "own":  # DC_STREAM_OWN: the net's own stream, asynchronous
+            stream = C.c_void_p(-1).value
         _check(_lib.dc_net_forward_batch(self._h, C.c_void_p(in_ptr), n, h, w, 1, C.c_void_p(prob_ptr or 0),
                                          C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(stream or 0)))
 
@@ -321,6 +340,16 @@ class Net(object):
         out = np.empty((n, 5, j), np.float64)
         _check(_lib.dc_net_decode_pose(self._h, float(scale), out.ctypes.data_as(C.c_void_p), 0, None))
         return out
+
+    def clone(self):
+        """A second executor of the same model (own activations / stream / graph) sharing the parameters and
+        the packed weights in HBM with this net."""
+        h = C.c_void_p()
+        _check(_lib.dc_net_clone(self._h, C.byref(h)))
+        return Net(None, _handle=h)
+
+    def synchronize(self):
+        _check(_lib.dc_net_synchronize(self._h))
 
     def flops(self):
         v = C.c_double()

@@ -5,3 +5,4 @@ from .model_zoo import deepercut_prototxt, deepercut_layer_table  # noqa: F401
 from .caffemodel import write_caffemodel, read_caffemodel  # noqa: F401
 from .synth import synth_weights, write_synth_caffemodel  # noqa: F401
 from .shard import lpt_shards, gather_maps, gather_maps_known  # noqa: F401
+from .pipeline import Pipeline  # noqa: F401

@@ -74,6 +74,12 @@ int dc_net_create(const char* prototxt_path, const char* caffemodel_path, int ph
 int dc_net_create_from_text(const char* prototxt_text, const char* caffemodel_path, int phase,
                             dc_net** out);
 int dc_net_destroy(dc_net* net);
+/* A second executor of the same model on the same device: own activations / stream / hipGraph, SHARED
+ * parameter blobs and packed filter images (no reference counterpart; Net::ShareTrainedLayersWith,
+ * net.cpp:751-769, is the nearest idea).  Used to keep several independent forwards in flight.           */
+int dc_net_clone(dc_net* net, dc_net** out);
+/* wait for everything enqueued on the net's own stream (see DC_STREAM_OWN)                                */
+int dc_net_synchronize(dc_net* net);
 int dc_net_set_option(dc_net* net, int key, int value);
 /* Net::CopyTrainedLayersFrom(file) (net.cpp:805-858): match by layer name, check blob
  * count and shape, ignore unmatched source layers.                                       */
@@ -135,8 +141,10 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev_ptr, int* channel_pitch);
  * inputs  : host or device NCHW float32 [n,3,H,W] (is_device selects)
  * outputs : prob [n,14,h,w], loc_pred [n,28,h,w], next_pred [n,364,h,w] NCHW float32, host or
  *           device like the input; any of them may be NULL to skip the copy-out.
- * stream  : hipStream_t to enqueue on (NULL = the net's own stream); when a stream is given
- *           and buffers are device-side the call is asynchronous.                         */
+ * stream  : hipStream_t to enqueue on.  NULL = the net's own stream, synchronous.  DC_STREAM_OWN = the
+ *           net's own stream, asynchronous for device buffers (pair with dc_net_synchronize).  With a
+ *           caller stream and device buffers the call is asynchronous on that stream.              */
+#define DC_STREAM_OWN ((void*)-1)
 int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
                          float* prob, float* loc_pred, float* next_pred, void* stream);
 

@@ -202,3 +202,27 @@ def test_pyramid_scales_batched(gpu_caffe, synth152, scale_hw):
         assert np.abs(a[k][1] - one[k][0]).max() <= 1e-5, k
         assert np.isfinite(a[k]).all()
     assert (a["prob"] > 0).all() and (a["prob"] < 1).all()
+
+
+def test_pipeline_of_clones_matches_sequential(gpu_caffe, synth152):
+    """deepcut_tools.Pipeline: three executors (a Net + two clones sharing its packed weights) with requests in
+    flight on their own streams give the same maps as one forward at a time."""
+    import torch
+    from deepcut_tools import Pipeline, deepercut_prototxt
+
+    path, _ = synth152
+    h, w = 104, 136
+    net = gpu_caffe.Net(deepercut_prototxt(152, h, w), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    dev = torch.device("cuda", 0)
+    imgs = [torch.from_numpy(rand_image(20 + i, h, w)).to(dev) for i in range(7)]
+    ref = [net.forward_batch(im.cpu().numpy()) for im in imgs]
+    pipe = Pipeline(net, depth=3)
+    assert pipe.depth == 3
+    outs = [[torch.empty(1, c, h // 8, w // 8, device=dev) for c in (14, 28, 364)] for _ in imgs]
+    torch.cuda.synchronize()
+    for i, im in enumerate(imgs):
+        pipe.submit(im.data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
+    assert pipe.drain()[-1] == 6
+    for i in range(len(imgs)):
+        for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
+            assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)

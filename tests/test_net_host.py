@@ -238,3 +238,23 @@ def test_resnet101_variant_builds():
     t = deepercut_layer_table(101)
     assert sum(l["type"] == "Convolution" for l in t) == 104 + 3
     assert "res4b22" in net.blobs and "res3b3" in net.blobs and net.outputs == ["loc_pred", "next_pred", "prob"]
+
+
+def test_clone_shares_parameters_and_plan():
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    net.params["conv1"][0].data[...] = 0.5
+    net.blobs["data"].reshape(2, 3, 72, 104)
+    c = net.clone()
+    assert c.blobs["data"].shape == (2, 3, 72, 104) and c.blobs["prob"].shape == (2, 14, 9, 13)
+    assert c._layer_names == net._layer_names and list(c.blobs) == list(net.blobs)
+    assert (c.params["conv1"][0].data == 0.5).all()
+    net.params["conv1"][0].data[0, 0, 0, 0] = 7.0  # same host memory
+    assert c.params["conv1"][0].data[0, 0, 0, 0] == 7.0
+    assert c.plan_text() == net.plan_text()
+    c.blobs["data"].data[...] = 1.0  # activations are private
+    assert (net.blobs["data"].data == 0).all()
+    del net
+    import gc
+
+    gc.collect()
+    assert c.params["conv1"][0].data[0, 0, 0, 0] == 7.0  # shared blobs outlive the parent
