@@ -37,6 +37,26 @@ def inject_weights(net, layers):
             p.data[...] = b
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes 256 hardware threads but grants 16 CPUs of quota; oversubscribing them makes the OpenMP
+    GEMM slower than one thread)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(proto_fn, layers, flops_full, full_hw):
     """The reference's CPU algorithm (oracle/: per-image im2col + SGEMM, unfused BatchNorm / Scale / ReLU /
     Eltwise passes, NCHW fp32) timed on this host's cores on a bounded sample of the SAME workload:
@@ -44,10 +64,11 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
     thread (the reference's default BLAS, ATLAS, is single-threaded) scaled by FLOPs (the path's cost is
     linear in H*W)."""
     import numpy as np
+
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, O.lib().oracle_max_threads()))
+    threads = max(1, effective_cores())
     h, w = full_hw
     O.set_threads(threads)
     net = O.OracleNet(proto_fn(h, w), layers)
@@ -73,7 +94,8 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
         "cores": threads,
         "kind": "port",
         "sample": "oracle (C restatement of Caffe's im2col+SGEMM CPU path, OpenMP) on %d whole 1x3x%dx%d forward(s), "
-                  "%.1f s, %.1f GFLOP/s on %d threads" % (n, h, w, dt_all, n * flops_full / dt_all / 1e9, threads),
+                  "%.1f s, %.1f GFLOP/s on %d threads (= the cgroup CPU quota of this box; %d hardware threads visible)"
+                  % (n, h, w, dt_all, n * flops_full / dt_all / 1e9, threads, os.cpu_count() or 0),
         "single_thread_value": (fl1 / dt_one) / flops_full,
         "single_thread_sample": "same code, 1 thread, one 1x3x%dx%d forward (%.1f GFLOP) in %.1f s = %.1f GFLOP/s, "
                                 "scaled by FLOPs to the 544x736 image" % (h1, w1, fl1 / 1e9, dt_one, fl1 / dt_one / 1e9),

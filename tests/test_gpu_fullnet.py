@@ -15,7 +15,7 @@ TOL = 1e-3
 def _oracle(proto, layers, img):
     from oracle import oracle as O
 
-    O.set_threads(min(16, os.cpu_count() or 1))
+    O.set_threads(min(16, os.cpu_count() or 1))  # the GPU box grants 16 CPUs of cgroup quota
     return O.OracleNet(proto, layers).forward(data=img)
 
 
