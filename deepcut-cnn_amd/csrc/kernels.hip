@@ -445,6 +445,14 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   ConvGemmParams p = p_in;
   const int ntaps = p.nty * p.ntx;
   if (ntaps < 1 || ntaps > kMaxTaps || p.klen % e.BK != 0 || p.Ktot != ntaps * p.klen) return (int)hipErrorInvalidValue;
+  // buffer (V#) addressing carries 32-bit byte offsets: every tensor of a launch must stay below 2 GiB
+  {
+    const double lim = 2147483647.0;
+    const double xb = 4.0 * (double)p.NB * (double)p.x_img_stride;
+    const double yb = 4.0 * ((double)p.NB * (double)p.y_img_stride);
+    const double wb = 4.0 * (double)p.Cout * (double)p.Ktot;
+    if (xb >= lim || yb >= lim || wb >= lim) return (int)hipErrorInvalidValue;
+  }
   int bias = 0;  // most negative tap displacement: one of the four corners of the arithmetic grid
   for (int ty : {0, p.nty - 1})
     for (int tx : {0, p.ntx - 1})

@@ -1383,7 +1383,7 @@ void Net::run_launch(const Launch& l, void* s) {
     case Launch::CONV: {
       ConvGemmParams g = l.cg;
       g.dbg = nullptr;
-      g.x = X.dev + l.x_off;
+      g.x = X.dev;
       g.y = Y.dev + l.y_off;
       g.resid = l.in2 >= 0 ? storages[l.in2]->dev + l.y_off : nullptr;
       g.w = vecs[l.w]->dev;
@@ -1431,7 +1431,13 @@ void Net::run_launch(const Launch& l, void* s) {
                      c2 / nw, c3 / nw);
         g.dbg = nullptr;
       }
-      KCHECK(launch_conv_gemm(g, l.variant, s));
+      {
+        const int rc = launch_conv_gemm(g, l.variant, s);
+        if (rc == (int)hipErrorInvalidValue)
+          throw DcError(DC_EUNSUP, "launch '" + l.label + "': unsupported geometry (a tensor of 2 GiB or more per launch — "
+                                   "split the batch — or a tap / K layout this variant cannot take)");
+        KCHECK(rc);
+      }
       break;
     }
     case Launch::POOL:

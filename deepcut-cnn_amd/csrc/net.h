@@ -109,7 +109,7 @@ struct Launch {
   ConvGemmParams cg{};  // pointers filled at launch time
   int variant = 0;
   int w = -1, scale = -1, shift = -1;  // DevVec ids
-  long x_off = 0, y_off = 0;           // element offsets into in / out images
+  long y_off = 0;                      // element offset of this launch's first output (deconvolution classes)
   double flops = 0;                    // algorithmic 2*MAC
   long grid = 0;
   // POOL
@@ -179,11 +179,5 @@ struct Net {
   void release_graph();
   void autotune();
 };
-
-// stand-alone layer forward on the device (Layer::Forward_gpu surface), host NCHW in/out
-void layer_forward(const std::string& layer_prototxt, const std::vector<const float*>& bottoms,
-                   const std::vector<std::vector<int>>& bottom_shapes,
-                   const std::vector<std::vector<float>>& weights, std::vector<float>& top,
-                   std::vector<int>& top_shape);
 
 }  // namespace dc
