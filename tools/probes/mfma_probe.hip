@@ -102,9 +102,34 @@ void run(const char* name, K kern, int blocks, int threads, double flop_per_mfma
   printf("%-34s blocks=%4d thr=%d  %8.3f ms  %7.1f TF/s  %6.1f ns per MFMA per wave\n", name, blocks, threads, ms, tf, ns_per_mfma_per_wave);
 }
 
-int main() {
+template <typename K>
+void run_long(const char* name, K kern, int blocks, int threads, double flop_per_mfma, float* d, int iters, int reps) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, 10, 1.f, 2.f);
+  hipDeviceSynchronize();
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, iters, 1.f, 2.f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double mfma = (double)blocks * threads / 64 * iters * 16.0;
+    printf("%-28s rep %d: %8.1f ms  %7.1f TF/s\n", name, r, ms, mfma * flop_per_mfma / (ms * 1e-3) / 1e12);
+  }
+}
+
+int main(int argc, char** argv) {
   float* d;
   hipMalloc(&d, 4096 * 1024 * 4);
+  if (argc > 1) {  // sustained-load mode: ~0.2 s launches, repeated
+    const double F32 = 2.0 * 32 * 32 * 2;
+    run_long("32x32x2 4acc sustained", k32<4, 0>, 256, 256, F32, d, 400000, 6);
+    run_long("32x32x2 4acc 2w/SIMD sustained", k32<4, 0>, 512, 256, F32, d, 200000, 4);
+    return 0;
+  }
   const double F32 = 2.0 * 32 * 32 * 2, F16 = 2.0 * 16 * 16 * 4;
   run("32x32x2 1acc 1wave/SIMD", k32<1, 0>, 256, 256, F32, d);
   run("32x32x2 2acc 1wave/SIMD", k32<2, 0>, 256, 256, F32, d);
