@@ -226,3 +226,58 @@ def test_pipeline_of_clones_matches_sequential(gpu_caffe, synth152):
     for i in range(len(imgs)):
         for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
             assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)
+
+
+@pytest.mark.parametrize("hw", [(16, 24), (24, 16), (40, 8)])
+def test_tiny_inputs(gpu_caffe, synth152, hw):
+    """Edge of the shape space: res4/res5 maps of 1x2 / 2x1 / 3x1 pixels, every tile mostly padding."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, layers = synth152
+    h, w = hw
+    proto = deepercut_prototxt(152, h, w)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True)
+    img = rand_image(9, h, w)
+    net.blobs["data"].data[...] = img
+    out = net.forward()
+    ref = _oracle(proto, layers, img)
+    for k in out:
+        assert out[k].shape == ref[k].shape
+        assert float(np.abs(out[k] - ref[k]).max()) <= TOL, k
+
+
+def test_partial_forward_ranges_unfused(gpu_caffe, synth152):
+    """Net::ForwardFromTo(start, end) with DC_OPT_FUSE 0 (net.cpp:565-581, test_net.cpp TestFromTo): run up to a
+    layer, overwrite the blob on the host (HEAD_AT_CPU -> re-uploaded), continue from the next layer."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, layers = synth152
+    proto = deepercut_prototxt(152, 64, 64)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, fuse=0)
+    img = rand_image(10, 64, 64)
+    net.blobs["data"].data[...] = img
+    names = net._layer_names
+    cut_idx = names.index("res2c_relu")
+    net._forward(0, cut_idx)  # pycaffe's forward(end=...) needs a layer whose name is also a blob name
+    mid = net.blobs["res2c"].data.copy()
+    ref = _oracle(proto, layers, img)
+    assert np.abs(mid - ref["res2c"]).max() <= 1e-3
+    net.blobs["res2c"].data[...] = mid * 0.5  # host write: authoritative copy is now on the CPU
+    net._forward(cut_idx + 1, len(names) - 1)
+    out = {k: net.blobs[k].data for k in net.outputs}
+    # oracle: same graph continued from the modified blob
+    from oracle import oracle as O
+    import re
+
+    tail_layers = proto.split("\n")
+    cut = [i for i, l in enumerate(tail_layers) if 'name: "res2c_relu"' in l][0]
+    tail = 'input: "res2c" input_dim: 1 input_dim: 256 input_dim: 16 input_dim: 16\n' + "\n".join(tail_layers[cut + 1:])
+    ref2 = O.OracleNet(tail, layers).forward(res2c=mid * 0.5)
+    for k in ("prob", "loc_pred", "next_pred"):
+        assert float(np.abs(out[k] - ref2[k]).max()) <= TOL, k
+    # with fusion on, a range that cuts through a fused group is refused, not silently mis-executed
+    net2 = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, fuse=2)
+    net2.blobs["data"].data[...] = img
+    with pytest.raises(gpu_caffe.DeepcutError) as e:
+        net2._forward(0, net2._layer_names.index("bn_conv1"))
+    assert "cuts through the fused group" in str(e.value)
