@@ -28,6 +28,7 @@ for p in (ROOT, PKG, os.path.join(PKG, "python")):
         sys.path.insert(0, p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (no sparsity)
 
 
 def inject_weights(net, layers):
@@ -122,6 +123,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per rank per step")
     ap.add_argument("--depth", type=int, default=152)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="device element type: f32 (the headline, BASELINE configs[1]) or f16 operands with fp32 "
+                         "accumulation (BASELINE configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--breakdown", default="", help="write the per-launch hipEvent table to this file")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "3")),
@@ -160,7 +164,7 @@ def main():
     layers = synth_weights(args.depth, seed=0)
     S = max(1, args.streams)
     proto = deepercut_prototxt(args.depth, H, W, B)
-    net = caffe.Net(proto, caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1)
+    net = caffe.Net(proto, caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1, dtype=args.dtype)
     inject_weights(net, layers)
     net.blobs["data"].reshape(B, 3, H, W)
     net.reshape()
@@ -253,7 +257,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic (randn*50 images resident in HBM; conditioned random-init weights, seed 0)",
             "config": {
                 "workload": "batch=%d single-scale %dx%d (WxH) ResNet-%d DeeperCut forward per GPU, fp32 "
@@ -273,15 +277,16 @@ def main():
                                       "tflops": total_images * flops_img / lat_dt / 1e12},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_gemm (fp32 v_mfma_f32_32x32x2_f32 gather-GEMM, all tile variants)",
+                "kernel": "conv_gemm (%s gather-GEMM, all tile variants)" % (
+                    "f16 v_mfma_f32_32x32x16_f16, fp32 accumulate" if args.dtype == "f16" else "fp32 v_mfma_f32_32x32x2_f32"),
                 "achieved": achieved,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "peak": PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "frac": achieved / (PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS),
                 "flops_per_launch": per_launch_flops,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_image": conv_launches,
-                "traffic": hbm_traffic_from_profile(),
+                "traffic": hbm_traffic_from_profile() if args.dtype == "f32" else None,
                 "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json); "
                                 "algorithmic minimum %.1f MB" % ((2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) / conv_launches / 1e6),
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,

@@ -110,6 +110,8 @@ int dc_net_set_option(dc_net* net, int key, int value) {
       n->fuse = value;
     } else if (key == DC_OPT_HIPGRAPH) {
       n->use_graph = value;
+    } else if (key == DC_OPT_DTYPE) {
+      n->set_dtype(value);
     } else {
       throw DcError(DC_EINVAL, "unknown option " + std::to_string(key));
     }
@@ -260,7 +262,7 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev, int* pitch) {
     }
     if (s.view_of >= 0) {  // channel slice of a concatenated head tensor
       Storage& base = *s.owner->storages[s.view_of];
-      *dev = base.dev + s.view_c0;
+      *dev = base.dev_at(s.view_c0);
       if (pitch) *pitch = base.cp();
     } else {
       *dev = s.dev;

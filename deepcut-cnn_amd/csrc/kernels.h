@@ -17,7 +17,8 @@ constexpr int kMaxTaps = 32;  // tap-validity masks are one 32-bit word per stag
 // 7 row-taps of 8 NHWC4 pixels) and, per output-parity class, the stride-2 Deconvolution heads.
 // The tap grid is arithmetic so the kernel advances it with scalar adds (no table loads in the K loop).
 struct ConvGemmParams {
-  const float* x;
+  int esize;          // bytes per activation / filter element: 4 (float) or 2 (_Float16); strides are in elements
+  const void* x;
   long x_img_stride;  // elements between images
   int x_row_stride;   // elements between rows
   int x_rows;         // H of the source
@@ -28,16 +29,16 @@ struct ConvGemmParams {
   int x0, ddx;        // element offset of tap column tx: x0 + tx*ddx
   int klen;           // K elements per tap (multiple of the variant's BK)
   int x_bias;         // min over taps of (dy*x_row_stride + xoff) (<= 0); filled by launch_conv_gemm
-  const float* w;
+  const void* w;
   int Ktot;
   int NB, OH, OW;
   int M;  // NB*OH*OW
   int Cout;
-  float* y;  // pre-offset to the first output element of this launch
+  void* y;  // pre-offset to the first output element of this launch
   long y_img_stride;
   int y_row_stride;  // elements per oy step
   int y_pix_stride;  // elements per ox step
-  const float* resid;  // same addressing as y (may alias y), or null
+  const void* resid;  // same addressing as y (may alias y), or null
   const float* scale;  // [Cout] or null (=1)
   const float* shift;  // [Cout] or null (=0)
   int relu;
@@ -56,32 +57,38 @@ int conv_num_variants();
 const ConvVariant& conv_variant(int i);
 // workgroups this variant launches for the problem
 int conv_variant_bk(int i);
+int conv_variant_esize(int i);
 long conv_grid(const ConvGemmParams& p, int variant);
 // returns hipError_t as int
 int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream);
 
+// The remaining kernels take `esize` = bytes per device element (4 float / 2 _Float16); host-side tensors
+// and the per-channel affine vectors are always float.
+
 // MAX pooling, NHWC, windows clipped to the image (pooling_layer.cpp:140-187).
-int launch_maxpool(const float* x, float* y, int NB, int H, int W, int C, int OH, int OW, int k, int s,
+int launch_maxpool(const void* x, void* y, int esize, int NB, int H, int W, int C, int OH, int OW, int k, int s,
                    int pad, void* stream);
 
 // y = act(x*a[c] + b[c] + z)   (a,b,z optional) — the stand-alone BatchNorm/Scale/ReLU/Eltwise/Sigmoid
 // layers when they are not folded into a producing convolution.
-int launch_eltwise(const float* x, const float* z, const float* a, const float* b, float* y, long total,
-                   int C, int relu, int sigmoid, void* stream);
+int launch_eltwise(const void* x, const void* z, const float* a, const float* b, void* y, int esize, long total, int C,
+                   int relu, int sigmoid, void* stream);
 
 // crop the top-left (offset oh,ow) OH x OW window of an NHWC tensor (crop_layer.cpp:37-50)
-int launch_crop(const float* x, float* y, int NB, int H, int W, int C, int oh, int ow, int OH, int OW,
+int launch_crop(const void* x, void* y, int esize, int NB, int H, int W, int C, int oh, int ow, int OH, int OW,
                 void* stream);
 
-// layout changes at the Blob boundary (host side is NCHW, blob.hpp:153-164)
+// layout changes at the Blob boundary (host side is NCHW float, blob.hpp:153-164)
 // src NCHW [NB,C,H,W] -> dst NHWC with channel pitch CP (>= C, extra channels zeroed)
-int launch_nchw_to_nhwc(const float* src, float* dst, int NB, int C, int H, int W, int CP, void* stream);
+int launch_nchw_to_nhwc(const float* src, void* dst, int esize, int NB, int C, int H, int W, int CP, void* stream);
 // src NHWC pitch CP, channels [c0, c0+C) -> dst NCHW [NB,C,H,W]
-int launch_nhwc_to_nchw(const float* src, float* dst, int NB, int C, int H, int W, int CP, int c0,
+int launch_nhwc_to_nchw(const void* src, float* dst, int esize, int NB, int C, int H, int W, int CP, int c0,
                         void* stream);
+// packed filter image float -> half (fp16 nets)
+int launch_f32_to_f16(const float* src, void* dst, long n, void* stream);
 
 // pose decode (estimate_pose.py:131-143) from NHWC score / refinement maps (channel pitch + first channel)
-int launch_pose_decode(const float* prob, int pcp, int pc0, const float* loc, int lcp, int lc0, int NB, int H, int W,
-                       int J, double scale, double* out, void* stream);
+int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H,
+                       int W, int J, double scale, double* out, void* stream);
 
 }  // namespace dc

@@ -41,30 +41,64 @@ __device__ __forceinline__ f32x4 dc_bload4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 constexpr unsigned kOOB = 0x80000000u;  // > any tensor size: hardware returns 0
 
-template <int BM, int BN, int BK, int WR, int WC, int WK, int PF>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// element-type traits of the gather-GEMM: activations / filters are float or _Float16 in HBM and LDS,
+// accumulation, the epilogue arithmetic and its constants are always float
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int SPC = 4;  // MFMA steps per 32-byte operand chunk: 4 x v_mfma_f32_32x32x2_f32 (k = 8)
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  }
+};
+template <>
+struct Elem<_Float16> {
+  static constexpr int SPC = 1;  // 1 x v_mfma_f32_32x32x16_f16 (k = 16) per 32-byte chunk
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, off, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF>
 __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int ES = sizeof(T);          // bytes per element
+  constexpr int VEC = 16 / ES;           // elements per 16-byte vector
+  constexpr int SPC = Elem<T>::SPC;
   constexpr int NW = WR * WC * WK;       // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int LDK = BK + 4;            // padded LDS row, floats (16-B aligned, bank-spread)
+  constexpr int LDB = BK * ES + 16;      // padded LDS row, bytes (16-B aligned, bank-spread)
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1 && TM % 32 == 0 && TN % 32 == 0, "wave tile = multiples of 32x32");
-  constexpr int C4 = BK / 4;             // float4 per tile row
+  constexpr int C4 = BK / VEC;           // 16-byte vectors per tile row
   constexpr int RPP = NT / C4;           // tile rows covered by one pass of the workgroup's threads
   constexpr int NA = BM / RPP, NBV = BN / RPP;
   static_assert(NA >= 1 && NBV >= 1, "tile too small for the loader");
-  constexpr int KCH = BK / 8;            // 8-deep k chunks per tile
+  constexpr int KCH = BK * ES / 32;      // 32-byte operand chunks per tile row
   static_assert(KCH % WK == 0, "k chunks must split evenly over WK");
   constexpr int NCH = KCH / WK;          // chunks this wave owns per tile
   static_assert(NCH >= 2 && NCH % 2 == 0, "the software pipeline needs an even number (>=2) of chunks per wave");
-  constexpr int TILE = (BM + BN) * LDK;  // floats per LDS stage
+  constexpr int NST = NCH * SPC;         // MFMA steps per tile per wave
+  static_assert(NST >= 4, "the pipeline places its work in 4 distinct MFMA steps");
+  constexpr int GBAR = SPC > 1 ? NST - 3 : NST - 1;  // step before which the tile's barrier is taken
+  constexpr int TILEB = (BM + BN) * LDB;  // bytes per LDS stage
   constexpr int RPW = 16 / WK;           // accumulator registers each split-K wave finalises
-  static_assert((WK - 1) * BM * BN <= 2 * TILE, "split-K partials must fit in the tile buffers");
+  static_assert((WK - 1) * BM * BN * 4 <= 2 * TILEB, "split-K partials must fit in the tile buffers");
   constexpr bool EARLY_RESID = FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 4 * BM];
-  i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILE);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB + 16 * BM];
+  i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILEB);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
+  const T* px = reinterpret_cast<const T*>(p.x);
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -97,7 +131,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
-  const int T = p.Ktot / BK;
+  const int T_ = p.Ktot / BK;
   auto stamp = [&](int slot) {
     if (p.dbg && lane == 0) {
       long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
@@ -110,24 +144,25 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // ---- prologue, ordered so that every exposed memory round trip overlaps another -------------------
   // (1) filter rows need no pixel decode: their first PF tiles go out immediately
   const int lrow = t / C4;
-  const int lc4 = (t % C4) * 4;
+  const int lcb = (t % C4) * 16;  // byte column of this thread's 16-byte vector
+  const int lce = lcb / ES;       // same, in elements
   unsigned bvoff[NBV];
 #pragma unroll
   for (int j = 0; j < NBV; ++j) {
     const int n = n0 + lrow + RPP * j;
-    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lc4) * 4u : kOOB;  // rows past Cout read as zeros
+    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lce) * ES : kOOB;  // rows past Cout read as zeros
   }
   const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(p.w, 0x7fffffffu);
-  f32x4 ra[PF][NA], rb[PF][NBV];
+  f32x4 ra[PF][NA], rb[PF][NBV];  // 16-byte containers (4 floats or 8 halves)
   int kg = 0;
   auto gload_b = [&](int slot) {
 #pragma unroll
-    for (int j = 0; j < NBV; ++j) rb[slot][j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * 4u);
+    for (int j = 0; j < NBV; ++j) rb[slot][j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * ES);
     kg += BK;
   };
 #pragma unroll
   for (int k = 0; k < PF; ++k)
-    if (k < T) gload_b(k);
+    if (k < T_) gload_b(k);
 
   // (2) epilogue constants (folded BatchNorm/Scale/bias) also travel now
   float sc[FN], sh[FN];
@@ -149,10 +184,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       const int rem = m - n * ohw;
       const int oy = rem / p.OW;
       const int ox = rem - oy * p.OW;
-      ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * 4);
+      ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES);
       ri.y = oy * p.sy;
       ri.z = ox * p.sx;
-      ri.w = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * 4);
+      ri.w = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * ES);
     }
     rowinfo[t] = ri;
   }
@@ -163,13 +198,13 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const i32x4 ri = rowinfo[lrow + RPP * i];
-    avoff[i] = (unsigned)ri.x + lc4 * 4;
+    avoff[i] = (unsigned)ri.x + lcb;
     unsigned mk = 0;
     int bit = 0;
     for (int ty = 0; ty < p.nty; ++ty) {
       const bool rok = (unsigned)(ri.y + p.dy0 + ty * p.ddy) < (unsigned)p.x_rows;
       for (int tx = 0; tx < p.ntx; ++tx, ++bit) {
-        const bool ok = rok && (unsigned)(ri.z + lc4 + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen;
+        const bool ok = rok && (unsigned)(ri.z + lce + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen;
         mk |= (ok ? 1u : 0u) << bit;
       }
     }
@@ -177,13 +212,13 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
   // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
-  const __amdgpu_buffer_rsrc_t xr = dc_rsrc(p.x + p.x_bias, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t xr = dc_rsrc(px + p.x_bias, 0x7fffffffu);
   // tap cursor, all uniform (SALU): (tx, c0, running bit) and the element displacement of the current tap
   int tx = 0, c0 = 0, tbit = 0;
   int row_soff = p.dy0 * p.x_row_stride + p.x0 - p.x_bias;  // displacement of tap (ty, 0)
   int tap_soff = row_soff;
   auto gload_a = [&](int slot) {
-    const unsigned soff = (unsigned)(tap_soff + c0) * 4u;
+    const unsigned soff = (unsigned)(tap_soff + c0) * ES;
     const unsigned bit = 1u << tbit;
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[slot][i] = dc_bload4(xr, (amask[i] & bit) ? avoff[i] : kOOB, soff);
@@ -202,7 +237,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   };
 #pragma unroll
   for (int k = 0; k < PF; ++k)
-    if (k < T) gload_a(k);
+    if (k < T_) gload_a(k);
 
   // (5) output addressing of the rows this wave will finalise, and (small tiles) the shortcut itself.
   //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
@@ -220,8 +255,8 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
           const int r = wk * RPW + e;
           const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
           const int co = n0 + wc * TN + b * 32 + (lane & 31);
-          const unsigned off = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * 4 : kOOB;
-          rs[(a * FN + b) * RPW + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off, 0, 0));
+          const unsigned off = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;
+          rs[(a * FN + b) * RPW + e] = Elem<T>::load(rr, off);
         }
   }
 
@@ -234,43 +269,45 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   auto lstore = [&](int buf, int slot) {
-    float* As = smem + buf * TILE;
-    float* Bs = As + BM * LDK;
+    unsigned char* As = smem + buf * TILEB;
+    unsigned char* Bs = As + BM * LDB;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDK + lc4) = ra[slot][i];
+      *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDB + lcb) = ra[slot][i];
 #pragma unroll
     for (int j = 0; j < NBV; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LDK + lc4) = rb[slot][j];
+      *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * j) * LDB + lcb) = rb[slot][j];
   };
-  // MFMA operand fragments, two register sets (chunk parity)
+  // MFMA operand fragments, two register sets (chunk parity); lane holds 16 bytes of row (lane&31):
+  // fp32: k = 4*(lane>>5) .. +3 of the 8-deep chunk; fp16: k = 8*(lane>>5) .. +7 of the 16-deep chunk
   f32x4 av[2][FM], bv[2][FN];
-  const int frag_a = (wr * TM + (lane & 31)) * LDK + (lane >> 5) * 4 + wk * 8;
-  const int frag_b = BM * LDK + (wc * TN + (lane & 31)) * LDK + (lane >> 5) * 4 + wk * 8;
+  const int frag_a = (wr * TM + (lane & 31)) * LDB + (lane >> 5) * 16 + wk * 32;
+  const int frag_b = BM * LDB + (wc * TN + (lane & 31)) * LDB + (lane >> 5) * 16 + wk * 32;
   auto frag_load = [&](int buf, int q, int set) {
-    const float* As = smem + buf * TILE + frag_a + q * WK * 8;
-    const float* Bs = smem + buf * TILE + frag_b + q * WK * 8;
+    const unsigned char* As = smem + buf * TILEB + frag_a + q * WK * 32;
+    const unsigned char* Bs = smem + buf * TILEB + frag_b + q * WK * 32;
 #pragma unroll
-    for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDK);
+    for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDB);
 #pragma unroll
-    for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDK);
+    for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDB);
   };
 
   // ---- K loop: software pipeline -------------------------------------------------------------------
   // A wave issues in order, and on gfx950 the fp32 MFMA shares the SIMD's fp32 datapath with VALU, so
   // (a) VALU work in the loop is paid on top of the MFMAs -> there is almost none (buffer addressing);
   // (b) anything not interleaved BETWEEN MFMAs in program order stalls the matrix pipe -> the loop's
-  //     non-MFMA work is placed into the 4 MFMA steps of each 8-deep chunk and pinned with sched_barrier:
-  //   chunk 0, step 0: ds_read the fragments of chunk 1
-  //            step 1: ds_write tile it+1 (ring slot loaded PF iterations ago) into the idle LDS stage
-  //            step 2/3: issue the global loads of tile it+1+PF into the ring slot just freed
-  //   chunk q, step 0: ds_read the fragments of chunk q+1
-  //   last chunk, step 1: barrier, then ds_read chunk 0 of tile it+1 from the stage just filled —
-  //            its latency is covered by the 3 remaining MFMA steps of this tile.
+  //     non-MFMA work is placed into specific MFMA steps of the tile and pinned with sched_barrier.
+  // Per tile a wave owns NCH 32-byte chunks = NST MFMA steps (4 per chunk in fp32, 1 in fp16):
+  //   first step of chunk q: ds_read the fragments of chunk q+1
+  //   step 1: ds_write tile it+1 (ring slot loaded PF iterations ago) into the idle LDS stage
+  //   step 2/3: issue the global loads of tile it+1+PF into the ring slot just freed
+  //   step GBAR: barrier, then ds_read chunk 0 of tile it+1 from the stage just filled — in fp32 its latency
+  //            is covered by the 3 remaining MFMA steps of this tile (all fragment reads of the current
+  //            stage are issued before the barrier, so the next tile may overwrite it).
   // Tile k lives in ring slot k % PF: filters are streamed from HBM once per forward (263 MB per image
   // sweep the 256 MB Infinity Cache), so a single tile of lookahead does not cover their latency.
   lstore(0, 0);
-  if (PF < T) {
+  if (PF < T_) {
     gload_a(0);
     gload_b(0);
   }
@@ -278,35 +315,37 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   frag_load(0, 0, 0);
   stamp(1);
   stamp(5);
-  for (int it0 = 0; it0 < T; it0 += PF) {
+  for (int it0 = 0; it0 < T_; it0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int it = it0 + u;
-      if (it >= T) break;
+      if (it >= T_) break;
       const int buf = it & 1;
       const int slot = (u + 1) % PF;  // ring slot of tile it+1 (it0 is a multiple of PF)
-      const bool more1 = it + 1 < T, moreP = it + 1 + PF < T;
+      const bool more1 = it + 1 < T_, moreP = it + 1 + PF < T_;
 #pragma unroll
-      for (int q = 0; q < NCH; ++q) {
-        const int cur = q & 1;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          if (st == 0 && q + 1 < NCH) frag_load(buf, q + 1, cur ^ 1);
-          if (st == 1 && q + 1 == NCH && more1) {  // after step 0 has consumed (waited for) this chunk's operands
-            __syncthreads();
-            frag_load(buf ^ 1, 0, 0);
-          }
-          if (q == 0 && st == 1 && more1) lstore(buf ^ 1, slot);
-          if (q == 0 && st == 2 && moreP) gload_a(slot);
-          if (q == 0 && st == 3 && moreP) gload_b(slot);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int a = 0; a < FM; ++a)
-#pragma unroll
-            for (int b = 0; b < FN; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+      for (int g = 0; g < NST; ++g) {
+        const int q = g / SPC, st = g % SPC, cur = q & 1;
+        if (st == 0 && q + 1 < NCH) frag_load(buf, q + 1, cur ^ 1);
+        if (g == GBAR && more1) {  // every fragment read of this stage has been issued (and is waited for here)
+          __syncthreads();
+          frag_load(buf ^ 1, 0, 0);
         }
+        if (g == 1 && more1) lstore(buf ^ 1, slot);
+        if (g == 2 && moreP) gload_a(slot);
+        if (g == 3 && moreP) gload_b(slot);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) {
+            if constexpr (SPC == 4)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
+            else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[cur][a]),
+                                                                 __builtin_bit_cast(f16x8, bv[cur][b]), acc[a][b], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -315,11 +354,11 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   stamp(6);
   // ---- epilogue ---------------------------------------------------------------------------------------
   // in-workgroup split-K: wave wk keeps registers [wk*RPW, (wk+1)*RPW) of every fragment and receives
-  // the other waves' partials for them through LDS, so all four waves store (no idle waves, 1/WK of the
+  // the other waves' partials for them through LDS, so all waves store (no idle waves, 1/WK of the
   // LDS traffic of a gather-to-one reduction)
   if (WK > 1) {
     __syncthreads();  // tile buffers are free
-    float* part = smem;
+    float* part = reinterpret_cast<float*>(smem);
     // layout: [dst wave q][src wave (wk != q) slot][wr*WC+wc][a][b][e][lane]
 #pragma unroll
     for (int q = 0; q < WK; ++q) {
@@ -343,8 +382,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
         for (int b = 0; b < FN; ++b)
 #pragma unroll
           for (int e = 0; e < RPW; ++e) {
-            // runtime register index only inside fully unrolled code: wk is wave-uniform but not constant,
-            // so select with a compile-time loop over the WK possibilities
+            // wk is wave-uniform but not a compile-time constant: select the register with an unrolled loop
 #pragma unroll
             for (int w2 = 0; w2 < WK; ++w2)
               if (w2 == wk) acc[a][b][w2 * RPW + e] += src[((a * FN + b) * RPW + e) * 64];
@@ -365,15 +403,14 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       for (int e = 0; e < RPW; ++e) {
         const int r = wk * RPW + e;
         const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
-        off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * 4 : kOOB;  // masked lanes: load 0 / store dropped
+        off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * ES : kOOB;  // masked lanes: load 0 / store dropped
       }
       if (EARLY_RESID) {
 #pragma unroll
         for (int e = 0; e < RPW; ++e) rv[e] = p.resid ? rs[(a * FN + b) * RPW + e] : 0.f;
       } else if (p.resid) {  // all shortcut loads of the fragment in flight at once
 #pragma unroll
-        for (int e = 0; e < RPW; ++e)
-          rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[e], 0, 0));
+        for (int e = 0; e < RPW; ++e) rv[e] = Elem<T>::load(rr, off[e]);
       } else {
 #pragma unroll
         for (int e = 0; e < RPW; ++e) rv[e] = 0.f;
@@ -387,7 +424,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
         float v = accv * sc[b] + sh[b] + rv[e];
         if (p.relu) v = fmaxf(v, 0.f);
         if (sig) v = 1.f / (1.f + expf(-v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off[e], 0, 0);
+        Elem<T>::store(v, yr, off[e]);
       }
     }
   }
@@ -400,11 +437,17 @@ struct VariantEntry {
   ConvVariant v;
   void (*kernel)(const ConvGemmParams);
   int BK;
+  int esize;
 };
 #define DC_VARIANT(BM, BN, BK, WR, WC, WK, PF)                                     \
   {                                                                                \
     {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
-        conv_gemm_kernel<BM, BN, BK, WR, WC, WK, PF>, BK                           \
+        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4                 \
+  }
+#define DC_VARIANT_H(BM, BN, BK, WR, WC, WK, PF)                                   \
+  {                                                                                \
+    {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},         \
+        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2              \
   }
 const VariantEntry kVariants[] = {
     DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
@@ -425,6 +468,17 @@ const VariantEntry kVariants[] = {
     DC_VARIANT(64, 64, 32, 2, 2, 2, 3),    // 14
     DC_VARIANT(32, 32, 128, 1, 1, 8, 3),   // 15
     DC_VARIANT(64, 128, 32, 2, 2, 2, 2),   // 16
+    // fp16 operands (v_mfma_f32_32x32x16_f16, fp32 accumulate); BK in halves: 64 = one 128-B line per row
+    DC_VARIANT_H(128, 128, 64, 2, 2, 1, 2),   // 17
+    DC_VARIANT_H(128, 64, 64, 2, 2, 1, 2),    // 18
+    DC_VARIANT_H(64, 128, 64, 2, 2, 1, 2),    // 19
+    DC_VARIANT_H(64, 64, 64, 2, 2, 1, 3),     // 20
+    DC_VARIANT_H(64, 64, 128, 2, 2, 2, 2),    // 21: 8 waves
+    DC_VARIANT_H(32, 64, 128, 1, 2, 2, 3),    // 22
+    DC_VARIANT_H(64, 32, 128, 2, 1, 2, 3),    // 23
+    DC_VARIANT_H(32, 64, 256, 1, 2, 4, 2),    // 24: 8 waves, split-K 4
+    DC_VARIANT_H(128, 128, 128, 2, 2, 2, 2),  // 25: 8 waves
+    DC_VARIANT_H(32, 32, 256, 1, 1, 4, 2),    // 26
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -432,6 +486,7 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 int conv_num_variants() { return kNumVariants; }
 const ConvVariant& conv_variant(int i) { return kVariants[i].v; }
 int conv_variant_bk(int i) { return kVariants[i].BK; }
+int conv_variant_esize(int i) { return kVariants[i].esize; }
 
 long conv_grid(const ConvGemmParams& p, int variant) {
   const ConvVariant& v = kVariants[variant].v;
@@ -443,14 +498,15 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   if (variant < 0 || variant >= kNumVariants) return (int)hipErrorInvalidValue;
   const VariantEntry& e = kVariants[variant];
   ConvGemmParams p = p_in;
+  if (p.esize != e.esize) return (int)hipErrorInvalidValue;
   const int ntaps = p.nty * p.ntx;
   if (ntaps < 1 || ntaps > kMaxTaps || p.klen % e.BK != 0 || p.Ktot != ntaps * p.klen) return (int)hipErrorInvalidValue;
   // buffer (V#) addressing carries 32-bit byte offsets: every tensor of a launch must stay below 2 GiB
   {
     const double lim = 2147483647.0;
-    const double xb = 4.0 * (double)p.NB * (double)p.x_img_stride;
-    const double yb = 4.0 * ((double)p.NB * (double)p.y_img_stride);
-    const double wb = 4.0 * (double)p.Cout * (double)p.Ktot;
+    const double xb = (double)e.esize * (double)p.NB * (double)p.x_img_stride;
+    const double yb = (double)e.esize * ((double)p.NB * (double)p.y_img_stride);
+    const double wb = (double)e.esize * (double)p.Cout * (double)p.Ktot;
     if (xb >= lim || yb >= lim || wb >= lim) return (int)hipErrorInvalidValue;
   }
   int bias = 0;  // most negative tap displacement: one of the four corners of the arithmetic grid
@@ -492,40 +548,42 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MAX pooling (NHWC, float4 over channels)
+// MAX pooling (NHWC, 16 bytes of channels per thread), windows clipped to the image
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int NB, int H, int W, int C, int OH, int OW, int k,
-                                                      int s, int pad) {
-  const int c4n = C / 4;
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int NB, int H, int W,
+                                                      int C, int OH, int OW, int k, int s, int pad) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int cvn = C / V;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)NB * OH * OW * c4n;
+  long total = (long)NB * OH * OW * cvn;
   if (idx >= total) return;
-  int c4 = (int)(idx % c4n);
-  long pix = idx / c4n;
+  int cv = (int)(idx % cvn);
+  long pix = idx / cvn;
   int ox = (int)(pix % OW);
   long t2 = pix / OW;
   int oy = (int)(t2 % OH);
   int n = (int)(t2 / OH);
   int hs = oy * s - pad, ws = ox * s - pad;
-  int he = min(hs + k, H), we = min(ws + k, W);  // pooling_layer.cpp:150-155 (pad == 0 on this path)
+  int he = min(hs + k, H), we = min(ws + k, W);  // pooling_layer.cpp:150-155
   hs = max(hs, 0);
   ws = max(ws, 0);
-  f32x4 m = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  vec_t m;
+#pragma unroll
+  for (int q = 0; q < V; ++q) m[q] = (T)(sizeof(T) == 4 ? -3.402823466e+38f : -65504.f);
   for (int iy = hs; iy < he; ++iy)
     for (int ix = ws; ix < we; ++ix) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + iy) * W + ix) * C + c4 * 4);
-      m.x = v.x > m.x ? v.x : m.x;
-      m.y = v.y > m.y ? v.y : m.y;
-      m.z = v.z > m.z ? v.z : m.z;
-      m.w = v.w > m.w ? v.w : m.w;
+      vec_t v = *reinterpret_cast<const vec_t*>(x + (((long)n * H + iy) * W + ix) * C + cv * V);
+#pragma unroll
+      for (int q = 0; q < V; ++q) m[q] = v[q] > m[q] ? v[q] : m[q];
     }
-  *reinterpret_cast<f32x4*>(y + (((long)n * OH + oy) * OW + ox) * C + c4 * 4) = m;
+  *reinterpret_cast<vec_t*>(y + (((long)n * OH + oy) * OW + ox) * C + cv * V) = m;
 }
 
-__global__ __launch_bounds__(256) void maxpool_scalar_kernel(const float* __restrict__ x,
-                                                             float* __restrict__ y, int NB, int H, int W,
-                                                             int C, int OH, int OW, int k, int s, int pad) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_scalar_kernel(const T* __restrict__ x, T* __restrict__ y, int NB, int H,
+                                                             int W, int C, int OH, int OW, int k, int s, int pad) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)NB * OH * OW * C;
   if (idx >= total) return;
@@ -542,30 +600,38 @@ __global__ __launch_bounds__(256) void maxpool_scalar_kernel(const float* __rest
   float m = -3.402823466e+38f;
   for (int iy = hs; iy < he; ++iy)
     for (int ix = ws; ix < we; ++ix) {
-      float v = x[(((long)n * H + iy) * W + ix) * C + c];
+      float v = (float)x[(((long)n * H + iy) * W + ix) * C + c];
       m = v > m ? v : m;
     }
-  y[idx] = m;
+  y[idx] = (T)m;
 }
 
-int launch_maxpool(const float* x, float* y, int NB, int H, int W, int C, int OH, int OW, int k, int s,
-                   int pad, void* stream) {
-  if (C % 4 == 0) {
-    long total = (long)NB * OH * OW * (C / 4);
+template <typename T>
+static int launch_maxpool_t(const void* x, void* y, int NB, int H, int W, int C, int OH, int OW, int k, int s, int pad,
+                            void* stream) {
+  constexpr int V = 16 / sizeof(T);
+  if (C % V == 0) {
+    long total = (long)NB * OH * OW * (C / V);
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, NB, H, W, C, OH, OW, k, s, pad);
+    hipLaunchKernelGGL(maxpool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (T*)y, NB, H, W, C, OH, OW, k, s, pad);
   } else {
     long total = (long)NB * OH * OW * C;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(maxpool_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, NB, H, W, C, OH, OW, k, s, pad);
+    hipLaunchKernelGGL(maxpool_scalar_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)x, (T*)y, NB, H, W, C, OH, OW, k, s, pad);
   }
   return (int)hipGetLastError();
 }
 
+int launch_maxpool(const void* x, void* y, int esize, int NB, int H, int W, int C, int OH, int OW, int k, int s,
+                   int pad, void* stream) {
+  return esize == 2 ? launch_maxpool_t<_Float16>(x, y, NB, H, W, C, OH, OW, k, s, pad, stream)
+                    : launch_maxpool_t<float>(x, y, NB, H, W, C, OH, OW, k, s, pad, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
-// stand-alone elementwise: y = act(x*a[c] + b[c] + z)
+// stand-alone elementwise: y = act(x*a[c] + b[c] + z)   (arithmetic in float)
 // ------------------------------------------------------------------------------------------------
 __device__ inline float dc_act(float v, int relu, int sigmoid) {
   if (relu) v = fmaxf(v, 0.f);
@@ -573,73 +639,79 @@ __device__ inline float dc_act(float v, int relu, int sigmoid) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void eltwise_vec4_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ z,
-                                                           const float* __restrict__ a,
-                                                           const float* __restrict__ b, float* __restrict__ y,
-                                                           long total4, int C, int relu, int sigmoid) {
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_vec_kernel(const T* __restrict__ x, const T* __restrict__ z,
+                                                          const float* __restrict__ a, const float* __restrict__ b,
+                                                          T* __restrict__ y, long totalv, int C, int relu, int sigmoid) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
   long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-    int c = (int)((i * 4) % C);
-    if (a) {
-      f32x4 av = *reinterpret_cast<const f32x4*>(a + c);
-      v *= av;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totalv; i += stride) {
+    vec_t v = reinterpret_cast<const vec_t*>(x)[i];
+    vec_t zz;
+    if (z) zz = reinterpret_cast<const vec_t*>(z)[i];
+    int c = (int)((i * V) % C);
+    vec_t o;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      float f = (float)v[q];
+      if (a) f *= a[c + q];
+      if (b) f += b[c + q];
+      if (z) f += (float)zz[q];
+      o[q] = (T)dc_act(f, relu, sigmoid);
     }
-    if (b) {
-      f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
-      v += bv;
-    }
-    if (z) v += reinterpret_cast<const f32x4*>(z)[i];
-    v.x = dc_act(v.x, relu, sigmoid);
-    v.y = dc_act(v.y, relu, sigmoid);
-    v.z = dc_act(v.z, relu, sigmoid);
-    v.w = dc_act(v.w, relu, sigmoid);
-    reinterpret_cast<f32x4*>(y)[i] = v;
+    reinterpret_cast<vec_t*>(y)[i] = o;
   }
 }
 
-__global__ __launch_bounds__(256) void eltwise_scalar_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ z,
-                                                             const float* __restrict__ a,
-                                                             const float* __restrict__ b,
-                                                             float* __restrict__ y, long total, int C,
-                                                             int relu, int sigmoid) {
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_scalar_kernel(const T* __restrict__ x, const T* __restrict__ z,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             T* __restrict__ y, long total, int C, int relu,
+                                                             int sigmoid) {
   long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    float v = x[i];
+    float v = (float)x[i];
     int c = (int)(i % C);
     if (a) v *= a[c];
     if (b) v += b[c];
-    if (z) v += z[i];
-    y[i] = dc_act(v, relu, sigmoid);
+    if (z) v += (float)z[i];
+    y[i] = (T)dc_act(v, relu, sigmoid);
   }
 }
 
-int launch_eltwise(const float* x, const float* z, const float* a, const float* b, float* y, long total,
-                   int C, int relu, int sigmoid, void* stream) {
+template <typename T>
+static int launch_eltwise_t(const void* x, const void* z, const float* a, const float* b, void* y, long total, int C,
+                            int relu, int sigmoid, void* stream) {
+  constexpr int V = 16 / sizeof(T);
   if (total <= 0) return 0;
-  if (C % 4 == 0 && total % 4 == 0) {
-    long t4 = total / 4;
-    long blocks = (t4 + 255) / 256;
+  if (C % V == 0 && total % V == 0) {
+    long tv = total / V;
+    long blocks = (tv + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(eltwise_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, z,
-                       a, b, y, t4, C, relu, sigmoid);
+    hipLaunchKernelGGL(eltwise_vec_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                       (const T*)z, a, b, (T*)y, tv, C, relu, sigmoid);
   } else {
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(eltwise_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       z, a, b, y, total, C, relu, sigmoid);
+    hipLaunchKernelGGL(eltwise_scalar_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)z, a, b, (T*)y, total, C, relu, sigmoid);
   }
   return (int)hipGetLastError();
+}
+
+int launch_eltwise(const void* x, const void* z, const float* a, const float* b, void* y, int esize, long total, int C,
+                   int relu, int sigmoid, void* stream) {
+  return esize == 2 ? launch_eltwise_t<_Float16>(x, z, a, b, y, total, C, relu, sigmoid, stream)
+                    : launch_eltwise_t<float>(x, z, a, b, y, total, C, relu, sigmoid, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // crop (NHWC)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                   int NB, int H, int W, int C, int oh, int ow, int OH,
-                                                   int OW) {
+template <typename T>
+__global__ __launch_bounds__(256) void crop_kernel(const T* __restrict__ x, T* __restrict__ y, int NB, int H, int W,
+                                                   int C, int oh, int ow, int OH, int OW) {
   long total = (long)NB * OH * OW * C;
   long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -653,22 +725,27 @@ __global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ x, 
   }
 }
 
-int launch_crop(const float* x, float* y, int NB, int H, int W, int C, int oh, int ow, int OH, int OW,
+int launch_crop(const void* x, void* y, int esize, int NB, int H, int W, int C, int oh, int ow, int OH, int OW,
                 void* stream) {
   long total = (long)NB * OH * OW * C;
   if (total <= 0) return 0;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(crop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, NB, H, W,
-                     C, oh, ow, OH, OW);
+  if (esize == 2)
+    hipLaunchKernelGGL(crop_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x, (_Float16*)y, NB, H, W, C, oh, ow, OH, OW);
+  else
+    hipLaunchKernelGGL(crop_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)y, NB, H, W, C, oh, ow, OH, OW);
   return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// NCHW <-> NHWC through a 32x32 LDS tile (both sides coalesced)
+// NCHW float (Blob side) <-> NHWC float / half (device image) through a 32x32 LDS tile, both sides coalesced
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
-                                                           float* __restrict__ dst, int C, int HW, int CP) {
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
+                                                           int HW, int CP) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -682,13 +759,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int pix = p0 + ty + 8 * k, c = c0 + tx;
-    if (pix < HW && c < CP) dst[((long)n * HW + pix) * CP + c] = tile[tx][ty + 8 * k];
+    if (pix < HW && c < CP) dst[((long)n * HW + pix) * CP + c] = (T)tile[tx][ty + 8 * k];
   }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src,
-                                                           float* __restrict__ dst, int C, int HW, int CP,
-                                                           int cbase) {
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int HW, int CP, int cbase) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -696,7 +773,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int pix = p0 + ty + 8 * k, c = c0 + tx;
-    tile[ty + 8 * k][tx] = (pix < HW && c < C) ? src[((long)n * HW + pix) * CP + cbase + c] : 0.f;
+    tile[ty + 8 * k][tx] = (pix < HW && c < C) ? (float)src[((long)n * HW + pix) * CP + cbase + c] : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -706,21 +783,58 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+int launch_nchw_to_nhwc(const float* src, void* dst, int esize, int NB, int C, int H, int W, int CP, void* stream) {
+  int HW = H * W;
+  if (NB <= 0 || HW <= 0) return 0;
+  dim3 grid((HW + 31) / 32, (CP + 31) / 32, NB);
+  if (esize == 2)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, C, HW, CP);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, C, HW, CP);
+  return (int)hipGetLastError();
+}
+
+int launch_nhwc_to_nchw(const void* src, float* dst, int esize, int NB, int C, int H, int W, int CP, int c0,
+                        void* stream) {
+  int HW = H * W;
+  if (NB <= 0 || HW <= 0) return 0;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, NB);
+  if (esize == 2)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, C, HW, CP, c0);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, C, HW, CP, c0);
+  return (int)hipGetLastError();
+}
+
+// float -> half conversion of a packed filter image (upload path of fp16 nets)
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
+  long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (_Float16)src[i];
+}
+int launch_f32_to_f16(const float* src, void* dst, long n, void* stream) {
+  if (n <= 0) return 0;
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // pose decode on the device (estimate_pose.py:131-143 `_pose_from_mats`): per joint the FIRST maximum of
 // the score map in row-major order, refined by the location-regression vector at that cell.  One block
 // per (image, joint); only 5 x J doubles per image leave the GPU instead of the maps.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pose_decode_kernel(const float* __restrict__ prob, int pcp, int pc0,
-                                                          const float* __restrict__ loc, int lcp, int lc0, int H,
-                                                          int W, int J, double scale, double* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void pose_decode_kernel(const T* __restrict__ prob, int pcp, int pc0,
+                                                          const T* __restrict__ loc, int lcp, int lc0, int H, int W,
+                                                          int J, double scale, double* __restrict__ out) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const int j = blockIdx.x, n = blockIdx.y, HW = H * W;
   float best = -3.402823466e+38f;
   int bi = 0x7fffffff;
   for (int p = threadIdx.x; p < HW; p += 256) {
-    const float v = prob[((long)n * HW + p) * pcp + pc0 + j];
+    const float v = (float)prob[((long)n * HW + p) * pcp + pc0 + j];
     if (v > best) best = v, bi = p;  // strided scan keeps the smallest index per thread
   }
   sv[threadIdx.x] = best;
@@ -741,39 +855,26 @@ __global__ __launch_bounds__(256) void pose_decode_kernel(const float* __restric
     const int p = si[0] == 0x7fffffff ? 0 : si[0];
     const int row = p / W, col = p - row * W;
     const double kLoc = 7.280109889280518;  // sqrt(53)  (_LOCREF_SCALE_MUL, estimate_pose.py:27)
-    const double ox = (double)loc[((long)n * HW + p) * lcp + lc0 + 2 * j];
-    const double oy = (double)loc[((long)n * HW + p) * lcp + lc0 + 2 * j + 1];
+    const double ox = (double)(float)loc[((long)n * HW + p) * lcp + lc0 + 2 * j];
+    const double oy = (double)(float)loc[((long)n * HW + p) * lcp + lc0 + 2 * j + 1];
     double* o = out + (long)n * 5 * J;
     o[0 * J + j] = ((double)col * 8.0 + 4.0 + ox * kLoc) / scale;
     o[1 * J + j] = ((double)row * 8.0 + 4.0 + oy * kLoc) / scale;
-    o[2 * J + j] = (double)prob[((long)n * HW + p) * pcp + pc0 + j];
+    o[2 * J + j] = (double)(float)prob[((long)n * HW + p) * pcp + pc0 + j];
     o[3 * J + j] = oy * kLoc / scale;
     o[4 * J + j] = ox * kLoc / scale;
   }
 }
 
-int launch_pose_decode(const float* prob, int pcp, int pc0, const float* loc, int lcp, int lc0, int NB, int H, int W,
-                       int J, double scale, double* out, void* stream) {
+int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H,
+                       int W, int J, double scale, double* out, void* stream) {
   if (NB <= 0 || J <= 0) return 0;
-  hipLaunchKernelGGL(pose_decode_kernel, dim3(J, NB), dim3(256), 0, (hipStream_t)stream, prob, pcp, pc0, loc, lcp, lc0,
-                     H, W, J, scale, out);
-  return (int)hipGetLastError();
-}
-
-int launch_nchw_to_nhwc(const float* src, float* dst, int NB, int C, int H, int W, int CP, void* stream) {
-  int HW = H * W;
-  if (NB <= 0 || HW <= 0) return 0;
-  dim3 grid((HW + 31) / 32, (CP + 31) / 32, NB);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, CP);
-  return (int)hipGetLastError();
-}
-
-int launch_nhwc_to_nchw(const float* src, float* dst, int NB, int C, int H, int W, int CP, int c0,
-                        void* stream) {
-  int HW = H * W;
-  if (NB <= 0 || HW <= 0) return 0;
-  dim3 grid((HW + 31) / 32, (C + 31) / 32, NB);
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, CP, c0);
+  if (esize == 2)
+    hipLaunchKernelGGL(pose_decode_kernel<_Float16>, dim3(J, NB), dim3(256), 0, (hipStream_t)stream, (const _Float16*)prob,
+                       pcp, pc0, (const _Float16*)loc, lcp, lc0, H, W, J, scale, out);
+  else
+    hipLaunchKernelGGL(pose_decode_kernel<float>, dim3(J, NB), dim3(256), 0, (hipStream_t)stream, (const float*)prob, pcp,
+                       pc0, (const float*)loc, lcp, lc0, H, W, J, scale, out);
   return (int)hipGetLastError();
 }
 

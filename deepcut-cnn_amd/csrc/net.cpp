@@ -60,7 +60,8 @@ size_t Storage::count() const {
 }
 int Storage::cp() const {
   int c = dim(1);
-  return pad4 ? (c + 3) / 4 * 4 : c;
+  const int v = 16 / esize;  // elements per 16-byte vector
+  return pad4 ? (c + v - 1) / v * v : c;
 }
 size_t Storage::dev_count() const { return (size_t)dim(0) * dim(2) * dim(3) * cp(); }
 void Storage::reshape(const std::vector<int>& s) {
@@ -97,12 +98,13 @@ float* Storage::host_ptr() {
   return host;
 }
 void Storage::ensure_dev(size_t n) {
-  if (n <= dev_cap && dev) return;
+  const size_t bytes = std::max<size_t>(n, 8) * (size_t)esize;
+  if (bytes <= dev_cap && dev) return;
   if (dev) HIPCHECK(hipFree(dev));
   dev = nullptr;
-  HIPCHECK(hipMalloc((void**)&dev, std::max<size_t>(n, 4) * sizeof(float)));
-  HIPCHECK(hipMemset(dev, 0, std::max<size_t>(n, 4) * sizeof(float)));  // pitch-padding channels stay 0
-  dev_cap = n;
+  HIPCHECK(hipMalloc((void**)&dev, bytes));
+  HIPCHECK(hipMemset(dev, 0, bytes));  // pitch-padding channels stay 0
+  dev_cap = bytes;
 }
 void Storage::ensure_stage(size_t n) {
   if (n <= stage_cap && stage) return;
@@ -232,6 +234,11 @@ Net* Net::clone() {
   for (size_t i = 0; i < inputs.size(); ++i) c->blobs[c->inputs[i]]->st->reshape(blobs[inputs[i]]->st->shape);
   c->fuse = fuse;
   c->use_graph = use_graph;
+  if (dtype != c->dtype) {
+    c->dtype = dtype;
+    for (auto& st : c->storages)
+      if (!st->is_param) st->esize = dtype == 1 ? 2 : 4;
+  }
   c->vecs = vecs;
   c->vec_keys_ = vec_keys_;
   c->tune_cache_ = tune_cache_;
@@ -239,6 +246,28 @@ Net* Net::clone() {
   c->device = device;
   c->reshape();
   return c.release();
+}
+
+// Device element type of activations and packed filters (host blobs stay float32 NCHW; accumulation and
+// the epilogue stay float32).  Switching re-creates the device images and re-packs the filters.
+void Net::set_dtype(int d) {
+  if (d != 0 && d != 1) throw DcError(DC_EINVAL, "dtype must be 0 (float32) or 1 (float16)");
+  if (d == dtype) return;
+  dtype = d;
+  for (auto& st : storages) {
+    if (st->is_param) continue;
+    if (st->head == HEAD_AT_GPU) sync_to_host(*st);  // keep what the user can still read
+    if (st->head == SYNCED) st->head = HEAD_AT_CPU;
+    if (st->dev) {
+      (void)hipFree(st->dev);
+      st->dev = nullptr;
+      st->dev_cap = 0;
+    }
+    st->esize = d == 1 ? 2 : 4;
+  }
+  weights_dirty = true;
+  plan_valid = false;
+  release_graph();
 }
 
 void Net::synchronize() {
@@ -600,14 +629,16 @@ double variant_cost(const ConvGemmParams& p, int v) {
   int FM = cv.BM / cv.WR / 32, FN = cv.BN / cv.WC / 32;
   const double wps = cv.WR * cv.WC * cv.WK / 4.0;  // waves per SIMD of one workgroup
   double wgs = (double)conv_grid(p, v);
-  double mfma = (double)FM * FN * (p.Ktot / 2.0) / cv.WK * 64.0;
+  // matrix-pipe cycles per k of one 32x32 fragment: 64/2 (v_mfma_f32_32x32x2_f32) or 32/16 (..._32x32x16_f16)
+  const double cyc_per_k = p.esize == 2 ? 2.0 : 32.0;
+  double mfma = (double)FM * FN * p.Ktot * cyc_per_k / cv.WK;
   double tiles = (double)p.Ktot / bk;
   // the matrix pipe serialises the MFMAs of co-resident waves; a second wave hides most per-tile overhead
   double per_wg = mfma * wps + tiles * (wps > 1 ? 60.0 : 220.0) + 2500.0;
   double rounds = std::ceil(wgs / 256.0);
   // the matrix pipe is shared by co-resident waves, so rounds serialise; partial last round costs a full one
   double t_mfma = rounds * per_wg;
-  double bytes = wgs * (double)p.Ktot * (cv.BM + cv.BN) * 4.0;
+  double bytes = wgs * (double)p.Ktot * (cv.BM + cv.BN) * (double)p.esize;
   double t_l2 = bytes / 4500.0;  // ~11 TB/s aggregate L2->LDS at 2.4 GHz
   return std::max(t_mfma, t_l2);
 }
@@ -857,6 +888,7 @@ void Net::build_plan() {
           auto st = std::make_shared<Storage>();
           st->id = (int)storages.size();
           st->owner = this;
+          st->esize = dtype == 1 ? 2 : 4;
           storages.push_back(st);
           id = st->id;
           aux_index_[key] = id;
@@ -971,6 +1003,9 @@ void Net::build_plan() {
     return s;
   };
   const int force_variant = env_int("DC_CONV_VARIANT", -1);
+  const int es = dtype == 1 ? 2 : 4;          // bytes per activation / filter element
+  const int kmin = dtype == 1 ? 64 : 32;      // smallest K tile of the dtype's variants (one 128-byte line)
+  const std::string dkey = dtype == 1 ? "h:" : "";
 
   auto affine_vecs = [&](const LOp& op, Launch& l, int C) {
     if (op.a.empty()) return;
@@ -988,17 +1023,18 @@ void Net::build_plan() {
     int best = -1;
     double bc = 0;
     for (int v = 0; v < conv_num_variants(); ++v) {
-      if (kgcd % conv_variant_bk(v) != 0) continue;
+      if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es) continue;
       if (force_variant >= 0 && v != force_variant) continue;
       double c = variant_cost(l.cg, v);
       if (best < 0 || c < bc) best = v, bc = c;
     }
     if (best < 0)
       for (int v = 0; v < conv_num_variants(); ++v) {
-        if (kgcd % conv_variant_bk(v) != 0) continue;
+        if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es) continue;
         double c = variant_cost(l.cg, v);
         if (best < 0 || c < bc) best = v, bc = c;
       }
+    if (best < 0) throw DcError(DC_EUNSUP, "launch '" + l.label + "': no tile variant takes K segments of " + std::to_string(kgcd) + " elements");
     l.variant = best;
     l.kernel = std::string("conv_gemm<") + conv_variant(best).name + ">";
     l.grid = conv_grid(l.cg, best);
@@ -1026,6 +1062,7 @@ void Net::build_plan() {
       Launch l = base;
       l.kind = Launch::CONV;
       ConvGemmParams& g = l.cg;
+      g.esize = es;
       g.x_img_stride = (long)H * W * CP;
       g.x_row_stride = W * CP;
       g.x_rows = H;
@@ -1033,14 +1070,14 @@ void Net::build_plan() {
       g.sy = c.sh;
       g.sx = c.sw * CP;
       int kgcd;
-      const bool rowtap = (CP % 32) != 0;
+      const bool rowtap = (CP % kmin) != 0;
       if (rowtap) {
         // small-channel input (the 3->4 channel stem): one tap per kernel ROW, the kw adjacent pixels of
         // that row being contiguous in NHWC; K per tap = kw*CP rounded up to 32 with zero weights
-        if (c.dw != 1 || CP % 4 != 0)
+        if (c.dw != 1 || CP % (16 / es) != 0)
           throw DcError(DC_EUNSUP, "layer '" + L.name + "': convolution over " + std::to_string(C) +
-                                       " channels needs dilation_w 1 (row-tap path) or a multiple of 32 channels");
-        int klen = (c.kw * CP + 31) / 32 * 32;
+                                       " channels needs dilation_w 1 (row-tap path) or a multiple of " + std::to_string(kmin) + " channels");
+        int klen = (c.kw * CP + kmin - 1) / kmin * kmin;
         if (c.kh > kMaxTaps) throw DcError(DC_EUNSUP, "layer '" + L.name + "': kernel too tall");
         g.nty = c.kh;
         g.ntx = 1;
@@ -1051,7 +1088,7 @@ void Net::build_plan() {
         g.klen = klen;
         g.Ktot = c.kh * klen;
         kgcd = klen;
-        l.w = get_vec("w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+        l.w = get_vec(dkey + "w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
           h.assign((size_t)c.num_output * g.Ktot, 0.f);
           const float* w = L.params[0]->st->host_ptr();  // [Cout][Cin][kh][kw]
           for (int co = 0; co < c.num_output; ++co)
@@ -1073,7 +1110,7 @@ void Net::build_plan() {
         g.Ktot = c.kh * c.kw * CP;
         kgcd = CP;
         const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
-        l.w = get_vec("w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()), [&](std::vector<float>& h) {
+        l.w = get_vec(dkey + "w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()), [&](std::vector<float>& h) {
           h.assign((size_t)OC * g.Ktot, 0.f);
           const int taps = c.kh * c.kw;
           int cbase = 0;
@@ -1103,6 +1140,7 @@ void Net::build_plan() {
       affine_vecs(op, l, OC);
       l.flops = 2.0 * g.M * (double)OC * C * c.kh * c.kw;
       plan_flops += l.flops;
+      vecs[l.w]->as_half = dtype == 1;
       choose_variant(l, kgcd);
       plan.push_back(std::move(l));
     } else if (op.kind == LOp::DECONV) {
@@ -1111,7 +1149,8 @@ void Net::build_plan() {
       // row i + (r + p - k*d)/s  (col2im_cpu, im2col.cpp:163-197, inverted: output-stationary).
       const LayerRec& L = layers[op.wl];
       const ConvSpec& c = L.conv;
-      if (CP % 32 != 0) throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution input channels must be a multiple of 32");
+      if (CP % kmin != 0)
+        throw DcError(DC_EUNSUP, "layer '" + L.name + "': deconvolution input channels must be a multiple of " + std::to_string(kmin));
       const int DH = c.sh * (H - 1) + c.dh * (c.kh - 1) + 1 - 2 * c.ph;  // full deconv output
       const int DW = c.sw * (W - 1) + c.dw * (c.kw - 1) + 1 - 2 * c.pw;
       const int oh = op.fused_crop ? op.oh : 0, ow = op.fused_crop ? op.ow : 0;
@@ -1140,6 +1179,7 @@ void Net::build_plan() {
           l.kind = Launch::CONV;
           l.label += " [class " + std::to_string(ry) + "," + std::to_string(rx) + "]";
           ConvGemmParams& g = l.cg;
+          g.esize = es;
           g.x_img_stride = (long)H * W * CP;
           g.x_row_stride = W * CP;
           g.x_rows = H;
@@ -1175,7 +1215,7 @@ void Net::build_plan() {
           g.sigmoid_ch = op.sigmoid_ch >= 0 ? op.sigmoid_ch : (op.sigmoid ? OC : 0);
           affine_vecs(op, l, OC);
           const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
-          l.w = get_vec("w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()) + ":" + std::to_string(ry) +
+          l.w = get_vec(dkey + "w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()) + ":" + std::to_string(ry) +
                             "," + std::to_string(rx),
                         [&](std::vector<float>& h) {
                           h.assign((size_t)OC * g.Ktot, 0.f);
@@ -1196,6 +1236,7 @@ void Net::build_plan() {
                           }
                         });
           l.flops = 2.0 * g.M * (double)OC * C * ntaps;
+          vecs[l.w]->as_half = dtype == 1;
           choose_variant(l, CP);
           plan.push_back(std::move(l));
           any = true;
@@ -1252,8 +1293,18 @@ void Net::upload_vecs() {
   for (auto& vp : vecs) {
     DevVec& v = *vp;
     if (!v.dev && !v.host.empty()) {
-      HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * sizeof(float)));
-      HIPCHECK(hipMemcpy(v.dev, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (v.as_half) {  // filter image of an fp16 net: upload as float, convert on the device, keep the half copy
+        float* tmp = nullptr;
+        HIPCHECK(hipMalloc((void**)&tmp, v.host.size() * sizeof(float)));
+        HIPCHECK(hipMemcpy(tmp, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * 2));
+        KCHECK(launch_f32_to_f16(tmp, v.dev, (long)v.host.size(), stream));
+        HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHECK(hipFree(tmp));
+      } else {
+        HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * sizeof(float)));
+        HIPCHECK(hipMemcpy(v.dev, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
       v.uploaded = v.host.size();
       std::vector<float>().swap(v.host);  // the packed image lives in HBM only
     }
@@ -1288,14 +1339,14 @@ void Net::autotune() {
     if (l.kind != Launch::CONV) continue;
     const ConvGemmParams& g = l.cg;
     char key[160];
-    std::snprintf(key, sizeof key, "%d/%d/%d/%d/%dx%d/%d,%d/%d/%d", g.M, g.Cout, g.Ktot, g.klen, g.nty, g.ntx, g.sy, g.sx,
-                  l.in2 >= 0 ? 1 : 0, g.OW);
+    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
+                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW);
     auto it = tune_cache_.find(key);
     if (it == tune_cache_.end()) {
       int best = l.variant;
       float best_ms = 1e30f;
       for (int v = 0; v < conv_num_variants(); ++v) {
-        if (g.klen % conv_variant_bk(v) != 0) continue;
+        if (g.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != g.esize) continue;
         Launch trial = l;
         trial.variant = v;
         run_launch(trial, stream);  // warm
@@ -1343,8 +1394,9 @@ void Net::sync_to_device(Storage& s) {
   if (s.shape.size() == 4) {
     s.ensure_stage(n);
     HIPCHECK(hipMemcpyAsync(s.stage, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-    KCHECK(launch_nchw_to_nhwc(s.stage, s.dev, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), stream));
+    KCHECK(launch_nchw_to_nhwc(s.stage, s.dev, s.esize, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), stream));
   } else {
+    if (s.esize != 4) throw DcError(DC_EUNSUP, "only 4-D blobs have a half-precision device image");
     HIPCHECK(hipMemcpyAsync(s.dev, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   }
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -1363,13 +1415,14 @@ void Net::sync_to_host(Storage& s) {
   if (s.view_of >= 0) {  // channel slice of a concatenated tensor
     Storage& base = *storages[s.view_of];
     s.ensure_stage(n);
-    KCHECK(launch_nhwc_to_nchw(base.dev, s.stage, s.dim(0), s.dim(1), s.dim(2), s.dim(3), base.cp(), s.view_c0, stream));
+    KCHECK(launch_nhwc_to_nchw(base.dev, s.stage, base.esize, s.dim(0), s.dim(1), s.dim(2), s.dim(3), base.cp(), s.view_c0, stream));
     HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   } else if (s.shape.size() == 4) {
     s.ensure_stage(n);
-    KCHECK(launch_nhwc_to_nchw(s.dev, s.stage, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), 0, stream));
+    KCHECK(launch_nhwc_to_nchw(s.dev, s.stage, s.esize, s.dim(0), s.dim(1), s.dim(2), s.dim(3), s.cp(), 0, stream));
     HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   } else {
+    if (s.esize != 4) throw DcError(DC_EUNSUP, "only 4-D blobs have a half-precision device image");
     HIPCHECK(hipMemcpyAsync(h, s.dev, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   }
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -1384,8 +1437,8 @@ void Net::run_launch(const Launch& l, void* s) {
       ConvGemmParams g = l.cg;
       g.dbg = nullptr;
       g.x = X.dev;
-      g.y = Y.dev + l.y_off;
-      g.resid = l.in2 >= 0 ? storages[l.in2]->dev + l.y_off : nullptr;
+      g.y = Y.dev_at(l.y_off);
+      g.resid = l.in2 >= 0 ? storages[l.in2]->dev_at(l.y_off) : nullptr;
       g.w = vecs[l.w]->dev;
       g.scale = l.scale >= 0 ? vecs[l.scale]->dev : nullptr;
       g.shift = l.shift >= 0 ? vecs[l.shift]->dev : nullptr;
@@ -1441,15 +1494,15 @@ void Net::run_launch(const Launch& l, void* s) {
       break;
     }
     case Launch::POOL:
-      KCHECK(launch_maxpool(X.dev, Y.dev, X.dim(0), X.dim(2), X.dim(3), X.cp(), Y.dim(2), Y.dim(3), l.pk, l.ps, l.pp, s));
+      KCHECK(launch_maxpool(X.dev, Y.dev, X.esize, X.dim(0), X.dim(2), X.dim(3), X.cp(), Y.dim(2), Y.dim(3), l.pk, l.ps, l.pp, s));
       break;
     case Launch::ELT:
       KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale >= 0 ? vecs[l.scale]->dev : nullptr,
-                            l.shift >= 0 ? vecs[l.shift]->dev : nullptr, Y.dev, (long)Y.dev_count(), Y.cp(), l.relu,
+                            l.shift >= 0 ? vecs[l.shift]->dev : nullptr, Y.dev, Y.esize, (long)Y.dev_count(), Y.cp(), l.relu,
                             l.sigmoid, s));
       break;
     case Launch::CROP:
-      KCHECK(launch_crop(X.dev, Y.dev, X.dim(0), X.dim(2), X.dim(3), X.cp(), l.oh, l.ow, Y.dim(2), Y.dim(3), s));
+      KCHECK(launch_crop(X.dev, Y.dev, X.esize, X.dim(0), X.dim(2), X.dim(3), X.cp(), l.oh, l.ow, Y.dim(2), Y.dim(3), s));
       break;
   }
 }
@@ -1469,7 +1522,7 @@ static void prepare_buffers(Net& n, bool& grew) {
   auto prep = [&](int sidx) {
     Storage& s = *n.storages[sidx];
     size_t need = s.dev_count();
-    if (!s.dev || s.dev_cap < need) {
+    if (!s.dev || s.dev_cap < std::max<size_t>(need, 8) * (size_t)s.esize) {
       s.ensure_dev(need);
       grew = true;
     }
@@ -1565,11 +1618,11 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   void* s = user_stream ? user_stream : stream;
   size_t cnt = in.count();
   if (is_device) {
-    KCHECK(launch_nchw_to_nhwc(input, in.dev, n, C, h, w, in.cp(), s));
+    KCHECK(launch_nchw_to_nhwc(input, in.dev, in.esize, n, C, h, w, in.cp(), s));
   } else {
     in.ensure_stage(cnt);
     HIPCHECK(hipMemcpyAsync(in.stage, input, cnt * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
-    KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, n, C, h, w, in.cp(), s));
+    KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, in.esize, n, C, h, w, in.cp(), s));
   }
   in.head = HEAD_AT_GPU;
   const int last = (int)layers.size() - 1;
@@ -1608,14 +1661,15 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
     if (it == blob_index.end()) throw DcError(DC_EINVAL, std::string("net has no blob '") + o.name + "'");
     Storage& st = *blobs[it->second]->st;
     size_t m = st.count();
-    const float* src = st.view_of >= 0 ? storages[st.view_of]->dev : st.dev;
+    const void* src = st.view_of >= 0 ? storages[st.view_of]->dev : st.dev;
+    const int ses = st.view_of >= 0 ? storages[st.view_of]->esize : st.esize;
     const int scp = st.view_of >= 0 ? storages[st.view_of]->cp() : st.cp();
     const int sc0 = st.view_of >= 0 ? st.view_c0 : 0;
     if (is_device) {
-      KCHECK(launch_nhwc_to_nchw(src, o.dst, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
+      KCHECK(launch_nhwc_to_nchw(src, o.dst, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
     } else {
       st.ensure_stage(m);
-      KCHECK(launch_nhwc_to_nchw(src, st.stage, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
+      KCHECK(launch_nhwc_to_nchw(src, st.stage, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
       HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
     }
   }
@@ -1635,7 +1689,7 @@ void Net::decode_pose(double scale, double* out, bool is_device, void* user_stre
   if (L.dim(1) != 2 * P.dim(1) || L.dim(2) != P.dim(2) || L.dim(3) != P.dim(3) || L.dim(0) != P.dim(0))
     throw DcError(DC_ESHAPE, "decode_pose: loc_pred must have 2 channels per joint and the score map's size");
   ensure_device();
-  auto img = [&](Storage& s, const float*& ptr, int& cp, int& c0) {
+  auto img = [&](Storage& s, const void*& ptr, int& cp, int& c0) {
     if (s.view_of >= 0) {
       ptr = storages[s.view_of]->dev;
       cp = storages[s.view_of]->cp();
@@ -1647,15 +1701,16 @@ void Net::decode_pose(double scale, double* out, bool is_device, void* user_stre
       c0 = 0;
     }
   };
-  const float *pp, *lp;
+  const void *pp, *lp;
   int pcp, pc0, lcp, lc0;
+  const int pes = P.view_of >= 0 ? storages[P.view_of]->esize : P.esize;
   img(P, pp, pcp, pc0);
   img(L, lp, lcp, lc0);
   const int NB = P.dim(0), J = P.dim(1), H = P.dim(2), W = P.dim(3);
   void* s = user_stream ? user_stream : stream;
   const size_t cnt = (size_t)NB * 5 * J;
   if (is_device) {
-    KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, NB, H, W, J, scale, out, s));
+    KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, pes, NB, H, W, J, scale, out, s));
     if (!user_stream) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
     return;
   }
@@ -1665,7 +1720,7 @@ void Net::decode_pose(double scale, double* out, bool is_device, void* user_stre
     HIPCHECK(hipMalloc((void**)&pose_dev, cnt * sizeof(double)));
     pose_cap = cnt;
   }
-  KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, NB, H, W, J, scale, pose_dev, s));
+  KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, pes, NB, H, W, J, scale, pose_dev, s));
   HIPCHECK(hipMemcpyAsync(out, pose_dev, cnt * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s));
   HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
@@ -1678,7 +1733,8 @@ std::string Net::plan_text() {
   std::ostringstream os;
   os << "# plan for input";
   for (int d : plan_input_shape) os << " " << d;
-  os << ": " << plan.size() << " launches, " << plan_flops / 1e9 << " GFLOP algorithmic, fuse=" << fuse << "\n";
+  os << ": " << plan.size() << " launches, " << plan_flops / 1e9 << " GFLOP algorithmic, fuse=" << fuse
+     << (dtype == 1 ? ", dtype=f16" : ", dtype=f32") << "\n";
   for (size_t i = 0; i < plan.size(); ++i) {
     const Launch& l = plan[i];
     os << i << "\t" << l.kernel << "\t";

@@ -39,12 +39,13 @@ struct Storage {
   float* host = nullptr;
   size_t host_cap = 0;
   bool host_pinned = false;
-  float* dev = nullptr;  // NHWC image, channel pitch cp()
-  size_t dev_cap = 0;
+  unsigned char* dev = nullptr;  // NHWC image (float or _Float16 elements, `esize` bytes each), channel pitch cp()
+  size_t dev_cap = 0;            // capacity in bytes
+  int esize = 4;                 // bytes per device element (2 in fp16 nets)
   float* stage = nullptr;  // device NCHW staging for up/download
   size_t stage_cap = 0;
   int head = UNINITIALIZED;
-  bool pad4 = false;   // channel pitch rounded up to 4 (tensors read by the gather-GEMM)
+  bool pad4 = false;   // channel pitch rounded up to one 16-byte vector (tensors read by the gather-GEMM)
   bool is_param = false;
   bool elided = false;  // absorbed by fusion in the current plan: never materialised
   int view_of = -1;     // >= 0: this blob is channels [view_c0, view_c0+C) of storage `view_of` (merged heads)
@@ -59,7 +60,8 @@ struct Storage {
   size_t dev_count() const;       // elements of the device image
   void reshape(const std::vector<int>& s);  // Blob::Reshape: capacity only grows (blob.cpp:23-43)
   float* host_ptr();              // allocates + zero-fills on first touch (syncedmem.cpp:25-31)
-  void ensure_dev(size_t n);
+  void ensure_dev(size_t n);  // n elements
+  void* dev_at(long elem) const { return dev + elem * esize; }
   void ensure_stage(size_t n);
 };
 
@@ -91,6 +93,7 @@ struct LayerRec {
 // ---- lowered plan -----------------------------------------------------------------------------------
 struct DevVec {  // a packed filter / affine vector; shared between a Net and its clones
   std::vector<float> host;
+  bool as_half = false;  // filter image of an fp16 net: converted to _Float16 on upload
   float* dev = nullptr;
   size_t uploaded = 0;
   DevVec() = default;
@@ -130,6 +133,7 @@ struct Net {
   std::vector<int> inputs, outputs;  // blob indices
 
   int fuse = 2;
+  int dtype = 0;  // 0: float activations/filters; 1: _Float16 activations/filters, fp32 accumulate + epilogue
   int use_graph = 0;
   bool weights_dirty = true;
   bool plan_valid = false;
@@ -154,6 +158,7 @@ struct Net {
   static Net* create(const std::string& prototxt_text, int phase);
   Net* clone();           // same graph and input shape, SHARED parameters and packed device weights
   void synchronize();     // wait for everything enqueued on the net's own stream
+  void set_dtype(int d);  // 0 float32 / 1 float16 device images (DC_OPT_DTYPE)
   void copy_from(const std::string& path);
   void save(const std::string& path);
   void reshape();         // propagate input shapes through every layer (Net::Reshape)

@@ -216,6 +216,8 @@ class Net(object):
             self.set_option(1, int(kw["fuse"]))
         if "hipgraph" in kw:
             self.set_option(2, int(kw["hipgraph"]))
+        if "dtype" in kw:
+            self.set_option(3, {"f32": 0, "float32": 0, "f16": 1, "float16": 1}[kw["dtype"]])
         self._blobs = None
         self._params = None
 

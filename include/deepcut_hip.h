@@ -49,6 +49,9 @@ extern "C" {
                                1: + residual-add and Deconvolution+Crop+Eltwise head fusion;
                                2 (default): + the sibling heads run as one concatenated GEMM     */
 #define DC_OPT_HIPGRAPH 2   /* 1: replay the per-shape launch sequence as a hipGraph        */
+#define DC_OPT_DTYPE 3      /* 0 (default): float32 activations and filters in HBM, v_mfma_f32_32x32x2_f32;
+                               1: float16 activations and filters, v_mfma_f32_32x32x16_f16 with float32
+                               accumulation and epilogue (BASELINE configs[2]); host blobs stay float32 */
 
 typedef struct dc_net dc_net;
 typedef struct dc_blob dc_blob;

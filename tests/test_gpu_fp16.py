@@ -1,0 +1,108 @@
+"""-m gpu: the float16 path (DC_OPT_DTYPE 1, BASELINE configs[2]: fp16 operands in HBM, v_mfma_f32_32x32x16_f16
+with float32 accumulation and float32 epilogue) against the float32 CPU oracle.
+
+Tolerances (stated, not 1e-3: activations are rounded to 11 significant bits after each of 152 layers):
+  prob      <= 2.5e-3 max-abs          (measured ~9e-4 at 240x320; the sigmoid compresses the error)
+  loc_pred, next_pred <= 4e-3 x max(1, range of the map)   (measured ~1.4e-3 x range)
+Single layers: <= 2e-3 relative to the output range (one rounding of inputs, weights and output)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rand_image
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_maps(out, ref):
+    assert float(np.abs(out["prob"] - ref["prob"]).max()) <= 2.5e-3
+    for k in ("loc_pred", "next_pred"):
+        rng = max(1.0, float(np.abs(ref[k]).max()))
+        err = float(np.abs(out[k] - ref[k]).max())
+        assert err <= 4e-3 * rng, (k, err, rng)
+        assert err > 1e-5, "suspiciously exact: is the fp16 path really running?"
+
+
+@pytest.mark.parametrize("fuse", [0, 2])
+@pytest.mark.parametrize("hw", [(64, 64), (104, 136)])
+def test_fp16_full_net_matches_oracle(gpu_caffe, synth152, hw, fuse):
+    from deepcut_tools import deepercut_prototxt
+
+    path, layers = synth152
+    h, w = hw
+    proto = deepercut_prototxt(152, h, w, 2)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, dtype="f16", fuse=fuse)
+    assert "dtype=f16" in net.plan_text() and "conv_gemm<h" in net.plan_text()
+    img = rand_image(31, h, w, n=2)
+    net.blobs["data"].data[...] = img
+    out = net.forward()
+    O.set_threads(min(16, os.cpu_count() or 1))
+    ref = O.OracleNet(proto, layers).forward(data=img)
+    _check_maps(out, ref)
+    if fuse == 0:  # intermediate blobs too, relative to their range
+        for name in ("conv1", "pool1", "res2c", "res3b7", "res4b35", "res5c"):
+            r = ref[name]
+            assert float(np.abs(net.blobs[name].data - r).max()) <= 1e-2 * max(1.0, float(np.abs(r).max())), name
+
+
+def test_fp16_pyramid_scale_batch8(gpu_caffe, synth152):
+    """BASELINE configs[2]: batch of 8 at the 0.5 scale of 736x544 (272x368), fp16 MFMA with fp32 accumulate."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, layers = synth152
+    h, w = 272, 368
+    proto = deepercut_prototxt(152, h, w, 8)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, dtype="f16")
+    imgs = rand_image(10, h, w, n=8)
+    out = net.forward_batch(imgs)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    ref = O.OracleNet(proto, layers).forward(data=imgs)
+    _check_maps(out, ref)
+    pose = net.decode_pose(0.5)  # the device decode reads the half maps
+    assert pose.shape == (8, 5, 14) and np.isfinite(pose).all()
+
+
+def test_switching_dtype_on_a_live_net(gpu_caffe, synth152):
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
+    img = rand_image(32, 64, 64)
+    net.blobs["data"].data[...] = img
+    a = {k: v.copy() for k, v in net.forward().items()}
+    net.set_option(3, 1)
+    net.blobs["data"].data[...] = img
+    b = {k: v.copy() for k, v in net.forward().items()}
+    net.set_option(3, 0)
+    net.blobs["data"].data[...] = img
+    c = net.forward()
+    for k in a:
+        assert np.array_equal(a[k], c[k]), k              # float32 is reproduced bit for bit
+        d = float(np.abs(a[k] - b[k]).max())
+        assert 1e-6 < d < 2e-2, (k, d)                    # float16 differs, slightly
+
+
+@pytest.mark.parametrize("cfg", [("conv", 7, 2, 3, 1, 3, 64, 41, 54), ("conv", 3, 1, 1, 1, 64, 64, 13, 17),
+                                 ("conv", 1, 2, 0, 1, 256, 128, 14, 18), ("conv", 3, 1, 2, 2, 512, 512, 7, 9),
+                                 ("conv", 1, 1, 0, 1, 2048, 512, 5, 6), ("deconv", 3, 2, 0, 1, 2048, 28, 4, 5)])
+def test_fp16_single_layers(gpu_caffe, cfg):
+    kind, k, s, p, d, cin, cout, h, w = cfg
+    rs = np.random.RandomState(abs(hash(cfg)) % (2 ** 31))
+    typ = "Convolution" if kind == "conv" else "Deconvolution"
+    text = ('input: "x" input_dim: 2 input_dim: %d input_dim: %d input_dim: %d\n' % (cin, h, w) +
+            'layer { name: "l" type: "%s" bottom: "x" top: "y" convolution_param { num_output: %d kernel_size: %d '
+            "stride: %d pad: %d dilation: %d } }" % (typ, cout, k, s, p, d))
+    net = gpu_caffe.Net(text, gpu_caffe.TEST, from_text=True, fuse=0, dtype="f16")
+    x = rs.randn(2, cin, h, w).astype(np.float32)
+    wshape = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+    wt = (rs.randn(*wshape) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    net.params["l"][0].data[...] = wt
+    net.params["l"][1].data[...] = b
+    net.blobs["x"].data[...] = x
+    got = net.forward()["y"]
+    ref = (O.conv_forward if kind == "conv" else O.deconv_forward)(x, wt, b, s, p, d)
+    assert got.shape == ref.shape
+    assert float(np.abs(got - ref).max()) <= 2e-3 * max(1.0, float(np.abs(ref).max()))

@@ -258,3 +258,17 @@ def test_clone_shares_parameters_and_plan():
 
     gc.collect()
     assert c.params["conv1"][0].data[0, 0, 0, 0] == 7.0  # shared blobs outlive the parent
+
+
+def test_fp16_lowering_on_the_host():
+    net = caffe.Net(deepercut_prototxt(152, 240, 320), caffe.TEST, from_text=True, dtype="f16")
+    text = net.plan_text()
+    lines = [l for l in text.splitlines() if not l.startswith("#")]
+    assert "dtype=f16" in text.splitlines()[0] and len(lines) == 161
+    assert all("conv_gemm<h" in l for l in lines if "conv_gemm" in l)
+    assert "K=448 taps=7" in lines[0]  # stem: 7 row taps of 8 pixels x 8 channels (3 padded to one 16-byte vector)
+    assert abs(net.flops() / 1e9 - 46.24) < 0.01
+    net.set_option(3, 0)
+    assert "dtype=f32" in net.plan_text() and "K=224 taps=7" in net.plan_text()
+    with pytest.raises(caffe.DeepcutError):
+        net.set_option(3, 7)
