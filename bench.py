@@ -292,6 +292,19 @@ def main():
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
             },
         }
+        if world == 1:
+            # the boundary as pycaffe uses it: host NCHW buffers in, host maps out (4.8 MB up + 10.2 MB down per
+            # 544x736 image over PCIe, pageable numpy memory) — reported beside `value`, never as `value`
+            xh = x.cpu().numpy()
+            net.forward_batch(xh)
+            t1 = time.perf_counter()
+            n_pcie = max(3, min(20, args.steps))
+            for _ in range(n_pcie):
+                net.forward_batch(xh)
+            dt_pcie = time.perf_counter() - t1
+            res["pcie_inclusive"] = {"value": n_pcie * B / dt_pcie, "unit": "images/s",
+                                     "ms_per_forward": dt_pcie / n_pcie * 1e3,
+                                     "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()
