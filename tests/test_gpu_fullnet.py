@@ -281,3 +281,26 @@ def test_partial_forward_ranges_unfused(gpu_caffe, synth152):
     with pytest.raises(gpu_caffe.DeepcutError) as e:
         net2._forward(0, net2._layer_names.index("bn_conv1"))
     assert "cuts through the fused group" in str(e.value)
+
+
+def test_sharded_runner_on_the_hip_path(gpu_caffe, synth152):
+    """deepcut_tools.ShardedPoseRunner (batching by shape + device decode + best-scale selection) == the
+    reference-style sequential loop of pose.estimate_pose, image by image."""
+    from deepcut_tools import ShardedPoseRunner, deepercut_prototxt
+    from pose import estimate_pose as ep
+
+    path, _ = synth152
+    rs = np.random.RandomState(4)
+    imgs = [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for (h, w) in [(96, 128), (96, 128), (120, 88)]]
+    scales = [0.75, 1.0]
+    net = gpu_caffe.Net(deepercut_prototxt(152, 96, 128), path, gpu_caffe.TEST, from_text=True)
+    res = ShardedPoseRunner(net).run(imgs, scales, want_maps=True)
+    assert len(res["items"]) == 6 and sorted(res["maps"]) == list(range(6))
+    assert res["maps"][0]["next_pred"].shape[0] == 364
+    net2 = gpu_caffe.Net(deepercut_prototxt(152, 96, 128), path, gpu_caffe.TEST, from_text=True)
+    for i, im in enumerate(imgs):
+        ref = ep.estimate_pose(im, None, None, scales, net=net2)
+        got = res["poses"][i]
+        assert (ref is None) == (got is None)
+        if ref is not None:
+            assert np.abs(got - ref).max() <= 1e-2  # batched vs single forward: fp32 summation order only

@@ -1,0 +1,114 @@
+"""CPU: deepcut_tools.ShardedPoseRunner — the multi-scale / multi-crop product path of BASELINE configs 3-5 —
+single process and world_size 2 over gloo, with a deterministic stand-in for the network (the real forward
+needs a GPU; tests/test_gpu_fullnet.py runs the runner on the HIP path)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deepcut_tools import ShardedPoseRunner, net_input_shape, plan_work
+
+
+class FakeNet(object):
+    """Deterministic 'detector': maps are a fixed function of the input batch, pose decode as the reference."""
+
+    def forward_batch(self, images, want=()):
+        n, _, h, w = images.shape
+        hh, ww = h // 8, w // 8
+        base = images.reshape(n, 3, hh, 8, ww, 8).mean(axis=(3, 5))  # [n,3,hh,ww]
+        ch = np.arange(14).reshape(1, 14, 1, 1)
+        self.prob = 1.0 / (1.0 + np.exp(-(base[:, :1] * 0.02 + np.sin(ch + base[:, 1:2] * 0.01))))
+        self.loc = np.tanh(np.repeat(base[:, 2:3], 28, axis=1) * 0.01 + np.arange(28).reshape(1, 28, 1, 1) * 0.1)
+        out = {}
+        if "prob" in want:
+            out = {"prob": self.prob.astype(np.float32), "loc_pred": self.loc.astype(np.float32),
+                   "next_pred": np.zeros((n, 364, hh, ww), np.float32)}
+        return out
+
+    def decode_pose(self, scale):
+        from pose.estimate_pose import pose_from_maps
+
+        return np.stack([pose_from_maps(self.prob[i], self.loc[i], scale) for i in range(self.prob.shape[0])])
+
+
+def _images():
+    rs = np.random.RandomState(3)
+    return [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for (h, w) in [(96, 128), (96, 128), (120, 88), (64, 64), (97, 130)]]
+
+
+def test_plan_is_balanced_and_deterministic():
+    shapes = [(336, 256)] * 32
+    items, shards = plan_work(shapes, [0.5, 0.75, 1.0, 1.25], 8)  # BASELINE configs[4]
+    assert len(items) == 128 and sorted(i for s in shards for i in s) == list(range(128))
+    assert [it[2] for it in items[:4]] == [(168, 128), (256, 192), (336, 256), (424, 320)]
+    loads = [sum(items[k][2][0] * items[k][2][1] for k in s) for s in shards]
+    assert max(loads) / (sum(loads) / 8.0) < 1.02
+    assert net_input_shape((544, 736), 1.25) == (680, 920)
+
+
+def test_single_process_matches_the_sequential_reference_loop():
+    from pose.estimate_pose import pose_from_maps, preprocess, select_best
+
+    imgs = _images()
+    scales = [0.75, 1.0, 1.25]
+    res = ShardedPoseRunner(FakeNet()).run(imgs, scales)
+    net = FakeNet()
+    for i, im in enumerate(imgs):
+        poses = []
+        for s in scales:
+            x = preprocess(im, s).transpose(2, 0, 1)[None]
+            net.forward_batch(x)
+            poses.append(pose_from_maps(net.prob[0], net.loc[0], s))
+        ref = select_best(poses)
+        assert np.allclose(res["poses"][i], ref, atol=1e-9)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "deepcut-cnn_amd", "python"))
+    sys.path.insert(0, here)
+    from test_runner_gloo import FakeNet, _images
+    from deepcut_tools import ShardedPoseRunner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = ShardedPoseRunner(FakeNet()).run(_images(), [0.75, 1.0, 1.25], want_maps=True)
+        if rank == 0:
+            q.put((res["item_poses"], [p is not None for p in res["poses"]], sorted(res["maps"].keys()),
+                   {k: v["prob"].shape for k, v in res["maps"].items()}))
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_equals_single_process():
+    single = ShardedPoseRunner(FakeNet()).run(_images(), [0.75, 1.0, 1.25], want_maps=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    item_poses, have, map_keys, map_shapes = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.allclose(item_poses, single["item_poses"], atol=1e-12)
+    assert map_keys == list(range(15)) and all(have)
+    for k, shp in map_shapes.items():
+        assert shp == single["maps"][k]["prob"].shape
