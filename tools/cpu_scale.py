@@ -1,3 +1,4 @@
+"""Diagnostics: thread scaling of the CPU oracle on this host (prints the cgroup CPU quota it finds)."""
 import sys, os, time
 sys.path.insert(0,'deepcut-cnn_amd/python'); sys.path.insert(0,'.')
 import numpy as np

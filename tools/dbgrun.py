@@ -1,3 +1,5 @@
+"""Diagnostics: run two 544x736 forwards of the synthetic-weight net (used with DC_DEBUG_TIMING=<launch index> to
+print device-side phase timestamps of one launch)."""
 import sys, os
 sys.path.insert(0,'deepcut-cnn_amd/python'); sys.path.insert(0,'.')
 import numpy as np, caffe
