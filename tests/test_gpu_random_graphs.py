@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 class Gen(object):
-    def __init__(self, seed):
+    def __init__(self, seed, chans=(32, 64, 96)):
+        self.chans = chans
         self.rs = np.random.RandomState(seed)
         self.layers = []
         self.shapes = {}
@@ -60,7 +61,7 @@ class Gen(object):
     def build(self):
         rs = self.rs
         n = int(rs.choice([1, 2]))
-        c0 = int(rs.choice([32, 64]))
+        c0 = int(rs.choice(self.chans[:2]))
         h, w = int(rs.randint(9, 22)), int(rs.randint(9, 22))
         self.shapes["x"] = (n, c0, h, w)
         cur = "x"
@@ -74,7 +75,7 @@ class Gen(object):
                 k = int(rs.choice([1, 3]))
                 s = int(rs.choice([1, 1, 2]))
                 d = int(rs.choice([1, 2])) if k == 3 else 1
-                cur = self.chain(self.conv(cur, int(rs.choice([32, 64, 96])), k, s, d, rs.rand() < 0.3))
+                cur = self.chain(self.conv(cur, int(rs.choice(self.chans)), k, s, d, rs.rand() < 0.3))
             elif kind == "res":
                 a = self.chain(self.conv(cur, c, int(rs.choice([1, 3])), 1, 1, False))
                 b = self.conv(a, c, 1, 1, 1, rs.rand() < 0.3)
@@ -94,7 +95,7 @@ class Gen(object):
                 self.shapes[top] = (nn, cc, int(np.ceil((hh - 3) / 2.0)) + 1, int(np.ceil((ww - 3) / 2.0)) + 1)
                 cur = top
             else:  # a side branch that stays a net output: `cur` gets two consumers
-                side = self.conv(cur, 32, 1, 1, 1, True)
+                side = self.conv(cur, self.chans[0], 1, 1, 1, True)
                 if rs.rand() < 0.5:
                     self.unary("Sigmoid", side, rs.rand() < 0.5)
             if hi is None and min(self.shapes[cur][2:]) >= 4 and rs.rand() < 0.5:
@@ -160,3 +161,24 @@ def test_random_graph(gpu_caffe, seed):
             assert got.shape == r.shape, (seed, fuse, name)
             err = float(np.abs(got - r).max()) / max(1.0, float(np.abs(r).max()))
             assert err <= 1e-4, (seed, fuse, name, err, text)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graph_fp16(gpu_caffe, seed):
+    """Same generator with channel counts that are multiples of 64 (one 128-byte line of halves), float16 device
+    images; tolerance 1e-2 of each blob's range (a handful of layers, each rounding its output to 11 bits)."""
+    text = Gen(500 + seed, chans=(64, 128, 192)).build()
+    rs = np.random.RandomState(3000 + seed)
+    ref = None
+    for fuse in (0, 2):
+        net = gpu_caffe.Net(text, gpu_caffe.TEST, from_text=True, fuse=fuse, dtype="f16")
+        weights = _fill(net, np.random.RandomState(4000 + seed))
+        if ref is None:
+            x = rs.randn(*net.blobs["x"].shape).astype(np.float32)
+            ref = O.OracleNet(text, weights).forward(x=x)
+        net.blobs["x"].data[...] = x
+        out = net.forward()
+        for name in (list(ref) if fuse == 0 else list(out)):
+            r = ref[name]
+            err = float(np.abs(net.blobs[name].data - r).max()) / max(1.0, float(np.abs(r).max()))
+            assert err <= 1e-2, (seed, fuse, name, err)
