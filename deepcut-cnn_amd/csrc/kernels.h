@@ -43,7 +43,13 @@ struct ConvGemmParams {
   const float* shift;  // [Cout] or null (=0)
   int relu;
   int sigmoid_ch;  // channels [0, sigmoid_ch) get the logistic
-  int xcd_gx;      // XCD-aware tile map: rectangles along n (0 = linear map); filled by launch_conv_gemm
+  // --- filled by launch_conv_gemm (host-side precomputation keeps integer divisions out of the prologue) ---
+  int xcd_on;              // XCD-aware tile map in use
+  int xcd_rect[8][4];      // per XCD q: {first n tile, n tiles, first m tile, m tiles} of its rectangle
+  unsigned div_ohw[2];     // magic {multiplier, shift} for m / (OH*OW)
+  unsigned div_ow[2];      // ... for m / OW
+  unsigned div_tn[2];      // ... for block / tiles_n (linear map)
+  int tiles_n;
   long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
 };
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -40,6 +41,10 @@ __device__ __forceinline__ f32x4 dc_bload4(__amdgpu_buffer_rsrc_t r, unsigned vo
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 constexpr unsigned kOOB = 0x80000000u;  // > any tensor size: hardware returns 0
+// n / d for 0 <= n < 2^31 with host-computed magic {mul, shift}: 2 VALU instead of the ~25 of a runtime division
+__device__ __forceinline__ int dc_fastdiv(int n, const unsigned (&mg)[2]) {
+  return (mg[1] >> 31) ? n : (int)(__umulhi((unsigned)n, mg[0]) >> (mg[1] & 31));  // bit 31 of the shift word: d == 1
+}
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -112,22 +117,17 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // tile grid is cut into 8 rectangles (gx x gy chosen on the host to minimise filters*gy + pixels*gx)
   // and XCD q walks rectangle q, so an L2 only fetches its rectangle's share of both operands.
   // Correctness does not depend on the placement (it is only a locality hint).
-  const int tiles_n = (p.Cout + BN - 1) / BN;
   int tile_n, tile_m;
-  if (p.xcd_gx > 0) {
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int gx = p.xcd_gx, gy = 8 / gx;                 // rectangles along n / along m
-    const int q = blockIdx.x & 7, slot = blockIdx.x >> 3; // XCD, position inside its rectangle
-    const int qx = q % gx, qy = q / gx;
-    const int n_lo = (tiles_n * qx) / gx, n_hi = (tiles_n * (qx + 1)) / gx;
-    const int m_lo = (tiles_m * qy) / gy, m_hi = (tiles_m * (qy + 1)) / gy;
-    const int rw = n_hi - n_lo, rh = m_hi - m_lo;
+  if (p.xcd_on) {
+    const int q = blockIdx.x & 7, slot = blockIdx.x >> 3;  // XCD, position inside its rectangle
+    const int n_lo = p.xcd_rect[q][0], rw = p.xcd_rect[q][1], m_lo = p.xcd_rect[q][2], rh = p.xcd_rect[q][3];
     if (slot >= rw * rh) return;  // grid is padded to 8 x the largest rectangle
-    tile_n = n_lo + slot % rw;
-    tile_m = m_lo + slot / rw;
+    const int sr = slot / rw;     // uniform (SALU) division
+    tile_n = n_lo + (slot - sr * rw);
+    tile_m = m_lo + sr;
   } else {
-    tile_n = blockIdx.x % tiles_n;
-    tile_m = blockIdx.x / tiles_n;
+    tile_m = dc_fastdiv(blockIdx.x, p.div_tn);
+    tile_n = blockIdx.x - tile_m * p.tiles_n;
   }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
@@ -135,11 +135,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   auto stamp = [&](int slot) {
     if (p.dbg && lane == 0) {
       long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
-      d[slot] = slot < 4 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter();
+      d[slot] = (long long)__builtin_readcyclecounter();
     }
   };
   stamp(0);
-  stamp(4);
 
   // ---- prologue, ordered so that every exposed memory round trip overlaps another -------------------
   // (1) filter rows need no pixel decode: their first PF tiles go out immediately
@@ -174,15 +173,15 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     sh[b] = (cok && p.shift) ? p.shift[co] : 0.f;
   }
 
+  stamp(1);
   // (3) one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
   if (t < BM) {
     const int m = m0 + t;
     i32x4 ri = {(int)kOOB, -(1 << 28), 0, -1};
     if (m < p.M) {
-      const int ohw = p.OH * p.OW;
-      const int n = m / ohw;
-      const int rem = m - n * ohw;
-      const int oy = rem / p.OW;
+      const int n = dc_fastdiv(m, p.div_ohw);
+      const int rem = m - n * (p.OH * p.OW);
+      const int oy = dc_fastdiv(rem, p.div_ow);
       const int ox = rem - oy * p.OW;
       ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES);
       ri.y = oy * p.sy;
@@ -192,6 +191,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     rowinfo[t] = ri;
   }
   __syncthreads();
+  stamp(2);
 
   // (4) activation rows: loop-invariant voffset + validity bit per tap (zero padding = OOB voffset)
   unsigned avoff[NA], amask[NA];
@@ -199,15 +199,11 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   for (int i = 0; i < NA; ++i) {
     const i32x4 ri = rowinfo[lrow + RPP * i];
     avoff[i] = (unsigned)ri.x + lcb;
-    unsigned mk = 0;
-    int bit = 0;
-    for (int ty = 0; ty < p.nty; ++ty) {
-      const bool rok = (unsigned)(ri.y + p.dy0 + ty * p.ddy) < (unsigned)p.x_rows;
-      for (int tx = 0; tx < p.ntx; ++tx, ++bit) {
-        const bool ok = rok && (unsigned)(ri.z + lce + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen;
-        mk |= (ok ? 1u : 0u) << bit;
-      }
-    }
+    unsigned colmask = 0, mk = 0;  // validity of a tap = (row tap valid) x (column tap valid)
+    for (int tx = 0; tx < p.ntx; ++tx)
+      colmask |= ((unsigned)(ri.z + lce + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
+    for (int ty = 0; ty < p.nty; ++ty)
+      if ((unsigned)(ri.y + p.dy0 + ty * p.ddy) < (unsigned)p.x_rows) mk |= colmask << (ty * p.ntx);
     amask[i] = mk;
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
@@ -238,6 +234,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
   for (int k = 0; k < PF; ++k)
     if (k < T_) gload_a(k);
+  stamp(3);
 
   // (5) output addressing of the rows this wave will finalise, and (small tiles) the shortcut itself.
   //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
@@ -313,8 +310,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   }
   __syncthreads();
   frag_load(0, 0, 0);
-  stamp(1);
-  stamp(5);
+  stamp(4);
   for (int it0 = 0; it0 < T_; it0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -350,85 +346,99 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     }
   }
 
-  stamp(2);
-  stamp(6);
+  stamp(5);
   // ---- epilogue ---------------------------------------------------------------------------------------
   // in-workgroup split-K: wave wk keeps registers [wk*RPW, (wk+1)*RPW) of every fragment and receives
   // the other waves' partials for them through LDS, so all waves store (no idle waves, 1/WK of the
-  // LDS traffic of a gather-to-one reduction)
-  if (WK > 1) {
-    __syncthreads();  // tile buffers are free
-    float* part = reinterpret_cast<float*>(smem);
-    // layout: [dst wave q][src wave (wk != q) slot][wr*WC+wc][a][b][e][lane]
+  // LDS traffic of a gather-to-one reduction).  The body is instantiated once per value of wk (wave-uniform
+  // branch) so that every accumulator index is a compile-time constant: no v_cndmask register selects.
+  auto finish = [&](auto wk_tag) {
+    constexpr int MYK = decltype(wk_tag)::value;
+    if (WK > 1) {
+      __syncthreads();  // tile buffers are free
+      float* part = reinterpret_cast<float*>(smem);
+      // layout: [dst wave q][src wave (!= q) slot][wr*WC+wc][a][b][e][lane]
 #pragma unroll
-    for (int q = 0; q < WK; ++q) {
-      if (q == wk) continue;
-      const int srcslot = wk < q ? wk : wk - 1;
-      float* dst = part + ((((q * (WK - 1) + srcslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
+      for (int q = 0; q < WK; ++q) {
+        if (q == MYK) continue;
+        const int srcslot = MYK < q ? MYK : MYK - 1;
+        float* dst = part + ((((q * (WK - 1) + srcslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+        for (int a = 0; a < FM; ++a)
 #pragma unroll
-        for (int b = 0; b < FN; ++b)
+          for (int b = 0; b < FN; ++b)
 #pragma unroll
-          for (int e = 0; e < RPW; ++e) dst[((a * FN + b) * RPW + e) * 64] = acc[a][b][q * RPW + e];
+            for (int e = 0; e < RPW; ++e) dst[((a * FN + b) * RPW + e) * 64] = acc[a][b][q * RPW + e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sslot = 0; sslot < WK - 1; ++sslot) {
+        const float* src = part + ((((MYK * (WK - 1) + sslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int e = 0; e < RPW; ++e) acc[a][b][MYK * RPW + e] += src[((a * FN + b) * RPW + e) * 64];
+      }
     }
-    __syncthreads();
+    stamp(6);
 #pragma unroll
-    for (int sslot = 0; sslot < WK - 1; ++sslot) {
-      const float* src = part + ((((wk * (WK - 1) + sslot) * WR * WC + wr * WC + wc) * FM * FN) * RPW) * 64 + lane;
+    for (int b = 0; b < FN; ++b) {
+      const int co = n0 + wc * TN + b * 32 + (lane & 31);
+      const bool cok = co < p.Cout;
+      const bool sig = co < p.sigmoid_ch;
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+      for (int a = 0; a < FM; ++a) {
+        unsigned off[RPW];
+        float rv[RPW];
 #pragma unroll
-        for (int b = 0; b < FN; ++b)
+        for (int e = 0; e < RPW; ++e) {
+          const int r = MYK * RPW + e;
+          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
+          off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * ES : kOOB;  // masked lanes: load 0 / store dropped
+        }
+        if (EARLY_RESID) {
 #pragma unroll
-          for (int e = 0; e < RPW; ++e) {
-            // wk is wave-uniform but not a compile-time constant: select the register with an unrolled loop
+          for (int e = 0; e < RPW; ++e) rv[e] = p.resid ? rs[(a * FN + b) * RPW + e] : 0.f;
+        } else if (p.resid) {  // all shortcut loads of the fragment in flight at once
 #pragma unroll
-            for (int w2 = 0; w2 < WK; ++w2)
-              if (w2 == wk) acc[a][b][w2 * RPW + e] += src[((a * FN + b) * RPW + e) * 64];
-          }
+          for (int e = 0; e < RPW; ++e) rv[e] = Elem<T>::load(rr, off[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < RPW; ++e) rv[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < RPW; ++e) {
+          float v = acc[a][b][MYK * RPW + e] * sc[b] + sh[b] + rv[e];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (sig) v = 1.f / (1.f + expf(-v));
+          Elem<T>::store(v, yr, off[e]);
+        }
+      }
     }
+  };
+  if constexpr (WK == 1) {
+    finish(std::integral_constant<int, 0>{});
+  } else if constexpr (WK == 2) {
+    if (wk == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+  } else if constexpr (WK == 4) {
+    if (wk == 0) finish(std::integral_constant<int, 0>{});
+    else if (wk == 1) finish(std::integral_constant<int, 1>{});
+    else if (wk == 2) finish(std::integral_constant<int, 2>{});
+    else finish(std::integral_constant<int, 3>{});
+  } else {
+    static_assert(WK == 8, "WK is 1, 2, 4 or 8");
+    if (wk == 0) finish(std::integral_constant<int, 0>{});
+    else if (wk == 1) finish(std::integral_constant<int, 1>{});
+    else if (wk == 2) finish(std::integral_constant<int, 2>{});
+    else if (wk == 3) finish(std::integral_constant<int, 3>{});
+    else if (wk == 4) finish(std::integral_constant<int, 4>{});
+    else if (wk == 5) finish(std::integral_constant<int, 5>{});
+    else if (wk == 6) finish(std::integral_constant<int, 6>{});
+    else finish(std::integral_constant<int, 7>{});
   }
-
-#pragma unroll
-  for (int b = 0; b < FN; ++b) {
-    const int co = n0 + wc * TN + b * 32 + (lane & 31);
-    const bool cok = co < p.Cout;
-    const bool sig = co < p.sigmoid_ch;
-#pragma unroll
-    for (int a = 0; a < FM; ++a) {
-      unsigned off[RPW];
-      float rv[RPW];
-#pragma unroll
-      for (int e = 0; e < RPW; ++e) {
-        const int r = wk * RPW + e;
-        const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
-        off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * ES : kOOB;  // masked lanes: load 0 / store dropped
-      }
-      if (EARLY_RESID) {
-#pragma unroll
-        for (int e = 0; e < RPW; ++e) rv[e] = p.resid ? rs[(a * FN + b) * RPW + e] : 0.f;
-      } else if (p.resid) {  // all shortcut loads of the fragment in flight at once
-#pragma unroll
-        for (int e = 0; e < RPW; ++e) rv[e] = Elem<T>::load(rr, off[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < RPW; ++e) rv[e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < RPW; ++e) {
-        float accv = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < WK; ++w2)
-          if (w2 == wk) accv = acc[a][b][w2 * RPW + e];
-        float v = accv * sc[b] + sh[b] + rv[e];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (sig) v = 1.f / (1.f + expf(-v));
-        Elem<T>::store(v, yr, off[e]);
-      }
-    }
-  }
-  stamp(3);
   stamp(7);
 }
 
@@ -516,11 +526,31 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   p.x_bias = bias;
   long grid = conv_grid(p, variant);
   if (grid <= 0) return 0;
+  // magic numbers for n / d, 0 <= n < 2^31: sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1, n/d = (n*mul) >> sh
+  auto magic = [](unsigned d, unsigned (&mg)[2]) {
+    if (d <= 1) {
+      mg[0] = 0;
+      mg[1] = 0x80000000u;
+      return;
+    }
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    const int sh = 31 + l;
+    const unsigned long long q = (((unsigned __int128)1) << sh) / d;
+    mg[0] = (unsigned)(q + 1);
+    mg[1] = (unsigned)(sh - 32);
+  };
+  const long tn = (p.Cout + e.v.BN - 1) / e.v.BN, tm = (p.M + e.v.BM - 1) / e.v.BM;
+  p.tiles_n = (int)tn;
+  magic((unsigned)tn, p.div_tn);
+  magic((unsigned)(p.OH * p.OW), p.div_ohw);
+  magic((unsigned)p.OW, p.div_ow);
   static const int xcd_map = getenv("DC_XCD_MAP") ? atoi(getenv("DC_XCD_MAP")) : 1;
-  p.xcd_gx = 0;
+  p.xcd_on = 0;
   if (xcd_map && grid >= 16) {
-    const long tn = (p.Cout + e.v.BN - 1) / e.v.BN, tm = (p.M + e.v.BM - 1) / e.v.BM;
-    // bytes an XCD's L2 must fetch for its rectangle: filters of its n-range + pixels (x taps) of its m-range
+    // Blocks are observed to land on XCD (blockIdx % 8), each with its own 4 MB L2.  Cut the tile grid into 8
+    // rectangles (gx along n, 8/gx along m) minimising the bytes an L2 must fetch for its rectangle
+    // (filters of its n-range + pixels of its m-range); XCD q walks rectangle q.  A locality hint only.
     double best = 1e300;
     int best_gx = 0;
     long best_grid = 0;
@@ -538,7 +568,15 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
       if (cost < best) best = cost, best_gx = gx, best_grid = maxrect * 8;
     }
     if (best_gx) {
-      p.xcd_gx = best_gx;
+      const int gx = best_gx, gy = 8 / gx;
+      for (int q = 0; q < 8; ++q) {
+        const int qx = q % gx, qy = q / gx;
+        p.xcd_rect[q][0] = (int)((tn * qx) / gx);
+        p.xcd_rect[q][1] = (int)((tn * (qx + 1)) / gx - (tn * qx) / gx);
+        p.xcd_rect[q][2] = (int)((tm * qy) / gy);
+        p.xcd_rect[q][3] = (int)((tm * (qy + 1)) / gy - (tm * qy) / gy);
+      }
+      p.xcd_on = 1;
       grid = best_grid;
     }
   }

@@ -1461,27 +1461,21 @@ void Net::run_launch(const Launch& l, void* s) {
         std::vector<long long> h(n);
         HIPCHECK(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
         (void)hipFree(d);
-        long long t0 = h[0];
-        for (long i = 0; i < l.grid * nwv; ++i) t0 = std::min(t0, h[i * 8]);
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, c1 = 0, c2 = 0, c3 = 0, last = 0, first_end = 1e30;
+        // slots: 0 start, 1 filter loads + epilogue constants issued, 2 pixel decode + barrier, 3 activation loads
+        // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
+        double dsum[8] = {0};
+        long cnt = 0;
         for (long i = 0; i < l.grid * nwv; ++i) {
           const long long* w = &h[i * 8];
-          s0 += (w[0] - t0) * 10e-3;
-          s1 += (w[1] - t0) * 10e-3;
-          s2 += (w[2] - t0) * 10e-3;
-          s3 += (w[3] - t0) * 10e-3;
-          c1 += (double)(w[5] - w[4]);
-          c2 += (double)(w[6] - w[5]);
-          c3 += (double)(w[7] - w[6]);
-          last = std::max(last, (w[3] - t0) * 10e-3);
-          first_end = std::min(first_end, (w[3] - t0) * 10e-3);
+          if (w[7] == 0) continue;  // workgroup of the padded XCD grid that exited at once
+          for (int k = 1; k < 8; ++k) dsum[k] += (double)(w[k] - w[k - 1]);
+          ++cnt;
         }
-        const double nw = (double)l.grid * nwv;
         std::fprintf(stderr,
-                     "[dc timing] launch %d %s %s\n  mean wave: start %.2f us, loop entry %.2f, loop exit %.2f, end %.2f;"
-                     " first wave ends %.2f, last wave ends %.2f us\n  cycles: prologue %.0f, K loop %.0f, epilogue %.0f\n",
-                     my_idx, l.kernel.c_str(), l.label.c_str(), s0 / nw, s1 / nw, s2 / nw, s3 / nw, first_end, last, c1 / nw,
-                     c2 / nw, c3 / nw);
+                     "[dc timing] launch %d %s %s\n  mean cycles per wave: filter-load issue %.0f | decode+barrier %.0f | "
+                     "activation-load issue %.0f | wait+stage+barrier %.0f | K loop %.0f | split-K exchange %.0f | epilogue math+stores %.0f\n",
+                     my_idx, l.kernel.c_str(), l.label.c_str(), dsum[1] / cnt, dsum[2] / cnt, dsum[3] / cnt, dsum[4] / cnt,
+                     dsum[5] / cnt, dsum[6] / cnt, dsum[7] / cnt);
         g.dbg = nullptr;
       }
       {
