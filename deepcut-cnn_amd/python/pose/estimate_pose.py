@@ -13,10 +13,20 @@ location-refinement components per joint), written against the `caffe` shim of t
   the refinement vector in the reference's (row-offset, column-offset) order;
 * scale selection (:119-126): the scale whose minimum joint confidence is highest (strict >, start 0).
 
-What differs: the reference tiles inputs wider than 700 px "to fit GPU memory" with a port of 1-based
-MATLAB indexing that trims the wrong seams and raises TypeError on current NumPy.  288 GB of
-HBM need no tiling: the whole image is one forward.  `num_tiles()` reproduces the reference's tile-count
-rule for callers that want to know what the reference would have done.
+Tiling (:146-221, 245-259).  The reference cuts inputs wider than 700 px into 700-px tiles overlapping by
+2 x 224 px "to fit GPU memory", with a port of 1-based MATLAB indexing: tile 0 is trimmed on both sides,
+tile 1 only at its end, the last tile is never recognised, rows are trimmed twice, the tile step (252 px)
+is not a whole number of 8-px map cells, and `rf / stride` is a float on Python 3 (TypeError) — SURVEY F7.
+Three behaviours are offered through `tiling=`:
+
+* None (default): no tiling.  288 GB of HBM hold any image; the whole canvas is one forward.
+* "exact": a correct overlap-tile stitcher (`tile_spans`): 688-px tiles (the largest multiple of the
+  network's stride 16 below 700) every 240 px, 28 map cells dropped on each *interior* seam only, so the
+  stitched map has exactly the un-tiled map's shape and, wherever the receptive field fits in the 224-px
+  margin, its values.
+* "reference": the reference's arithmetic as it ran under Python 2 (integer `rf / stride`), bugs
+  included, for callers that must reproduce its output; pinned by tests/golden/tiling_golden.npz, which
+  was produced by the reference's own `_process_image_tiled`.
 """
 import logging as _logging
 
@@ -41,6 +51,78 @@ def num_tiles(length, max_size=700, rf=224):
     while (max_size - rf) * 2 + (max_size - 2 * rf) * k <= length:
         k += 1
     return 2 + k
+
+
+def tile_spans(length, max_size=700, rf=224, stride=STRIDE):
+    """Exact tiling of one side of `length` px (a multiple of `stride`): a list of
+    (start_px, end_px, keep_lo, keep_hi) with keep_* in map cells relative to the tile.  Tiles are
+    tile = max_size rounded down to a multiple of 16 px long (the network's deepest stride, so every
+    tile samples the same pixel grid as the whole image) and start every tile - 2*rf px; rf/stride cells
+    are dropped next to interior seams only, and the kept cell ranges partition [0, length/stride)."""
+    if rf % 16 or length % stride:
+        raise ValueError("rf must be a multiple of 16 and length a multiple of %d" % stride)
+    if length <= max_size:
+        return [(0, length, 0, length // stride)]
+    tile = max_size // 16 * 16
+    step = tile - 2 * rf
+    if step <= 0:
+        raise ValueError("max_size %d leaves no interior between two %d-px margins" % (max_size, rf))
+    cut = rf // stride
+    spans, start = [], 0
+    while True:
+        end = min(start + tile, length)
+        last = end == length
+        cells = (end - start) // stride
+        spans.append((start, end, cut if start else 0, cells if last else cells - cut))
+        if last:
+            return spans
+        start += step
+
+
+def _reference_cut(n_tiles, idx, cut):
+    """The slice `_cutoff_tile` (estimate_pose.py:245-259) applies for tile `idx` of `n_tiles`: the
+    comparisons are 1-based while the caller counts from 0, so tile 0 loses both margins, tile 1 its
+    trailing margin and `idx == n_tiles` never happens."""
+    if n_tiles == 1:
+        return slice(None)
+    if idx == 1:
+        return slice(None, -cut)
+    return slice(cut, -cut)
+
+
+def forward_maps_tiled(net, net_input, max_size=700, rf=224, mode="exact", forward=None):
+    """HxWx3 float32 canvas -> (prob [14,h,w], loc_pred [28,h,w]) from per-tile forwards.
+    mode "exact": see `tile_spans`; mode "reference": the reference's stitching (module docstring).
+    `forward(net, tile)` defaults to `forward_maps`."""
+    forward = forward or forward_maps
+    h, w = net_input.shape[:2]
+    if mode == "exact":
+        rows = []
+        for y0, y1, ky0, ky1 in tile_spans(h, max_size, rf):
+            line = []
+            for x0, x1, kx0, kx1 in tile_spans(w, max_size, rf):
+                prob, loc = forward(net, net_input[y0:y1, x0:x1])
+                line.append((prob[:, ky0:ky1, kx0:kx1], loc[:, ky0:ky1, kx0:kx1]))
+            rows.append((_np.concatenate([t[0] for t in line], axis=2),
+                         _np.concatenate([t[1] for t in line], axis=2)))
+        return (_np.concatenate([r[0] for r in rows], axis=1), _np.concatenate([r[1] for r in rows], axis=1))
+    if mode != "reference":
+        raise ValueError("tiling mode must be 'exact' or 'reference', not %r" % (mode,))
+    cut = rf // STRIDE  # Python 2's `rf / stride`
+    nx, ny = num_tiles(w, max_size, rf), num_tiles(h, max_size, rf)
+    step = max_size - 2 * rf
+    rows = []
+    for j in range(ny):
+        sy = _reference_cut(ny, j, cut)
+        line = []
+        for i in range(nx):
+            sx = _reference_cut(nx, i, cut)
+            prob, loc = forward(net, net_input[j * step:j * step + max_size, i * step:i * step + max_size])
+            line.append((prob[:, :, sx][:, sy], loc[:, :, sx][:, sy]))
+        # the reference trims the assembled line in y a second time (:208-211)
+        rows.append((_np.concatenate([t[0] for t in line], axis=2)[:, sy],
+                     _np.concatenate([t[1] for t in line], axis=2)[:, sy]))
+    return (_np.concatenate([r[0] for r in rows], axis=1), _np.concatenate([r[1] for r in rows], axis=1))
 
 
 def _resize_bilinear_u8(image, scale):
@@ -121,14 +203,18 @@ def forward_maps(net, net_input):
     return net.blobs["prob"].data[0].copy(), net.blobs["loc_pred"].data[0].copy()
 
 
-def estimate_pose(image, model_def, model_bin, scales=None, net=None):
-    """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring)."""
+def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None):
+    """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring).
+    tiling: None (one forward per scale), "exact" or "reference" (see `forward_maps_tiled`)."""
     if scales is None:
         scales = [1.0]
     if net is None:
         net = _get_model(model_def, model_bin)
     poses = []
     for s in scales:
-        prob, loc = forward_maps(net, preprocess(image, s))
+        if tiling is None:
+            prob, loc = forward_maps(net, preprocess(image, s))
+        else:
+            prob, loc = forward_maps_tiled(net, preprocess(image, s), mode=tiling)
         poses.append(pose_from_maps(prob, loc, s))
     return select_best(poses)

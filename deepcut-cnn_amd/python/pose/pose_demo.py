@@ -33,9 +33,11 @@ def draw_disc(image, cx, cy, radius, color):
 @click.option("--folder_image_suffix", type=click.STRING, default=".png")
 @click.option("--use_cpu", type=click.BOOL, is_flag=True, default=False)
 @click.option("--gpu", type=click.INT, default=0)
+@click.option("--tiling", type=click.Choice(["none", "exact", "reference"]), default="none",
+              help="none: one forward per scale (default); exact / reference: see pose.estimate_pose")
 @click.option("--model_def", default=os.path.join(_HERE, "..", "..", "models", "deepercut", "ResNet-152.prototxt"))
 @click.option("--model_bin", default=os.path.join(_HERE, "..", "..", "models", "deepercut", "ResNet-152.caffemodel"))
-def predict_pose_from(image_name, out_name, scales, visualize, folder_image_suffix, use_cpu, gpu, model_def, model_bin):
+def predict_pose_from(image_name, out_name, scales, visualize, folder_image_suffix, use_cpu, gpu, tiling, model_def, model_bin):
     import caffe
     from PIL import Image
 
@@ -60,7 +62,7 @@ def predict_pose_from(image_name, out_name, scales, visualize, folder_image_suff
             LOG.warning("The image is grayscale! This may deteriorate performance!")
             img = np.dstack((img, img, img))
         img = img[:, :, :3][:, :, ::-1]  # RGB -> BGR
-        pose = estimate_pose(img, model_def, model_bin, scales)
+        pose = estimate_pose(img, model_def, model_bin, scales, tiling=None if tiling == "none" else tiling)
         np.savez_compressed(target, pose=pose)
         if visualize and pose is not None:
             vis = img[:, :, ::-1].copy()
