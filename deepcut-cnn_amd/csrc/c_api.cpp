@@ -286,6 +286,26 @@ int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, v
   return guard([&] { N(net)->decode_pose(scale, pose, is_device != 0, stream); });
 }
 
+int dc_net_forward_images(dc_net* net, const unsigned char* images, int n, int height, int width, double scale,
+                          int is_device, float* prob, float* loc_pred, float* next_pred, double* pose, void* stream) {
+  REQUIRE(net);
+  REQUIRE(images);
+  if (n <= 0 || height <= 0 || width <= 0) return fail(DC_EINVAL, "n, height and width must be positive");
+  if (!(scale > 0)) return fail(DC_EINVAL, "scale must be positive");
+  return guard([&] {
+    N(net)->forward_images(images, n, height, width, scale, is_device != 0, prob, loc_pred, next_pred, pose, stream);
+  });
+}
+
+int dc_image_canvas_size(int height, int width, double scale, int* canvas_h, int* canvas_w) {
+  REQUIRE(canvas_h);
+  REQUIRE(canvas_w);
+  if (height <= 0 || width <= 0 || !(scale > 0)) return fail(DC_EINVAL, "height, width and scale must be positive");
+  int nh, nw;
+  dc::image_canvas_size(height, width, scale, *canvas_h, *canvas_w, nh, nw);
+  return DC_OK;
+}
+
 int dc_net_flops(dc_net* net, double* flops) {
   REQUIRE(net);
   REQUIRE(flops);

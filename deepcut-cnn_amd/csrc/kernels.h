@@ -94,6 +94,28 @@ int launch_nhwc_to_nchw(const void* src, float* dst, int esize, int NB, int C, i
 int launch_f32_to_f16(const float* src, void* dst, long n, void* stream);
 
 // pose decode (estimate_pose.py:131-143) from NHWC score / refinement maps (channel pitch + first channel)
+// Image pre-processing of the demo (python/pose/estimate_pose.py:83-103) on the device: replicate padding by
+// coordinate clamping, Pillow's two-pass 8-bit bilinear resample (22-bit fixed-point weights from the host),
+// mean subtraction and the zero canvas, written straight into the network's NHWC input image.
+struct ImagePrepParams {
+  const unsigned char* src;  // [n][h][w][3] BGR uint8
+  int n, h, w;
+  int out_h, out_w;          // canvas = the network input
+  int use_h, use_w;          // top-left part of the resized image that lands on the canvas; the rest is zero
+  const int* x_bounds;       // [new_w][2] first tap, tap count; nullptr: no horizontal pass
+  const int* x_coeffs;       // [new_w][x_ksize]
+  int x_ksize;
+  const int* y_bounds;       // nullptr: no vertical pass
+  const int* y_coeffs;
+  int y_ksize;
+  unsigned char* tmp;        // [n][rows][use_w][4]: rows row0..row0+rows of the horizontally resampled padded image
+  int row0, rows;
+  void* dst;                 // [n][out_h][out_w][dst_cp] float (dst_esize 4) or _Float16 (2); pad channels zeroed
+  int dst_esize, dst_cp;
+  float mean[3];
+};
+int launch_image_prep(const ImagePrepParams& p, void* stream);
+
 int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H,
                        int W, int J, double scale, double* out, void* stream);
 

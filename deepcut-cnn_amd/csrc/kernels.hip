@@ -916,4 +916,91 @@ int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int 
   return (int)hipGetLastError();
 }
 
+// ---- image pre-processing -----------------------------------------------------------------------------------------
+// Integer work at a few bytes per pixel: HBM/latency-bound, one thread per output pixel, no LDS.
+__device__ __forceinline__ int clip8_fixed(int acc) {
+  const int v = acc >> 22;  // PRECISION_BITS = 32 - 8 - 2 (Pillow Resample.c)
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void image_resample_x_kernel(ImagePrepParams p) {
+  const long total = (long)p.n * p.rows * p.use_w;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % p.use_w);
+  const long t = i / p.use_w;
+  const int r = (int)(t % p.rows), n = (int)(t / p.rows);
+  const int sy = min(p.row0 + r, p.h - 1);  // rows >= h replicate the last row (estimate_pose.py:89-92)
+  const unsigned char* row = p.src + ((long)n * p.h + sy) * p.w * 3;
+  const int xmin = p.x_bounds[2 * x], cnt = p.x_bounds[2 * x + 1];
+  const int* kk = p.x_coeffs + (long)x * p.x_ksize;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+  for (int k = 0; k < cnt; ++k) {
+    const int sx = min(xmin + k, p.w - 1);  // columns >= w replicate the last column (:93-95)
+    const int c = kk[k];
+    a0 += row[sx * 3 + 0] * c;
+    a1 += row[sx * 3 + 1] * c;
+    a2 += row[sx * 3 + 2] * c;
+  }
+  reinterpret_cast<uchar4*>(p.tmp)[i] = make_uchar4((unsigned char)clip8_fixed(a0), (unsigned char)clip8_fixed(a1),
+                                                    (unsigned char)clip8_fixed(a2), 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void image_finish_kernel(ImagePrepParams p) {
+  const long total = (long)p.n * p.out_h * p.out_w;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % p.out_w);
+  const long t = i / p.out_w;
+  const int y = (int)(t % p.out_h), n = (int)(t / p.out_h);
+  float v[3] = {0.f, 0.f, 0.f};
+  if (y < p.use_h && x < p.use_w) {
+    auto fetch = [&](int row, int& b0, int& b1, int& b2) {
+      if (p.x_bounds) {
+        const uchar4 q = reinterpret_cast<const uchar4*>(p.tmp)[((long)n * p.rows + (row - p.row0)) * p.use_w + x];
+        b0 = q.x, b1 = q.y, b2 = q.z;
+      } else {
+        const unsigned char* s = p.src + (((long)n * p.h + min(row, p.h - 1)) * p.w + min(x, p.w - 1)) * 3;
+        b0 = s[0], b1 = s[1], b2 = s[2];
+      }
+    };
+    int o0, o1, o2;
+    if (p.y_bounds) {
+      const int ymin = p.y_bounds[2 * y], cnt = p.y_bounds[2 * y + 1];
+      const int* kk = p.y_coeffs + (long)y * p.y_ksize;
+      int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+      for (int k = 0; k < cnt; ++k) {
+        int b0, b1, b2;
+        fetch(ymin + k, b0, b1, b2);
+        const int c = kk[k];
+        a0 += b0 * c, a1 += b1 * c, a2 += b2 * c;
+      }
+      o0 = clip8_fixed(a0), o1 = clip8_fixed(a1), o2 = clip8_fixed(a2);
+    } else {
+      fetch(y, o0, o1, o2);
+    }
+    v[0] = (float)o0 - p.mean[0], v[1] = (float)o1 - p.mean[1], v[2] = (float)o2 - p.mean[2];
+  }
+  T* d = reinterpret_cast<T*>(p.dst) + i * p.dst_cp;
+  for (int c = 0; c < p.dst_cp; ++c) d[c] = (T)(c < 3 ? v[c] : 0.f);
+}
+
+int launch_image_prep(const ImagePrepParams& p, void* stream) {
+  if (p.dst_esize != 2 && p.dst_esize != 4) return (int)hipErrorInvalidValue;
+  if (p.dst_cp < 3 || p.use_h > p.out_h || p.use_w > p.out_w) return (int)hipErrorInvalidValue;
+  if (p.x_bounds) {
+    const long total = (long)p.n * p.rows * p.use_w;
+    if (total > 0)
+      hipLaunchKernelGGL(image_resample_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  }
+  const long total = (long)p.n * p.out_h * p.out_w;
+  if (total <= 0) return 0;
+  if (p.dst_esize == 2)
+    hipLaunchKernelGGL(image_finish_kernel<_Float16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(image_finish_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
 }  // namespace dc

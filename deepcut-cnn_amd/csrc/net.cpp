@@ -208,6 +208,8 @@ Net::~Net() {
   release_graph();
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
   if (pose_dev) (void)hipFree(pose_dev);
+  if (img_dev_) (void)hipFree(img_dev_);
+  if (tmp_dev_) (void)hipFree(tmp_dev_);
 }
 
 Net* Net::create(const std::string& text, int phase) {
@@ -1590,8 +1592,8 @@ void Net::forward(int start, int end) {
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
 }
 
-void Net::forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc, float* next,
-                        void* user_stream) {
+// Common front half of the batched entries: shape the input blob, (re)build the plan, make the device state ready.
+Storage& Net::begin_batch(int n, int h, int w) {
   if (Context::get().mode != DC_MODE_GPU)
     throw DcError(DC_ENOCPU, "forward_batch() in CPU mode: libdeepcut_hip provides the MI355X path only");
   if (inputs.size() != 1) throw DcError(DC_EINVAL, "forward_batch needs a single-input net");
@@ -1607,18 +1609,11 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   prepare_buffers(*this, grew);
   if (grew) release_graph();
   if (!tuned) autotune();
-  const bool own_async = user_stream == (void*)-1;  // DC_STREAM_OWN: the net's stream, no final sync
-  if (own_async) user_stream = nullptr;
-  void* s = user_stream ? user_stream : stream;
-  size_t cnt = in.count();
-  if (is_device) {
-    KCHECK(launch_nchw_to_nhwc(input, in.dev, in.esize, n, C, h, w, in.cp(), s));
-  } else {
-    in.ensure_stage(cnt);
-    HIPCHECK(hipMemcpyAsync(in.stage, input, cnt * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
-    KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, in.esize, n, C, h, w, in.cp(), s));
-  }
-  in.head = HEAD_AT_GPU;
+  return in;
+}
+
+// Enqueue every launch of the plan on stream s (the input image is already in HBM).
+void Net::enqueue_plan(void* s) {
   const int last = (int)layers.size() - 1;
   if (use_graph) {
     // the launch sequence is captured once on the net's own stream and replayed on whichever stream
@@ -1645,6 +1640,10 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   }
   for (auto& l : plan) storages[l.out]->head = HEAD_AT_GPU;
   for (int v : plan_views_) storages[v]->head = HEAD_AT_GPU;
+}
+
+// Copy the three output maps out as NCHW float32 (host or device destination), enqueued on s.
+void Net::emit_maps(float* prob, float* loc, float* next, bool is_device, void* s) {
   struct Out {
     const char* name;
     float* dst;
@@ -1666,6 +1665,169 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
       KCHECK(launch_nhwc_to_nchw(src, st.stage, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
       HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
     }
+  }
+}
+
+void Net::forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc, float* next,
+                        void* user_stream) {
+  Storage& in = begin_batch(n, h, w);
+  const int C = in.dim(1);
+  const bool own_async = user_stream == (void*)-1;  // DC_STREAM_OWN: the net's stream, no final sync
+  if (own_async) user_stream = nullptr;
+  void* s = user_stream ? user_stream : stream;
+  size_t cnt = in.count();
+  if (is_device) {
+    KCHECK(launch_nchw_to_nhwc(input, in.dev, in.esize, n, C, h, w, in.cp(), s));
+  } else {
+    in.ensure_stage(cnt);
+    HIPCHECK(hipMemcpyAsync(in.stage, input, cnt * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
+    KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, in.esize, n, C, h, w, in.cp(), s));
+  }
+  in.head = HEAD_AT_GPU;
+  enqueue_plan(s);
+  emit_maps(prob, loc, next, is_device, s);
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+// ---- image entry: the demo's pre-processing on the device ------------------------------------------------------------
+// python/pose/estimate_pose.py:83-103: replicate the last row/column 64 px, scipy.misc.imresize(.., scale, 'bilinear')
+// (= Pillow's 8-bit two-pass resample to (int(W*s), int(H*s)); identity when the size does not change), subtract the
+// BGR mean, paste on a zero canvas whose sides are rounded up to the stride.  The resample is integer arithmetic with
+// 22-bit fixed-point weights; the weights are computed here on the host in double precision exactly as
+// Pillow's precompute_coeffs / normalize_coeffs_8bpc do, so the device result is bit-identical to the reference's.
+#pragma clang fp contract(off)
+ResampleTable::~ResampleTable() {
+  if (dev_bounds) (void)hipFree(dev_bounds);
+  if (dev_coeffs) (void)hipFree(dev_coeffs);
+}
+
+void resample_coeffs(int in_size, int out_size, int& ksize, std::vector<int>& bounds, std::vector<int>& coeffs) {
+  const int kPrecisionBits = 32 - 8 - 2;
+  double filterscale, scale;
+  filterscale = scale = (double)in_size / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 1.0 * filterscale;  // bilinear: support 1
+  ksize = (int)std::ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  coeffs.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = 0.0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      double v = (x + xmin - center + 0.5) * ss;
+      if (v < 0.0) v = -v;
+      const double w = v < 1.0 ? 1.0 - v : 0.0;
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x) {
+      if (ww != 0.0) k[x] /= ww;
+      coeffs[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << kPrecisionBits)) : (int)(0.5 + k[x] * (1 << kPrecisionBits));
+    }
+    bounds[(size_t)xx * 2] = xmin;
+    bounds[(size_t)xx * 2 + 1] = xmax;
+  }
+}
+
+std::shared_ptr<ResampleTable> Net::resample_table(int in_size, int out_size) {
+  auto key = std::make_pair(in_size, out_size);
+  auto it = resample_.find(key);
+  if (it != resample_.end()) return it->second;
+  auto t = std::make_shared<ResampleTable>();
+  std::vector<int> b, c;
+  resample_coeffs(in_size, out_size, t->ksize, b, c);
+  t->bounds = b;
+  HIPCHECK(hipMalloc((void**)&t->dev_bounds, b.size() * sizeof(int)));
+  HIPCHECK(hipMalloc((void**)&t->dev_coeffs, c.size() * sizeof(int)));
+  HIPCHECK(hipMemcpy(t->dev_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(t->dev_coeffs, c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (resample_.size() > 64) resample_.clear();  // a pyramid uses a handful; bound the cache anyway
+  resample_[key] = t;
+  return t;
+}
+
+void image_canvas_size(int h, int w, double scale, int& out_h, int& out_w, int& new_h, int& new_w) {
+  const int kStride = 8, kPad = 64;
+  out_w = (int)(std::ceil((double)w * scale / kStride) * kStride);  // estimate_pose.py:85-88
+  out_h = (int)(std::ceil((double)h * scale / kStride) * kStride);
+  new_w = (int)((double)(w + kPad) * scale);  // scipy.misc.imresize: (array(im.size) * scale).astype(int)
+  new_h = (int)((double)(h + kPad) * scale);
+}
+
+void Net::forward_images(const unsigned char* bgr, int n, int h, int w, double scale, bool is_device, float* prob, float* loc,
+                         float* next, double* pose, void* user_stream) {
+  if (Context::get().mode != DC_MODE_GPU)
+    throw DcError(DC_ENOCPU, "forward_images() in CPU mode: libdeepcut_hip provides the MI355X path only");
+  if (n <= 0 || h <= 0 || w <= 0 || !(scale > 0)) throw DcError(DC_EINVAL, "forward_images: n, height, width and scale must be positive");
+  int out_h, out_w, new_h, new_w;
+  image_canvas_size(h, w, scale, out_h, out_w, new_h, new_w);
+  if (new_h < 1 || new_w < 1 || out_h < 8 || out_w < 8)
+    throw DcError(DC_ESHAPE, "forward_images: scale " + std::to_string(scale) + " leaves no pixels of a " + std::to_string(h) + "x" +
+                                 std::to_string(w) + " image");
+  Storage& in = begin_batch(n, out_h, out_w);
+  if (in.dim(1) != 3) throw DcError(DC_ESHAPE, "forward_images needs a 3-channel input blob");
+  const bool own_async = user_stream == (void*)-1;
+  if (own_async) user_stream = nullptr;
+  void* s = user_stream ? user_stream : stream;
+  const int kPad = 64;
+  const int ph = h + kPad, pw = w + kPad;              // the replicate-padded image (never materialised)
+  const int use_h = std::min(out_h, new_h), use_w = std::min(out_w, new_w);  // part of the resized image on the canvas
+  const unsigned char* src = bgr;
+  const size_t bytes = (size_t)n * h * w * 3;
+  if (!is_device) {
+    if (bytes > img_cap_) {
+      if (img_dev_) HIPCHECK(hipFree(img_dev_));
+      img_dev_ = nullptr;
+      HIPCHECK(hipMalloc((void**)&img_dev_, bytes));
+      img_cap_ = bytes;
+    }
+    HIPCHECK(hipMemcpyAsync(img_dev_, bgr, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    src = img_dev_;
+  }
+  const bool need_x = new_w != pw, need_y = new_h != ph;
+  ImagePrepParams q{};
+  q.src = src;
+  q.n = n, q.h = h, q.w = w;
+  q.out_h = out_h, q.out_w = out_w, q.use_h = use_h, q.use_w = use_w;
+  q.dst = in.dev, q.dst_esize = in.esize, q.dst_cp = in.cp();
+  q.mean[0] = 104.f, q.mean[1] = 117.f, q.mean[2] = 123.f;  // _MEAN, estimate_pose.py:26
+  std::shared_ptr<ResampleTable> hold_y, hold_x;  // the tables outlive a cache flush until the launches are enqueued
+  if (need_y) {
+    hold_y = resample_table(ph, new_h);
+    const ResampleTable& ty = *hold_y;
+    q.y_bounds = ty.dev_bounds, q.y_coeffs = ty.dev_coeffs, q.y_ksize = ty.ksize;
+    // rows of the (padded, horizontally resampled) image the kept output rows read
+    q.row0 = ty.bounds[0];
+    q.rows = ty.bounds[(size_t)(use_h - 1) * 2] + ty.bounds[(size_t)(use_h - 1) * 2 + 1] - q.row0;
+  } else {
+    q.row0 = 0, q.rows = use_h;
+  }
+  if (need_x) {
+    hold_x = resample_table(pw, new_w);
+    const ResampleTable& tx = *hold_x;
+    q.x_bounds = tx.dev_bounds, q.x_coeffs = tx.dev_coeffs, q.x_ksize = tx.ksize;
+    const size_t tb = (size_t)n * q.rows * use_w * 4;
+    if (tb > tmp_cap_) {
+      if (tmp_dev_) HIPCHECK(hipFree(tmp_dev_));
+      tmp_dev_ = nullptr;
+      HIPCHECK(hipMalloc((void**)&tmp_dev_, tb));
+      tmp_cap_ = tb;
+    }
+    q.tmp = tmp_dev_;
+  }
+  KCHECK(launch_image_prep(q, s));
+  in.head = HEAD_AT_GPU;
+  enqueue_plan(s);
+  emit_maps(prob, loc, next, is_device, s);
+  if (pose) {
+    decode_pose(scale, pose, is_device, (user_stream || own_async) ? s : nullptr);
   }
   if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }

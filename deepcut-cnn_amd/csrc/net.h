@@ -102,6 +102,21 @@ struct DevVec {  // a packed filter / affine vector; shared between a Net and it
   ~DevVec();
 };
 
+struct ResampleTable {  // Pillow-style 8-bit bilinear resample of one axis: taps and 22-bit weights, on the device
+  int ksize = 0;
+  std::vector<int> bounds;  // host copy of [out][2] (first tap, tap count)
+  int* dev_bounds = nullptr;
+  int* dev_coeffs = nullptr;
+  ResampleTable() = default;
+  ResampleTable(const ResampleTable&) = delete;
+  ResampleTable& operator=(const ResampleTable&) = delete;
+  ~ResampleTable();
+};
+// host side of Pillow's precompute_coeffs + normalize_coeffs_8bpc (bilinear, whole-image box)
+void resample_coeffs(int in_size, int out_size, int& ksize, std::vector<int>& bounds, std::vector<int>& coeffs);
+// estimate_pose.py:85-88,96: canvas (stride-8) and resized-image sizes for an h x w image at `scale`
+void image_canvas_size(int h, int w, double scale, int& out_h, int& out_w, int& new_h, int& new_w);
+
 struct Launch {
   enum Kind { CONV, POOL, ELT, CROP } kind = CONV;
   std::string label;    // e.g. "res4b3_branch2b+bn+scale+relu"
@@ -166,6 +181,9 @@ struct Net {
   void forward(int start, int end);
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
                      float* next, void* user_stream);
+  // image entry: pre-processing (estimate_pose.py:83-103) + forward + optional decode, all on the device
+  void forward_images(const unsigned char* bgr, int n, int h, int w, double scale, bool is_device, float* prob, float* loc,
+                      float* next, double* pose, void* user_stream);
   void sync_to_host(Storage& s);       // SyncedMemory::to_cpu
   void sync_to_device(Storage& s);     // SyncedMemory::to_gpu
   void decode_pose(double scale, double* out, bool is_device, void* user_stream);  // after a forward
@@ -183,6 +201,15 @@ struct Net {
   void run_plan(int start, int end, void* s);
   void release_graph();
   void autotune();
+  Storage& begin_batch(int n, int h, int w);
+  void enqueue_plan(void* s);
+  void emit_maps(float* prob, float* loc, float* next, bool is_device, void* s);
+  std::shared_ptr<ResampleTable> resample_table(int in_size, int out_size);
+  std::map<std::pair<int, int>, std::shared_ptr<ResampleTable>> resample_;
+  unsigned char* img_dev_ = nullptr;  // uint8 source images uploaded from the host
+  size_t img_cap_ = 0;
+  unsigned char* tmp_dev_ = nullptr;  // horizontally resampled rows
+  size_t tmp_cap_ = 0;
 };
 
 }  // namespace dc

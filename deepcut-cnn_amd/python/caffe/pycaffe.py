@@ -88,6 +88,8 @@ def _load():
         "dc_blob_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
         "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
         "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
+        "dc_net_forward_images": (ci, [vp, vp, ci, ci, ci, C.c_double, ci, vp, vp, vp, vp, vp]),
+        "dc_image_canvas_size": (ci, [ci, ci, C.c_double, C.POINTER(ci), C.POINTER(ci)]),
         "dc_net_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_net_num_launches": (ci, [vp]),
         "dc_net_plan_text": (cp, [vp]),
@@ -122,6 +124,13 @@ def set_device(device_id):
 
 def device_count():
     return _lib.dc_device_count()
+
+
+def canvas_size(height, width, scale):
+    """(H, W) of the network input the demo builds for an image at `scale` (estimate_pose.py:85-88)."""
+    h, w = C.c_int(), C.c_int()
+    _check(_lib.dc_image_canvas_size(int(height), int(width), float(scale), C.byref(h), C.byref(w)))
+    return h.value, w.value
 
 
 class Blob(object):
@@ -342,6 +351,43 @@ class Net(object):
         out = np.empty((n, 5, j), np.float64)
         _check(_lib.dc_net_decode_pose(self._h, float(scale), out.ctypes.data_as(C.c_void_p), 0, None))
         return out
+
+    def forward_images(self, images, scale=1.0, want=("prob", "loc_pred"), pose=True):
+        """images: uint8 [n,H,W,3] (or [H,W,3]) BGR host array.  The demo's pre-processing (replicate pad, PIL-exact
+        bilinear rescale, mean subtraction, stride-8 canvas; estimate_pose.py:83-103) runs on the device, then the
+        forward and — pose=True — `_pose_from_mats`.  -> dict with the requested NCHW maps and "pose" [n,5,J]."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        if x.ndim == 3:
+            x = x[None]
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("images must be uint8 [n,H,W,3] (BGR)")
+        n, h, w, _ = x.shape
+        ch, cw = canvas_size(h, w, scale)
+        self.blobs["data"].reshape(n, 3, ch, cw)
+        self.reshape()
+        outs, ptrs = {}, {}
+        for k in ("prob", "loc_pred", "next_pred"):
+            if k in want:
+                outs[k] = np.empty(self.blobs[k].shape, np.float32)
+                ptrs[k] = outs[k].ctypes.data_as(C.c_void_p)
+            else:
+                ptrs[k] = None
+        pp = None
+        if pose:
+            outs["pose"] = np.empty((n, 5, self.blobs["prob"].shape[1]), np.float64)
+            pp = outs["pose"].ctypes.data_as(C.c_void_p)
+        _check(_lib.dc_net_forward_images(self._h, x.ctypes.data_as(C.c_void_p), n, h, w, float(scale), 0, ptrs["prob"],
+                                          ptrs["loc_pred"], ptrs["next_pred"], pp, None))
+        return outs
+
+    def forward_images_device(self, img_ptr, n, h, w, scale=1.0, prob_ptr=None, loc_ptr=None, next_ptr=None,
+                              pose_ptr=None, stream=None):
+        """Device-resident form of forward_images: raw device pointers, asynchronous on `stream` ("own" = the net's)."""
+        if stream == "own":
+            stream = C.c_void_p(-1).value
+        _check(_lib.dc_net_forward_images(self._h, C.c_void_p(img_ptr), n, h, w, float(scale), 1, C.c_void_p(prob_ptr or 0),
+                                          C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(pose_ptr or 0),
+                                          C.c_void_p(stream or 0)))
 
     def clone(self):
         """A second executor of the same model (own activations / stream / graph) sharing the parameters and

@@ -7,7 +7,9 @@ Every (image, scale) pair is an independent forward, so the work i
   3. on each rank, items with the same net-input shape are forwarded as ONE batch
      (`Net.forward_batch`), the pose is decoded on the device (`Net.decode_pose`: arg-max + location
      refinement, estimate_pose.py:131-143), optionally the three maps are kept (multi-person consumers
-     need `next_pred`);
+     need `next_pred`).  With the default pre-processing and a net that has `forward_images`, items of the
+     same source size and scale go through the image entry instead: uint8 pixels up, pre-processing
+     (estimate_pose.py:83-103, bit-exact) + forward + decode on the device, 70 doubles per item back;
   4. ONE exchange: poses (70 doubles per item) and, if asked for, the maps are gathered to rank 0
      (`gather_maps`: grouped send/recv, variable sizes);
   5. rank 0 keeps, per image, the scale whose minimum joint confidence is highest (estimate_pose.py:119-126).
@@ -49,11 +51,12 @@ class ShardedPoseRunner(object):
     """`net`: a caffe.Net of this package (or anything with forward_batch(images)->dict and
     decode_pose(scale)->[n,5,J]).  `preprocess(image, scale) -> HxWx3 float32` defaults to pose.estimate_pose's."""
 
-    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None):
+    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True):
         self.net = net
         self.group = group
         self.max_batch = max_batch
         self.device = device
+        self.image_entry = bool(device_preprocess and preprocess is None and hasattr(net, "forward_images"))
         if preprocess is None:
             from pose.estimate_pose import preprocess as _pp
 
@@ -72,10 +75,24 @@ class ShardedPoseRunner(object):
         items, shards = plan_work([im.shape[:2] for im in images], scales, world)
         mine = shards[rank]
         by_shape = {}
+        by_source = {}
         for k in mine:
-            by_shape.setdefault(items[k][2], []).append(k)
+            if self.image_entry:
+                by_source.setdefault((images[items[k][0]].shape[:2], items[k][1]), []).append(k)
+            else:
+                by_shape.setdefault(items[k][2], []).append(k)
         poses = {}
         maps = {}
+        for key in sorted(by_source):
+            ks, s = by_source[key], key[1]
+            for b0 in range(0, len(ks), self.max_batch):
+                chunk = ks[b0:b0 + self.max_batch]
+                out = self.net.forward_images(np.stack([images[items[k][0]] for k in chunk]), s,
+                                              want=("prob", "loc_pred", "next_pred") if want_maps else (), pose=True)
+                for j, k in enumerate(chunk):
+                    poses[k] = out["pose"][j]
+                    if want_maps:
+                        maps[k] = {name: out[name][j].copy() for name in ("prob", "loc_pred", "next_pred")}
         for hw in sorted(by_shape):
             ks = by_shape[hw]
             for b0 in range(0, len(ks), self.max_batch):

@@ -203,15 +203,21 @@ def forward_maps(net, net_input):
     return net.blobs["prob"].data[0].copy(), net.blobs["loc_pred"].data[0].copy()
 
 
-def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None):
+def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None, on_device=True):
     """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring).
-    tiling: None (one forward per scale), "exact" or "reference" (see `forward_maps_tiled`)."""
+    tiling: None (one forward per scale), "exact" or "reference" (see `forward_maps_tiled`).
+    on_device: without tiling, pre-process and decode on the GPU (`Net.forward_images`: the same canvas bit
+    for bit, the same forward, 70 doubles back instead of the maps); False keeps every step where the
+    reference has it (Pillow + NumPy on the host around `net.forward()`)."""
     if scales is None:
         scales = [1.0]
     if net is None:
         net = _get_model(model_def, model_bin)
     poses = []
     for s in scales:
+        if tiling is None and on_device and hasattr(net, "forward_images") and _np.asarray(image).dtype == _np.uint8:
+            poses.append(net.forward_images(_np.asarray(image), s, want=(), pose=True)["pose"][0])
+            continue
         if tiling is None:
             prob, loc = forward_maps(net, preprocess(image, s))
         else:

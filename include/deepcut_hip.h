@@ -156,6 +156,22 @@ int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, i
  * (row, column) order, all divided by `scale`) to a host buffer (is_device=0) or a device buffer.        */
 int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, void* stream);
 
+/* ---- image entry: the demo's pre-processing on the device + forward + optional decode -------------------
+ * python/pose/estimate_pose.py:83-128 for `n` same-size images at one scale, without the float canvas ever
+ * existing on the host: replicate the last row / column 64 px (:89-95), scipy.misc.imresize(img, scale,
+ * 'bilinear') = Pillow's 8-bit two-pass bilinear resample to (int((W+64)*scale), int((H+64)*scale)) (:96;
+ * bit-exact: 22-bit fixed-point weights computed as Pillow does; the identity at scale 1), subtract the BGR
+ * mean [104,117,123] (:97), paste on a zero canvas of ceil(H*scale/8)*8 x ceil(W*scale/8)*8 (:85-88,
+ * :99-103), written straight into the `data` blob's image in HBM; then the forward; then, if `pose` is not
+ * NULL, `_pose_from_mats` (:131-143) as dc_net_decode_pose does.
+ * images  : n * height * width * 3 bytes, BGR, HWC, packed; host (is_device=0) or device memory.
+ * outputs : as dc_net_forward_batch (any may be NULL); pose = n*5*J doubles or NULL, host/device like the rest.
+ * stream  : as dc_net_forward_batch.  The net input is reshaped to the canvas size.                       */
+int dc_net_forward_images(dc_net* net, const unsigned char* images, int n, int height, int width, double scale,
+                          int is_device, float* prob, float* loc_pred, float* next_pred, double* pose, void* stream);
+/* the canvas (= network input) height and width dc_net_forward_images uses for an image at `scale` */
+int dc_image_canvas_size(int height, int width, double scale, int* canvas_h, int* canvas_w);
+
 /* ---- Layer::Forward_gpu surface ---------------------------------------------------------
  * One reference layer stand-alone = a one-layer prototxt given to dc_net_create_from_text with
  * DC_OPT_FUSE 0, weights injected through dc_net_param + dc_blob_mutable_cpu_data: the CDNA4

@@ -85,5 +85,5 @@ def test_exact_tiling_equals_one_forward(gpu_caffe, hw):
     assert prob.shape == whole_prob.shape == (14, h // 8, w // 8) and loc.shape == whole_loc.shape
     assert float(np.abs(whole_loc).max()) > 0.5  # the comparison is not about zeros
     # same arithmetic per cell; only the tile variant (summation order) may differ between shapes
-    assert float(np.abs(prob - whole_prob).max()) <= 1e-5
+    assert float(np.abs(prob - whole_prob).max()) <= 1e-4
     assert float(np.abs(loc - whole_loc).max()) <= 1e-4 * max(1.0, float(np.abs(whole_loc).max()))
