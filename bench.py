@@ -305,6 +305,17 @@ def main():
             res["pcie_inclusive"] = {"value": n_pcie * B / dt_pcie, "unit": "images/s",
                                      "ms_per_forward": dt_pcie / n_pcie * 1e3,
                                      "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
+            # the image entry: uint8 pixels up (1.2 MB), pre-processing + forward + pose decode on the device,
+            # 5x14 doubles down — what the demo needs per image
+            img8 = np.random.RandomState(2).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+            net.forward_images(img8, 1.0, want=(), pose=True)
+            t1 = time.perf_counter()
+            for _ in range(n_pcie):
+                net.forward_images(img8, 1.0, want=(), pose=True)
+            dt_img = time.perf_counter() - t1
+            res["pcie_inclusive_image_entry"] = {"value": n_pcie * B / dt_img, "unit": "images/s",
+                                                 "ms_per_forward": dt_img / n_pcie * 1e3,
+                                                 "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()

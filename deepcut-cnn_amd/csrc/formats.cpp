@@ -334,6 +334,55 @@ LayerBlobs parse_layer(Reader r) {
   return L;
 }
 
+// V1LayerParameter (caffe.proto:1205-1296): bottom 2, top 3, name 4, type 5 (enum), blobs 6, and the V0 wrapper
+// `layer` 1 (V0LayerParameter, caffe.proto:1299-1341: name 1, type 2 (string), blobs 50).
+LayerBlobs parse_v1_layer(Reader r) {
+  LayerBlobs L;
+  while (!r.done()) {
+    uint64_t tag = r.varint();
+    int fn = (int)(tag >> 3), wt = (int)(tag & 7);
+    if (wt == 2 && (fn == 2 || fn == 3 || fn == 4)) {
+      Reader s = r.sub();
+      std::string v((const char*)s.p, (size_t)(s.e - s.p));
+      if (fn == 4) L.name = v;
+      else if (fn == 2) L.bottoms.push_back(v);
+      else L.tops.push_back(v);
+    } else if (fn == 5 && wt == 0) {
+      L.type = v1_layer_type_name((int)r.varint());
+    } else if (fn == 6 && wt == 2) {
+      L.blobs.push_back(parse_blob(r.sub()));
+    } else if (fn == 1 && wt == 2) {  // V0: the connectivity is outside, name / type / blobs inside
+      Reader v0 = r.sub();
+      while (!v0.done()) {
+        uint64_t t0 = v0.varint();
+        int f0 = (int)(t0 >> 3), w0 = (int)(t0 & 7);
+        if (w0 == 2 && (f0 == 1 || f0 == 2)) {
+          Reader s = v0.sub();
+          std::string v((const char*)s.p, (size_t)(s.e - s.p));
+          if (f0 == 1) L.name = v;
+          else {
+            // V0 type strings are lower-case ("conv", "relu", ...; upgrade_proto.cpp:540-600); only the ones this
+            // path can hold weights for are named, the rest keep their V0 spelling
+            static const std::pair<const char*, const char*> kV0[] = {
+                {"conv", "Convolution"}, {"innerproduct", "InnerProduct"}, {"pool", "Pooling"}, {"relu", "ReLU"},
+                {"sigmoid", "Sigmoid"},  {"split", "Split"}};
+            L.type = v;
+            for (auto& e : kV0)
+              if (v == e.first) L.type = e.second;
+          }
+        } else if (f0 == 50 && w0 == 2) {
+          L.blobs.push_back(parse_blob(v0.sub()));
+        } else {
+          v0.skip(w0);
+        }
+      }
+    } else {
+      r.skip(wt);
+    }
+  }
+  return L;
+}
+
 struct Writer {
   std::string out;
   void varint(uint64_t v) {
@@ -356,7 +405,7 @@ ModelFile read_caffemodel(const std::string& path) {
   std::string buf = read_file(path);
   ModelFile m;
   Reader r{(const uint8_t*)buf.data(), (const uint8_t*)buf.data() + buf.size()};
-  bool saw_v1 = false;
+  std::vector<LayerBlobs> v1;
   while (!r.done()) {
     uint64_t tag = r.varint();
     int fn = (int)(tag >> 3), wt = (int)(tag & 7);
@@ -365,16 +414,49 @@ ModelFile read_caffemodel(const std::string& path) {
       m.name.assign((const char*)s.p, (size_t)(s.e - s.p));
     } else if (fn == 100 && wt == 2) {
       m.layers.push_back(parse_layer(r.sub()));
+    } else if (fn == 2 && wt == 2) {  // V1LayerParameter `layers` (caffe.proto:95)
+      v1.push_back(parse_v1_layer(r.sub()));
     } else {
-      if (fn == 2 && wt == 2) saw_v1 = true;  // V1LayerParameter `layers` (caffe.proto:95)
       r.skip(wt);
     }
   }
-  if (m.layers.empty() && saw_v1)
-    throw DcError(DC_EUNSUP, "caffemodel " + path +
-                                 " uses the deprecated V1 'layers' field; upgrade it with the reference's "
-                                 "upgrade_net_proto_binary first");
+  // UpgradeV1Net (upgrade_proto.cpp:647-664): when a file carries V1 `layers`, they are the model and any `layer`
+  // entries beside them are ignored
+  if (!v1.empty()) m.layers = std::move(v1);
   return m;
+}
+
+namespace {
+struct V1Type {
+  int id;
+  const char* ident;
+  const char* name;
+};
+// enum values: caffe.proto:1211-1252; names: upgrade_proto.cpp:852-940
+const V1Type kV1Types[] = {
+    {0, "NONE", ""}, {35, "ABSVAL", "AbsVal"}, {1, "ACCURACY", "Accuracy"}, {30, "ARGMAX", "ArgMax"}, {2, "BNLL", "BNLL"},
+    {3, "CONCAT", "Concat"}, {37, "CONTRASTIVE_LOSS", "ContrastiveLoss"}, {4, "CONVOLUTION", "Convolution"},
+    {5, "DATA", "Data"}, {39, "DECONVOLUTION", "Deconvolution"}, {6, "DROPOUT", "Dropout"},
+    {32, "DUMMY_DATA", "DummyData"}, {7, "EUCLIDEAN_LOSS", "EuclideanLoss"}, {25, "ELTWISE", "Eltwise"},
+    {38, "EXP", "Exp"}, {8, "FLATTEN", "Flatten"}, {9, "HDF5_DATA", "HDF5Data"}, {10, "HDF5_OUTPUT", "HDF5Output"},
+    {28, "HINGE_LOSS", "HingeLoss"}, {11, "IM2COL", "Im2col"}, {12, "IMAGE_DATA", "ImageData"},
+    {13, "INFOGAIN_LOSS", "InfogainLoss"}, {14, "INNER_PRODUCT", "InnerProduct"}, {15, "LRN", "LRN"},
+    {29, "MEMORY_DATA", "MemoryData"}, {16, "MULTINOMIAL_LOGISTIC_LOSS", "MultinomialLogisticLoss"}, {34, "MVN", "MVN"},
+    {17, "POOLING", "Pooling"}, {26, "POWER", "Power"}, {18, "RELU", "ReLU"}, {19, "SIGMOID", "Sigmoid"},
+    {27, "SIGMOID_CROSS_ENTROPY_LOSS", "SigmoidCrossEntropyLoss"}, {36, "SILENCE", "Silence"}, {20, "SOFTMAX", "Softmax"},
+    {21, "SOFTMAX_LOSS", "SoftmaxWithLoss"}, {22, "SPLIT", "Split"}, {33, "SLICE", "Slice"}, {23, "TANH", "TanH"},
+    {24, "WINDOW_DATA", "WindowData"}, {31, "THRESHOLD", "Threshold"}};
+}  // namespace
+
+const char* v1_layer_type_name(int enum_value) {
+  for (auto& t : kV1Types)
+    if (t.id == enum_value) return t.name;
+  return "";
+}
+const char* v1_layer_type_name(const std::string& ident) {
+  for (auto& t : kV1Types)
+    if (ident == t.ident) return t.name;
+  return "";
 }
 
 void write_caffemodel(const std::string& path, const ModelFile& m) {

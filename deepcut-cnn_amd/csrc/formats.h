@@ -63,7 +63,14 @@ struct ModelFile {
   std::string name;
   std::vector<LayerBlobs> layers;
 };
+// Reads the current format (NetParameter.layer, field 100) and, like the reference's UpgradeNetAsNeeded
+// (src/caffe/util/upgrade_proto.cpp:19-78), the deprecated V1 `layers` (field 2, V1LayerParameter) including V0 files
+// whose V1 entries wrap a V0LayerParameter (`layer`, field 1): name / type / bottoms / tops / blobs are carried over,
+// the V1 type enum becomes the current type string.
 ModelFile read_caffemodel(const std::string& path);
+// V1LayerParameter.LayerType (caffe.proto:1211-1252) -> current type string (upgrade_proto.cpp:852-940); "" if unknown
+const char* v1_layer_type_name(int enum_value);
+const char* v1_layer_type_name(const std::string& enum_identifier);  // "CONVOLUTION" -> "Convolution"
 void write_caffemodel(const std::string& path, const ModelFile& m);
 
 std::string read_file(const std::string& path);  // throws DcError(DC_EIO, "Could not open file ...")

@@ -284,8 +284,31 @@ int Net::layer_index(const std::string& nm) const {
 
 void Net::init_from(const TextMsg& root) {
   name = root.str("name");
-  if (!root.subs("layers").empty())
-    throw DcError(DC_EUNSUP, "prototxt uses the deprecated V1 'layers' field; upgrade it (upgrade_net_proto_text)");
+  // Deprecated V1 definitions (`layers { type: CONVOLUTION ... }`) are upgraded in place as the reference does on load
+  // (UpgradeV1Net / UpgradeV1LayerParameter, upgrade_proto.cpp:647-850): the enum becomes the type string, the
+  // train-only blobs_lr / weight_decay fields are dropped, every *_param message keeps its name.  V0 definitions
+  // (a nested `layer { }` inside `layers`) are refused.
+  std::vector<std::shared_ptr<TextMsg>> upgraded;
+  if (!root.subs("layers").empty()) {
+    if (!root.subs("layer").empty())
+      throw DcError(DC_EINVAL, "prototxt mixes 'layer' and deprecated 'layers' entries");
+    for (auto* l : root.subs("layers")) {
+      if (l->sub("layer")) throw DcError(DC_EUNSUP, "V0 net definitions are not supported; upgrade with upgrade_net_proto_text");
+      auto u = std::make_shared<TextMsg>();
+      for (auto& f : l->fields) {
+        if (f.key == "blobs_lr" || f.key == "weight_decay" || f.key == "blob_share_mode") continue;
+        TextField g = f;
+        if (f.key == "type" && !f.msg) {
+          const char* nm = v1_layer_type_name(f.scalar);
+          if (!*nm) throw DcError(DC_EUNSUP, "unknown V1 layer type '" + f.scalar + "'");
+          g.scalar = nm;
+          g.quoted = true;
+        }
+        u->fields.push_back(g);
+      }
+      upgraded.push_back(u);
+    }
+  }
   std::vector<std::string> in_names = root.strs("input");
   std::vector<std::vector<int>> in_shapes;
   {
@@ -306,7 +329,9 @@ void Net::init_from(const TextMsg& root) {
     if (in_shapes.size() != in_names.size()) throw DcError(DC_EINVAL, "one input_shape per input required");
   }
   std::vector<RawLayer> raw;
-  for (auto* l : root.subs("layer")) {
+  std::vector<const TextMsg*> layer_defs = root.subs("layer");
+  for (auto& u : upgraded) layer_defs.push_back(u.get());
+  for (auto* l : layer_defs) {
     if (!phase_included(*l, phase)) continue;
     RawLayer r;
     r.name = l->str("name");

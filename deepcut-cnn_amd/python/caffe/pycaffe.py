@@ -133,6 +133,14 @@ def canvas_size(height, width, scale):
     return h.value, w.value
 
 
+class Layer(object):
+    """caffe.Layer as pycaffe shows it: the type string and the parameter blobs."""
+
+    def __init__(self, type_, blobs):
+        self.type = type_
+        self.blobs = list(blobs)
+
+
 class Blob(object):
     """caffe.Blob (_caffe.cpp:259-277).  `.data` is a writable float32 NCHW view of the blob's host
     memory whose base object keeps the owning Net alive (python/caffe/test/test_net.py:48-60)."""
@@ -253,6 +261,13 @@ class Net(object):
     @property
     def layer_types(self):
         return [_lib.dc_net_layer_type(self._h, i).decode() for i in range(_lib.dc_net_num_layers(self._h))]
+
+    @property
+    def layers(self):
+        """caffe.Net.layers (_caffe.cpp:243-244, Layer :279-284): one object per layer (auto-inserted Split layers
+        included) with `.type` and `.blobs` (the layer's parameter blobs, shared with `net.params`)."""
+        names, types, params = self._layer_names, self.layer_types, self.params
+        return [Layer(t, params.get(n, [])) for n, t in zip(names, types)]
 
     @property
     def params(self):
