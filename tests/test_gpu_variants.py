@@ -1,0 +1,64 @@
+"""-m gpu: every tile variant of the gather-GEMM kernel, forced one at a time (DC_CONV_VARIANT) over the whole
+ResNet-152 graph at 72x104, against the CPU oracle.  Autotuning only ever times the variants; this is where each
+of them has to be right (4- and 8-wave workgroups, in-workgroup split-K 1/2/4/8, fp32 and fp16 operands)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rand_image
+
+pytestmark = pytest.mark.gpu
+H, W = 72, 104
+NUM_VARIANTS = 27  # csrc/kernels.hip kVariants; the last test fails if the table grows without this number
+
+
+@pytest.fixture(scope="module")
+def reference(synth152):
+    from deepcut_tools import deepercut_prototxt
+    from oracle import oracle as O
+
+    path, layers = synth152
+    O.set_threads(min(16, os.cpu_count() or 1))
+    img = rand_image(9, H, W)
+    return img, O.OracleNet(deepercut_prototxt(152, H, W), layers).forward(data=img)
+
+
+def _run(gpu_caffe, synth152, v, dtype, img, monkeypatch):
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    monkeypatch.setenv("DC_CONV_VARIANT", str(v))
+    net = gpu_caffe.Net(deepercut_prototxt(152, H, W), path, gpu_caffe.TEST, from_text=True, dtype=dtype)
+    net.blobs["data"].data[...] = img
+    net.forward()
+    used = set(ln.split("\t")[1] for ln in net.plan_text().splitlines() if "conv_gemm<" in ln)
+    return net, used
+
+
+@pytest.mark.parametrize("v", range(NUM_VARIANTS))
+def test_forced_variant_matches_oracle(gpu_caffe, synth152, reference, monkeypatch, v):
+    img, ref = reference
+    net, used = _run(gpu_caffe, synth152, v, "f32", img, monkeypatch)
+    names = sorted(used)
+    if any(n.startswith("conv_gemm<h") for n in names) or len(names) > 4:
+        # a float16 variant index (ignored by a float32 net: every layer falls back to the cost model's choice)
+        net, used = _run(gpu_caffe, synth152, v, "f16", img, monkeypatch)
+        assert all(n.startswith("conv_gemm<h") for n in used)
+        assert len(used) <= 4, "variant %d was not forced: %s" % (v, sorted(used))
+        assert float(np.abs(net.blobs["prob"].data - ref["prob"]).max()) <= 2.5e-3
+        for k in ("loc_pred", "next_pred"):
+            assert float(np.abs(net.blobs[k].data - ref[k]).max()) <= 4e-3 * max(1.0, float(np.abs(ref[k]).max()))
+        return
+    # layers whose K segments the forced variant cannot take fall back, so a few names may appear; the forced one leads
+    for k in ("prob", "loc_pred", "next_pred"):
+        assert float(np.abs(net.blobs[k].data - ref[k]).max()) <= 1e-3, (k, names)
+
+
+def test_variant_table_size_is_what_this_file_covers(gpu_caffe, synth152, reference, monkeypatch):
+    img, _ = reference
+    _, base = _run(gpu_caffe, synth152, -1, "f32", img, monkeypatch)
+    _, beyond = _run(gpu_caffe, synth152, NUM_VARIANTS, "f32", img, monkeypatch)  # out of range: nothing is forced
+    assert beyond == base
+    _, last = _run(gpu_caffe, synth152, NUM_VARIANTS - 1, "f32", img, monkeypatch)
+    assert last != base  # the last covered index does force a variant
