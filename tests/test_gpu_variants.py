@@ -57,8 +57,10 @@ def test_forced_variant_matches_oracle(gpu_caffe, synth152, reference, monkeypat
 
 def test_variant_table_size_is_what_this_file_covers(gpu_caffe, synth152, reference, monkeypatch):
     img, _ = reference
+    monkeypatch.setenv("DC_AUTOTUNE", "0")  # cost-model choice: what a forced index falls back to where it cannot apply
     _, base = _run(gpu_caffe, synth152, -1, "f32", img, monkeypatch)
     _, beyond = _run(gpu_caffe, synth152, NUM_VARIANTS, "f32", img, monkeypatch)  # out of range: nothing is forced
     assert beyond == base
-    _, last = _run(gpu_caffe, synth152, NUM_VARIANTS - 1, "f32", img, monkeypatch)
-    assert last != base  # the last covered index does force a variant
+    _, base16 = _run(gpu_caffe, synth152, -1, "f16", img, monkeypatch)
+    _, last = _run(gpu_caffe, synth152, NUM_VARIANTS - 1, "f16", img, monkeypatch)  # the table ends with the float16 tiles
+    assert last != base16  # the last covered index does force a variant
