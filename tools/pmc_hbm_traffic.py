@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""HBM traffic per conv_gemm launch from two rocprofv3 --pmc passes (rocpd sqlite), as MI355X_MICROARCH.md's HBM
+section prescribes: FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, both in KB, FETCH_SIZE x2 on gfx950 for
+wide (16 B/lane) coalesced reads, WRITE_SIZE taken as is.
+   python tools/pmc_hbm_traffic.py fetch.db write.db "<description>" > profiles/<name>.json"""
+import json
+import sqlite3
+import sys
+
+
+def per_launch(path, counter):
+    c = sqlite3.connect(path)
+    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%conv_gemm%'",
+                     (counter,)).fetchone()
+    return v / n, n
+
+
+def main(fetch_db, write_db, desc):
+    f, nf = per_launch(fetch_db, "FETCH_SIZE")
+    w, nw = per_launch(write_db, "WRITE_SIZE")
+    print(json.dumps({
+        "source": desc,
+        "conv_gemm_dispatches": nf,
+        "fetch_kb_per_launch_raw": f,
+        "write_kb_per_launch_raw": w,
+        "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced "
+                      "(16 B/lane) streaming reads -> x2; WRITE_SIZE uncalibrated, taken as is; both counters are KB",
+        "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+        "algorithmic_min_bytes_per_launch": (2.07e9 + 0.263e9) / 160.0,
+    }, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")

@@ -1,13 +1,55 @@
 #!/usr/bin/env python
 """Per-kernel MFMA utilisation table from a rocprofv3 --pmc pass (rocpd sqlite):
-   python tools/pmc_mfma_util.py <results.db> "<description line>" > profiles/<name>.txt
+   python tools/pmc_mfma_util.py <results.db> "<description line>" [plan.txt] > profiles/<name>.txt
+With a plan file (bench.py --breakdown output, or Net.plan_text()) a second table groups the launches by network
+stage (conv1 / res2 / res3 / res4 / res5 / heads): dispatches are matched to plan lines by their order in a forward.
 Counters needed: SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE."""
 import collections
 import sqlite3
 import sys
 
 
-def main(path, desc):
+def stage_of(label):
+    for key, name in (("res2", "res2 (conv2_x)"), ("res3d", "heads"), ("res3", "res3 (conv3_x)"), ("res4", "res4 (conv4_x)"),
+                      ("res5c_up", "heads"), ("res5", "res5 (conv5_x)"), ("conv1", "conv1")):
+        if label.startswith(key):
+            return name
+    return "heads"
+
+
+def per_stage(c, plan_path):
+    labels = []
+    for ln in open(plan_path):
+        f = ln.rstrip("\n").split("\t")
+        if len(f) == 4 and f[0].isdigit() and "conv_gemm<" in f[1]:
+            labels.append(f[3])
+    n = len(labels)
+    rows = c.execute("select dispatch_id, counter_name, value, duration from counters_collection where kernel_name like '%conv_gemm%' "
+                     "and counter_name in ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES') order by dispatch_id").fetchall()
+    ids = sorted(set(r[0] for r in rows))
+    if n == 0 or len(ids) % n:
+        print("# per-stage table skipped: %d conv_gemm dispatches is not a multiple of the plan's %d" % (len(ids), n))
+        return
+    pos = {d: i % n for i, d in enumerate(ids)}
+    agg = collections.OrderedDict()
+    for d, cn, v, dur in rows:
+        a = agg.setdefault(stage_of(labels[pos[d]]), {"GRBM_GUI_ACTIVE": 0.0, "SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "n": 0, "ns": 0.0})
+        a[cn] += v
+        if cn == "GRBM_GUI_ACTIVE":
+            a["n"] += 1
+            a["ns"] += dur
+    print("# by network stage (%d forwards of %d conv_gemm launches):" % (len(ids) // n, n))
+    print("%-18s %9s %12s %9s %12s" % ("stage", "launches", "busy share", "MfmaUtil", "MfmaUtil(t)"))
+    tot = sum(a["GRBM_GUI_ACTIVE"] for a in agg.values())
+    for st in ("conv1", "res2 (conv2_x)", "res3 (conv3_x)", "res4 (conv4_x)", "res5 (conv5_x)", "heads"):
+        if st in agg:
+            a = agg[st]
+            print("%-18s %9d %11.1f%% %8.1f%% %11.1f%%" % (st, a["n"] * n // len(ids), 100 * a["GRBM_GUI_ACTIVE"] / tot,
+                                                          100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024),
+                                                          100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * 2.4 * 1024)))
+
+
+def main(path, desc, plan_path=None):
     c = sqlite3.connect(path)
     rows = c.execute("select kernel_name, grid_size, workgroup_size, counter_name, sum(value), count(*), sum(duration) "
                      "from counters_collection group by kernel_name, grid_size, workgroup_size, counter_name").fetchall()
@@ -18,7 +60,9 @@ def main(path, desc):
     print("# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs): share of ALL matrix pipes busy while the")
     print("#            kernel runs (64 busy cycles per v_mfma_f32_32x32x2_f32, summed over SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs).")
     print("# Profiled passes serialise dispatches and clock lower: durations are longer than in the --kernel-trace --stats summaries.")
-    print("%-36s %6s %5s %9s %9s %9s %9s" % ("kernel<BM,BN,BK,WR,WC,WK,PF>", "WGs", "n", "us/launch", "MfmaUtil", "WAIT_ANY", "WAIT_INST"))
+    print("# MfmaUtil(t) = the same busy cycles / (dispatch duration x 2.4 GHz x 1024 SIMDs): GRBM_GUI_ACTIVE of a counter-collecting dispatch")
+    print("#            also covers its set-up and drain (~20 % more cycles than the timestamps), which the timestamps do not.")
+    print("%-36s %6s %5s %9s %9s %11s %9s %9s" % ("kernel<BM,BN,BK,WR,WC,WK,PF>", "WGs", "n", "us/launch", "MfmaUtil", "MfmaUtil(t)", "WAIT_ANY", "WAIT_INST"))
     tm = tg = 0.0
     for (k, g, wg), d in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0,))[0]):
         if "conv_gemm" not in k:
@@ -29,10 +73,14 @@ def main(path, desc):
         wc = d["SQ_WAVE_CYCLES"][0]
         tm += mf
         tg += gui
-        print("%-36s %6d %5d %9.1f %8.1f%% %8.1f%% %8.1f%%" % (k[k.index("<"):k.index(">") + 1], g // wg, n, d["GRBM_GUI_ACTIVE"][2] / n / 1e3,
-                                                            100 * mf / (gui * 1024), 100 * d["SQ_WAIT_ANY"][0] / wc, 100 * d["SQ_WAIT_INST_ANY"][0] / wc))
+        dur_cycles = d["GRBM_GUI_ACTIVE"][2] * 2.4  # ns x 2.4 cycles/ns
+        print("%-36s %6d %5d %9.1f %8.1f%% %10.1f%% %8.1f%% %8.1f%%" % (k[k.index("<"):k.index(">") + 1], g // wg, n, d["GRBM_GUI_ACTIVE"][2] / n / 1e3,
+                                                                     100 * mf / (gui * 1024), 100 * mf / (dur_cycles * 1024),
+                                                                     100 * d["SQ_WAIT_ANY"][0] / wc, 100 * d["SQ_WAIT_INST_ANY"][0] / wc))
     print("# all conv_gemm dispatches (conv1..conv5 + heads): MfmaUtil = %.1f%% of the 1024 matrix pipes over the kernels' own run time" % (100 * tm / (tg * 1024)))
+    if plan_path:
+        per_stage(c, plan_path)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", sys.argv[3] if len(sys.argv) > 3 else None)
