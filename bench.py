@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--breakdown", default="", help="write the per-launch hipEvent table to this file")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "3")),
                     help="independent batch-B forwards kept in flight per GPU (each on its own HIP stream and Net)")
+    ap.add_argument("--backend", default=os.environ.get("DC_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend for N>1: nccl (= RCCL, the real thing) or gloo (lets two ranks share one "
+                         "GPU to smoke-test the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -143,11 +146,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())  # smoke test: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import __graft_entry__ as ge
 
