@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libdeepcut_hip.so")
-SOURCES = ["formats.cpp", "net.cpp", "c_api.cpp", "kernels.hip"]
+SOURCES = ["formats.cpp", "hdf5_reader.cpp", "net.cpp", "c_api.cpp", "kernels.hip"]
 HEADERS = ["formats.h", "net.h", "kernels.h", os.path.join("..", "..", "include", "deepcut_hip.h")]
 
 

@@ -72,6 +72,10 @@ ModelFile read_caffemodel(const std::string& path);
 const char* v1_layer_type_name(int enum_value);
 const char* v1_layer_type_name(const std::string& enum_identifier);  // "CONVOLUTION" -> "Convolution"
 void write_caffemodel(const std::string& path, const ModelFile& m);
+// HDF5 weights (Net::ToHDF5 / CopyTrainedLayersFromHDF5, net.cpp:861-975): /data/<layer>/<param index> float datasets.
+// Decoded from the HDF5 file format directly (hdf5_reader.cpp); no HDF5 library involved.
+bool is_hdf5_path(const std::string& path);  // the reference's rule: the name ends in ".h5" (net.cpp:843-850)
+ModelFile read_hdf5_weights(const std::string& path);
 
 std::string read_file(const std::string& path);  // throws DcError(DC_EIO, "Could not open file ...")
 

@@ -577,11 +577,14 @@ void Net::reshape() {
 
 // ---- weights --------------------------------------------------------------------------------------
 void Net::copy_from(const std::string& path) {
-  ModelFile m = read_caffemodel(path);
+  const bool h5 = is_hdf5_path(path);  // Net::CopyTrainedLayersFrom(string): ".h5" -> HDF5, else binaryproto (net.cpp:843-858)
+  ModelFile m = h5 ? read_hdf5_weights(path) : read_caffemodel(path);
   for (auto& src : m.layers) {  // Net::CopyTrainedLayersFrom (net.cpp:805-840)
     int li = layer_index(src.name);
     if (li < 0) continue;  // "Ignoring source layer"
     LayerRec& L = layers[li];
+    // binaryproto: the counts must agree (net.cpp:822-823); HDF5: the source may hold fewer only for shared
+    // parameters (net.cpp:883-898), which this forward path does not have, so the same rule applies
     if (L.params.size() != src.blobs.size())
       throw DcError(DC_ESHAPE, "Incompatible number of blobs for layer " + src.name + ": net has " +
                                    std::to_string(L.params.size()) + ", file has " + std::to_string(src.blobs.size()));

@@ -85,7 +85,10 @@ int dc_net_clone(dc_net* net, dc_net** out);
 int dc_net_synchronize(dc_net* net);
 int dc_net_set_option(dc_net* net, int key, int value);
 /* Net::CopyTrainedLayersFrom(file) (net.cpp:805-858): match by layer name, check blob
- * count and shape, ignore unmatched source layers.                                       */
+ * count and shape, ignore unmatched source layers.  Formats: binary NetParameter in the current
+ * `layer` form or the deprecated V1 / V0 `layers` form (upgraded as upgrade_proto.cpp:19-78 does),
+ * and — for names ending in ".h5", the reference's rule (net.cpp:843-850) — HDF5 weights
+ * /data/<layer>/<param index> (CopyTrainedLayersFromHDF5, net.cpp:861-909).                     */
 int dc_net_copy_from(dc_net* net, const char* caffemodel_path);
 /* Net::ToProto + WriteProtoToBinaryFile (net.cpp:910-925; _caffe.cpp:98-102)             */
 int dc_net_save(dc_net* net, const char* caffemodel_path);
