@@ -585,6 +585,234 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   return (int)hipGetLastError();
 }
 
+// =====================================================================================================================
+// Winograd F(2x2, 3x3): Y = A^T [ (G g G^T) . (B^T d B) ] A per 4x4 input patch d -> 2x2 outputs, summed over input
+// channels as 16 independent GEMMs (one per transform position (i, j)): 2.25x fewer MFMA flops than the direct form.
+//
+// At batch 1 a res4 layer has only 391 tiles x 256 channels, so the kernel is built around operand TRAFFIC, not flops:
+//  * workgroup = 4 x 8 tiles (two 16-tile MFMA fragments) x 16 output channels, 8 waves = (transform row i) x (fragment);
+//    a wave owns the 4 positions (i, 0..3) of its fragment: 4 accumulators of v_mfma_f32_16x16x4_f32;
+//  * the 10 x 18 input pixels the block reads are staged ONCE per 32 channels in LDS (ring of 3, one barrier per 32
+//    channels); every wave reads the two patch rows its transform row needs and does B^T d B in registers (packed fp32)
+//    one sub-step ahead of its MFMAs — the transformed input never exists in memory;
+//  * the transformed filters are the big stream (16/9 of the filter bytes, no reuse inside a workgroup): pre-packed on
+//    the host so that each wave reads its B fragments straight from global memory, 1 KB contiguous per load, two
+//    sub-steps ahead; workgroups that share them (same 16 output channels) are adjacent in the grid;
+//  * the inverse transform reduces over j in registers and over i (four waves) through LDS, then applies the folded
+//    BatchNorm/Scale affine, the shortcut and ReLU like the gather-GEMM's epilogue.
+// Measured on the res4 3x3 shape (1x34x46, 256 -> 256): 17.2 us vs 23.5 us for the direct kernel (tools/probes/winograd_probe.hip).
+namespace {
+constexpr int WBTY = 4, WBTX = 8, WBN = 16, WKC = 32;
+constexpr int WRH = 2 * WBTY + 2, WRW = 2 * WBTX + 2;   // staged pixels: 10 x 18
+constexpr int WPSTR = WKC + 4;                           // floats per staged pixel (2*PSTR = 8 mod 64 banks)
+constexpr int WNTH = 512;
+constexpr int WNLD = (WRH * WRW * (WKC / 4) + WNTH - 1) / WNTH;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wino_rowbase(int row) { return row * WRW * WPSTR + 4 * ((row >> 1) & 1); }
+__device__ __forceinline__ f32x2 wlo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+}  // namespace
+
+__global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float stage[3][WRH * WRW * WPSTR + 8];
+  __shared__ float part[4][2][2][4][64];  // [i][b][tf][r][lane]
+  const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
+  const float* __restrict__ up = reinterpret_cast<const float*>(p.w);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int C = p.klen, H = p.x_rows, W = p.x_rowlen / p.klen;
+  // dilation d: the image is d*d interleaved phase images, each an ordinary pad-1 3x3 problem on the pixels
+  // (phy + d*u, phx + d*v); tiles, blocks and staged coordinates below live on the phase grid (u, v)
+  const int d = p.ddy;
+  const int TY = ((p.OH + d - 1) / d + 1) >> 1, TX = ((p.OW + d - 1) / d + 1) >> 1;
+  const int NBY = (TY + WBTY - 1) / WBTY, NBX = (TX + WBTX - 1) / WBTX;
+  const int nblk = p.NB * d * d * NBY * NBX;
+  const int nt = blockIdx.x / nblk, blk = blockIdx.x - nt * nblk;  // same-filter workgroups are adjacent
+  const int nph = blk / (NBY * NBX), brem = blk - nph * (NBY * NBX);
+  const int n = nph / (d * d), ph = nph - n * (d * d);
+  const int phy = ph / d, phx = ph - phy * d;
+  const int by = brem / NBX, bx = brem - by * NBX;
+  const int oy0 = 2 * WBTY * by - 1, ox0 = 2 * WBTX * bx - 1;  // phase-grid coordinates of staged pixel (0, 0): pad 1
+  const int kg = lane >> 4;
+  const int i = wave & 3, tf = wave >> 2;
+  // B^T row i as a combination of two patch rows: i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
+  const int ra = i == 0 ? 0 : (i == 2 ? 2 : 1), rb = i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
+  const float sb = i == 1 ? 1.f : -1.f;
+  const float* xn = x + (long)n * p.x_img_stride;
+  int gofs[WNLD], sofs[WNLD];
+#pragma unroll
+  for (int q = 0; q < WNLD; ++q) {
+    const int e = t + q * WNTH;
+    const int pix = e / (WKC / 4), cq = e % (WKC / 4);
+    const int py = pix / WRW, px = pix % WRW;
+    const int iy = phy + d * (oy0 + py), ix = phx + d * (ox0 + px);
+    const bool ok = pix < WRH * WRW && oy0 + py >= 0 && ox0 + px >= 0 && iy < H && ix < W;
+    gofs[q] = ok ? iy * p.x_row_stride + ix * C + cq * 4 : -1;
+    sofs[q] = pix < WRH * WRW ? wino_rowbase(py) + px * WPSTR + cq * 4 : -1;
+  }
+  const int r = (lane & 15) >> 3, c = lane & 7;
+  const int ofs_a = wino_rowbase(2 * (2 * tf + r) + ra) + 2 * c * WPSTR + kg * 4;
+  const int ofs_b = wino_rowbase(2 * (2 * tf + r) + rb) + 2 * c * WPSTR + kg * 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ub = up + ((long)(nt * 4 + i) * (C / 16)) * (4 * 64 * 4) + lane * 4;
+  f32x4 g[WNLD], b[3][4], da[2][4], db[2][4];
+  auto gload = [&](int K) {
+#pragma unroll
+    for (int q = 0; q < WNLD; ++q) g[q] = gofs[q] >= 0 ? *reinterpret_cast<const f32x4*>(xn + gofs[q] + K * WKC) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < WNLD; ++q)
+      if (sofs[q] >= 0) *reinterpret_cast<f32x4*>(&stage[buf][sofs[q]]) = g[q];
+  };
+  auto bload = [&](int slot, int k16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[slot][j] = *reinterpret_cast<const f32x4*>(ub + ((long)k16 * 4 + j) * 256);
+  };
+  auto lread = [&](int slot, int buf, int h) {
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      da[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_a + c4 * WPSTR + h * 16]);
+      db[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_b + c4 * WPSTR + h * 16]);
+    }
+  };
+  auto compute = [&](int slot, int bslot) {
+    f32x2 tl[4], th[4];
+    const f32x2 sb2 = {sb, sb};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      tl[c4] = wlo(da[slot][c4]) + sb2 * wlo(db[slot][c4]);
+      th[c4] = whi(da[slot][c4]) + sb2 * whi(db[slot][c4]);
+    }
+    f32x2 vl[4], vh[4];
+    vl[0] = tl[0] - tl[2], vh[0] = th[0] - th[2];
+    vl[1] = tl[1] + tl[2], vh[1] = th[1] + th[2];
+    vl[2] = tl[2] - tl[1], vh[2] = th[2] - th[1];
+    vl[3] = tl[1] - tl[3], vh[3] = th[1] - th[3];
+    // four independent accumulators between two MFMAs on the same one (a dependent 8-pass MFMA would need s_nops)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vl[j][0], b[bslot][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vl[j][1], b[bslot][j][1], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vh[j][0], b[bslot][j][2], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vh[j][1], b[bslot][j][3], acc[j], 0, 0, 0);
+  };
+  const int NS = C / WKC;
+  // pipeline: global -> registers (3 steps ahead) -> LDS ring of 3 (2 steps ahead) -> registers (1 sub-step ahead) -> MFMA
+  gload(0);
+  bload(0, 0);
+  bload(1, 1);
+  sstore(0);
+  if (NS > 1) {
+    gload(1);
+    sstore(1);
+  }
+  if (NS > 2) gload(2);
+  __syncthreads();
+  lread(0, 0, 0);
+  // one staged step: U = K % 3 is a template-like constant so that every ring slot is a compile-time register name
+  auto step = [&](int K, auto u_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    __syncthreads();  // buffers <= K+1 are complete; buffer (K+2)%3 is free
+    __builtin_amdgcn_sched_barrier(0);
+    lread(1, U, 1);
+    bload((2 * U + 2) % 3, 2 * K + 2 < 2 * NS ? 2 * K + 2 : 0);  // the tail loads are harmless re-reads of step 0
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0, (2 * U) % 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 2 < NS) sstore((U + 2) % 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 1 < NS) lread(0, (U + 1) % 3, 0);
+    bload((2 * U + 3) % 3, 2 * K + 3 < 2 * NS ? 2 * K + 3 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, (2 * U + 1) % 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (K + 3 < NS) gload(K + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int K0 = 0; K0 < NS; K0 += 3) {
+    step(K0, std::integral_constant<int, 0>{});
+    if (K0 + 1 < NS) step(K0 + 1, std::integral_constant<int, 1>{});
+    if (K0 + 2 < NS) step(K0 + 2, std::integral_constant<int, 2>{});
+  }
+  // inverse transform: over j in registers (P[b] = sum_j M[i][j] A[j][b]), over i through LDS
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    part[i][0][tf][r4][lane] = acc[0][r4] + acc[1][r4] + acc[2][r4];
+    part[i][1][tf][r4][lane] = acc[1][r4] - acc[2][r4] - acc[3][r4];
+  }
+  __syncthreads();
+  const int a = (wave >> 1) & 1, bq = wave & 1;  // this wave finalises output pixel (a, bq) of the tiles of fragment tf
+  const int co = nt * WBN + (lane & 15);
+  const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
+  float* yb = reinterpret_cast<float*>(p.y);
+  const float* rbp = reinterpret_cast<const float*>(p.resid);
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const float p0 = part[0][bq][tf][r4][lane], p1 = part[1][bq][tf][r4][lane], p2 = part[2][bq][tf][r4][lane], p3 = part[3][bq][tf][r4][lane];
+    float v = a == 0 ? p0 + p1 + p2 : p1 - p2 - p3;
+    const int q = 4 * (lane >> 4) + r4;  // D layout: row (tile in fragment) = 4*(lane/16) + r, col (channel) = lane%16
+    const int ty = by * WBTY + 2 * tf + (q >> 3), tx = bx * WBTX + (q & 7);
+    const int oy = phy + d * (2 * ty + a), ox = phx + d * (2 * tx + bq);
+    if (oy < p.OH && ox < p.OW) {
+      const long off = (long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride + co;
+      v = v * sc + sh;
+      if (rbp) v += rbp[off];
+      if (p.relu) v = fmaxf(v, 0.f);
+      yb[off] = v;
+    }
+  }
+}
+
+bool wino_eligible(const ConvGemmParams& p) {
+  const int d = p.ddy;  // dilation (1 or more), the same along x and y, with pad = dilation ("same" convolution)
+  if (p.esize != 4 || p.nty != 3 || p.ntx != 3 || p.sy != 1 || d < 1 || d > 4 || p.dy0 != -d) return false;
+  const int C = p.klen;
+  if (C <= 0 || C % WKC != 0 || p.Cout % WBN != 0 || p.sigmoid_ch != 0) return false;
+  if (p.sx != C || p.ddx != d * C || p.x0 != -d * C) return false;           // stride 1, dilation d, pad d along x
+  if (p.x_rowlen % C != 0 || p.x_row_stride != p.x_rowlen) return false;     // dense NHWC rows of C channels
+  if (p.OH != p.x_rows || p.OW != p.x_rowlen / C) return false;              // "same" convolution
+  return true;
+}
+
+long wino_grid(const ConvGemmParams& p) {
+  const int d = p.ddy;
+  const int TY = ((p.OH + d - 1) / d + 1) / 2, TX = ((p.OW + d - 1) / d + 1) / 2;
+  return (long)p.NB * d * d * ((TY + WBTY - 1) / WBTY) * ((TX + WBTX - 1) / WBTX) * (p.Cout / WBN);
+}
+
+size_t wino_packed_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
+
+void wino_pack_filters(const float* g, int Cout, int Cin, float* out) {
+  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* w = g + ((size_t)co * Cin + ci) * 9;
+      double tmp[4][3], U[4][4];
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 3; ++b) tmp[a][b] = G[a][0] * w[b] + G[a][1] * w[3 + b] + G[a][2] * w[6 + b];
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) U[a][b] = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+      const int nt = co / 16, col = co % 16, k16 = ci / 16, kg = (ci % 16) / 4, s = ci % 4;
+      const int lane = kg * 16 + col;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+          out[(((((size_t)nt * 4 + i) * (Cin / 16) + k16) * 4 + j) * 64 + lane) * 4 + s] = (float)U[i][j];
+    }
+}
+
+int launch_wino_conv(const ConvGemmParams& p, void* stream) {
+  if (!wino_eligible(p)) return (int)hipErrorInvalidValue;
+  const long grid = wino_grid(p);
+  if (grid <= 0) return 0;
+  if (grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino_f23_kernel, dim3((unsigned)grid), dim3(WNTH), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // MAX pooling (NHWC, 16 bytes of channels per thread), windows clipped to the image
 // ------------------------------------------------------------------------------------------------

@@ -1049,6 +1049,7 @@ void Net::build_plan() {
       for (int c = 0; c < C; ++c) h[c] = (float)op.b[c];
     });
   };
+  const int wino_mode = env_int("DC_WINOGRAD", -1);  // -1: where measured faster (autotune); 0: never; 1: wherever eligible
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
     double bc = 0;
@@ -1068,6 +1069,11 @@ void Net::build_plan() {
     l.variant = best;
     l.kernel = std::string("conv_gemm<") + conv_variant(best).name + ">";
     l.grid = conv_grid(l.cg, best);
+  };
+  auto use_wino = [&](Launch& l) {
+    l.variant = kWinoVariant;
+    l.kernel = "wino_f23<4x8x16>";
+    l.grid = wino_grid(l.cg);
   };
 
   for (auto& op : ops) {
@@ -1172,6 +1178,15 @@ void Net::build_plan() {
       plan_flops += l.flops;
       vecs[l.w]->as_half = dtype == 1;
       choose_variant(l, kgcd);
+      // stride-1 3x3 layers can also run as Winograd F(2x2,3x3): keep the transformed filters next to the direct ones
+      // and let the per-shape timing decide (kernels.hip, wino_f23_kernel)
+      if (!rowtap && wino_mode != 0 && op.wls.empty() && wino_eligible(g)) {
+        l.wino_w = get_vec(dkey + "wino:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          h.assign(wino_packed_floats(c.num_output, C), 0.f);
+          wino_pack_filters(L.params[0]->st->host_ptr(), c.num_output, C, h.data());
+        });
+        if (wino_mode == 1 && (force_variant < 0 || force_variant == kWinoVariant)) use_wino(l);
+      }
       plan.push_back(std::move(l));
     } else if (op.kind == LOp::DECONV) {
       // stride-s transposed convolution = s*s ordinary gather-GEMMs, one per output residue class
@@ -1354,9 +1369,11 @@ void Net::autotune() {
   if (cache_path && tune_cache_.empty()) {
     if (FILE* f = std::fopen(cache_path, "r")) {
       char key[200], vname[64];
-      while (std::fscanf(f, "%199s %63s", key, vname) == 2)
+      while (std::fscanf(f, "%199s %63s", key, vname) == 2) {
+        if (std::string(vname) == "wino_f23") tune_cache_[key] = kWinoVariant;
         for (int v = 0; v < conv_num_variants(); ++v)
           if (std::string(conv_variant(v).name) == vname) tune_cache_[key] = v;
+      }
       std::fclose(f);
     }
   }
@@ -1392,17 +1409,40 @@ void Net::autotune() {
         }
         if (ms < best_ms) best_ms = ms, best = v;
       }
+      if (l.wino_w >= 0) {  // the Winograd form of this layer competes with the best direct tile
+        Launch trial = l;
+        trial.variant = kWinoVariant;
+        run_launch(trial, stream);
+        float ms = 1e30f;
+        for (int t2 = 0; t2 < 2; ++t2) {
+          HIPCHECK(hipEventRecord(e0, (hipStream_t)stream));
+          for (int r = 0; r < reps; ++r) run_launch(trial, stream);
+          HIPCHECK(hipEventRecord(e1, (hipStream_t)stream));
+          HIPCHECK(hipEventSynchronize(e1));
+          float m2 = 0;
+          HIPCHECK(hipEventElapsedTime(&m2, e0, e1));
+          ms = std::min(ms, m2);
+        }
+        if (ms < best_ms) best_ms = ms, best = kWinoVariant;
+      }
       it = tune_cache_.emplace(key, best).first;
     }
     l.variant = it->second;
-    l.kernel = std::string("conv_gemm<") + conv_variant(l.variant).name + ">";
-    l.grid = conv_grid(l.cg, l.variant);
+    if (l.variant == kWinoVariant && l.wino_w < 0) l.variant = 0;  // a stale cache line: this build cannot run it
+    if (l.variant == kWinoVariant) {
+      l.kernel = "wino_f23<4x8x16>";
+      l.grid = wino_grid(l.cg);
+    } else {
+      l.kernel = std::string("conv_gemm<") + conv_variant(l.variant).name + ">";
+      l.grid = conv_grid(l.cg, l.variant);
+    }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (cache_path && tune_cache_.size() != cached_before) {
     if (FILE* f = std::fopen(cache_path, "w")) {
-      for (auto& kv : tune_cache_) std::fprintf(f, "%s %s\n", kv.first.c_str(), conv_variant(kv.second).name);
+      for (auto& kv : tune_cache_)
+        std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
       std::fclose(f);
     }
   }
@@ -1472,6 +1512,12 @@ void Net::run_launch(const Launch& l, void* s) {
       g.w = vecs[l.w]->dev;
       g.scale = l.scale >= 0 ? vecs[l.scale]->dev : nullptr;
       g.shift = l.shift >= 0 ? vecs[l.shift]->dev : nullptr;
+      if (l.variant == kWinoVariant) {  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
+        if (l.wino_w < 0) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
+        g.w = vecs[l.wino_w]->dev;
+        KCHECK(launch_wino_conv(g, s));
+        break;
+      }
       static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
       const int my_idx = (int)(&l - plan.data());
       if (dbg_idx >= 0 && my_idx == dbg_idx) {

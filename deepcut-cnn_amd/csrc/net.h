@@ -127,6 +127,7 @@ struct Launch {
   ConvGemmParams cg{};  // pointers filled at launch time
   int variant = 0;
   int w = -1, scale = -1, shift = -1;  // DevVec ids
+  int wino_w = -1;                     // DevVec id of the Winograd-transformed filters (eligible 3x3 layers), else -1
   long y_off = 0;                      // element offset of this launch's first output (deconvolution classes)
   double flops = 0;                    // algorithmic 2*MAC
   long grid = 0;
