@@ -615,7 +615,10 @@ __device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v
 
 __global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) {
   __shared__ __attribute__((aligned(16))) float stage[3][WRH * WRW * WPSTR + 8];
-  __shared__ float part[4][2][2][4][64];  // [i][b][tf][r][lane]
+  // [i][b][tf][r][lane] partial inverse transforms: reuses the staging ring once the K loop is over (78 KB per
+  // workgroup instead of 94: two workgroups fit the 160 KB of a CU)
+  float (*part)[2][2][4][64] = reinterpret_cast<float (*)[2][2][4][64]>(&stage[0][0]);
+  static_assert(sizeof(float) * 4 * 2 * 2 * 4 * 64 <= sizeof(stage), "partials must fit in the staging ring");
   const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
   const float* __restrict__ up = reinterpret_cast<const float*>(p.w);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) 
     if (K0 + 2 < NS) step(K0 + 2, std::integral_constant<int, 2>{});
   }
   // inverse transform: over j in registers (P[b] = sum_j M[i][j] A[j][b]), over i through LDS
+  __syncthreads();  // every wave is done reading the staging ring, which the partials now overwrite
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
     part[i][0][tf][r4][lane] = acc[0][r4] + acc[1][r4] + acc[2][r4];

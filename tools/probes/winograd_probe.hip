@@ -10,6 +10,7 @@
 // i (the four waves) through LDS once at the end.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -214,8 +215,13 @@ int main() {
     std::vector<long long> hd((size_t)grid * 8 * 4);
     CK(hipMemcpy(hd.data(), dd, hd.size() * 8, hipMemcpyDeviceToHost));
     double p[3] = {0, 0, 0};
-    for (int w = 0; w < grid * 8; ++w)
+    std::vector<double> tot;
+    for (int w = 0; w < grid * 8; ++w) {
       for (int k = 0; k < 3; ++k) p[k] += (double)(hd[w * 4 + k + 1] - hd[w * 4 + k]);
+      tot.push_back((double)(hd[w * 4 + 3] - hd[w * 4]));
+    }
+    std::sort(tot.begin(), tot.end());
+    printf("per-wave total cycles: min %.0f  median %.0f  p90 %.0f  max %.0f\n", tot[0], tot[tot.size() / 2], tot[tot.size() * 9 / 10], tot.back());
     printf("mean cycles per wave: prologue %.0f | K loop %.0f (%.0f per 16-channel sub-step) | inverse transform + stores %.0f\n", p[0] / (grid * 8), p[1] / (grid * 8), p[1] / (grid * 8) / (C / 16), p[2] / (grid * 8));
   }
   CK(hipMemcpy(hy.data(), dy, hy.size() * 4, hipMemcpyDeviceToHost));
