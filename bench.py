@@ -245,7 +245,7 @@ def main():
     if rank == 0:
         total_images = args.steps * B * world
         launches = net.num_launches()
-        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln)
+        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln)
         # roofline of the dominant kernel family (conv_gemm: every convolution/deconvolution launch):
         # algorithmic FLOPs per launch / average launch duration over the ONE-FORWARD-AT-A-TIME timed
         # region (launches do not overlap there, so the duration is the kernel's own and agrees with
@@ -285,7 +285,7 @@ def main():
                                       "tflops": total_images * flops_img / lat_dt / 1e12},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_gemm (%s gather-GEMM, all tile variants)" % (
+                "kernel": "conv_gemm + wino_f23 (%s gather-GEMM, all tile variants; Winograd F(2x2,3x3) where it is faster)" % (
                     "f16 v_mfma_f32_32x32x16_f16, fp32 accumulate" if args.dtype == "f16" else "fp32 v_mfma_f32_32x32x2_f32"),
                 "achieved": achieved,
                 "peak": PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS,

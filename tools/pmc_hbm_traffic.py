@@ -10,7 +10,7 @@ import sys
 
 def per_launch(path, counter):
     c = sqlite3.connect(path)
-    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and kernel_name like '%conv_gemm%'",
+    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and (kernel_name like '%conv_gemm%' or kernel_name like '%wino_f23%')",
                      (counter,)).fetchone()
     return v / n, n
 

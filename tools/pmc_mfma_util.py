@@ -21,10 +21,10 @@ def per_stage(c, plan_path):
     labels = []
     for ln in open(plan_path):
         f = ln.rstrip("\n").split("\t")
-        if len(f) == 4 and f[0].isdigit() and "conv_gemm<" in f[1]:
+        if len(f) == 4 and f[0].isdigit() and ("conv_gemm<" in f[1] or "wino_f23<" in f[1]):
             labels.append(f[3])
     n = len(labels)
-    rows = c.execute("select dispatch_id, counter_name, value, duration from counters_collection where kernel_name like '%conv_gemm%' "
+    rows = c.execute("select dispatch_id, counter_name, value, duration from counters_collection where (kernel_name like '%conv_gemm%' or kernel_name like '%wino_f23%') "
                      "and counter_name in ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES') order by dispatch_id").fetchall()
     ids = sorted(set(r[0] for r in rows))
     if n == 0 or len(ids) % n:
@@ -65,7 +65,7 @@ def main(path, desc, plan_path=None):
     print("%-36s %6s %5s %9s %9s %11s %9s %9s" % ("kernel<BM,BN,BK,WR,WC,WK,PF>", "WGs", "n", "us/launch", "MfmaUtil", "MfmaUtil(t)", "WAIT_ANY", "WAIT_INST"))
     tm = tg = 0.0
     for (k, g, wg), d in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0,))[0]):
-        if "conv_gemm" not in k:
+        if "conv_gemm" not in k and "wino_f23" not in k:
             continue
         n = d["GRBM_GUI_ACTIVE"][1]
         gui = d["GRBM_GUI_ACTIVE"][0] / 8.0
@@ -74,10 +74,11 @@ def main(path, desc, plan_path=None):
         tm += mf
         tg += gui
         dur_cycles = d["GRBM_GUI_ACTIVE"][2] * 2.4  # ns x 2.4 cycles/ns
-        print("%-36s %6d %5d %9.1f %8.1f%% %10.1f%% %8.1f%% %8.1f%%" % (k[k.index("<"):k.index(">") + 1], g // wg, n, d["GRBM_GUI_ACTIVE"][2] / n / 1e3,
+        label = k[k.index("<"):k.index(">") + 1] if "<" in k else "wino_f23 (Winograd F(2x2,3x3))"
+        print("%-36s %6d %5d %9.1f %8.1f%% %10.1f%% %8.1f%% %8.1f%%" % (label, g // wg, n, d["GRBM_GUI_ACTIVE"][2] / n / 1e3,
                                                                      100 * mf / (gui * 1024), 100 * mf / (dur_cycles * 1024),
                                                                      100 * d["SQ_WAIT_ANY"][0] / wc, 100 * d["SQ_WAIT_INST_ANY"][0] / wc))
-    print("# all conv_gemm dispatches (conv1..conv5 + heads): MfmaUtil = %.1f%% of the 1024 matrix pipes over the kernels' own run time" % (100 * tm / (tg * 1024)))
+    print("# all convolution / deconvolution dispatches (conv1..conv5 + heads): MfmaUtil = %.1f%% of the 1024 matrix pipes over the kernels' own run time" % (100 * tm / (tg * 1024)))
     if plan_path:
         per_stage(c, plan_path)
 

@@ -22,10 +22,10 @@ def main(path):
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-112s %8d %12.1f %10.2f %7.2f" % (name[:112], n, t / 1e3, t / n / 1e3, 100.0 * t / tot))
     print("# total kernel time: %.3f ms over %d dispatches" % (tot / 1e6, sum(a[0] for a in agg.values())))
-    n = sum(a[0] for k, a in agg.items() if "conv_gemm_kernel" in k)
-    t = sum(a[1] for k, a in agg.items() if "conv_gemm_kernel" in k)
+    n = sum(a[0] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k)
+    t = sum(a[1] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k)
     if n:
-        print("# conv_gemm_kernel family: %d dispatches, %.3f ms total, average %.2f us per launch" % (n, t / 1e6, t / n / 1e3))
+        print("# conv_gemm_kernel + wino_f23_kernel (every convolution / deconvolution launch): %d dispatches, %.3f ms total, average %.2f us per launch" % (n, t / 1e6, t / n / 1e3))
 
 
 if __name__ == "__main__":
