@@ -306,6 +306,23 @@ int dc_image_canvas_size(int height, int width, double scale, int* canvas_h, int
   return DC_OK;
 }
 
+int dc_net_detect_parts(dc_net* net, double scale, float threshold, int radius, int max_det, int* counts, double* dets) {
+  REQUIRE(net);
+  REQUIRE(counts);
+  REQUIRE(dets);
+  return guard([&] { N(net)->detect_parts(scale, threshold, radius, max_det, counts, dets); });
+}
+
+int dc_net_decode_pairwise(dc_net* net, double scale, int ndet, const int* detections, const double* mean,
+                           const double* stdev, double* out) {
+  REQUIRE(net);
+  if (ndet > 0) {
+    REQUIRE(detections);
+    REQUIRE(out);
+  }
+  return guard([&] { N(net)->decode_pairwise(scale, ndet, detections, mean, stdev, out); });
+}
+
 int dc_net_flops(dc_net* net, double* flops) {
   REQUIRE(net);
   REQUIRE(flops);

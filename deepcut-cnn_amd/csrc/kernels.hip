@@ -1148,6 +1148,139 @@ int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int 
   return (int)hipGetLastError();
 }
 
+// ---- multi-person consumers: part candidates (NMS) and pairwise regression decode ------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void part_nms_kernel(const T* __restrict__ prob, int pcp, int pc0, int NB, int H, int W, int J,
+                                                       float thr, int radius, int cap, int* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ cand) {
+  const long total = (long)NB * J * H * W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % W);
+  long t = i / W;
+  const int row = (int)(t % H);
+  t /= H;
+  const int j = (int)(t % J), n = (int)(t / J);
+  const T* base = prob + ((long)n * H * W) * pcp + pc0 + j;
+  const float v = (float)base[((long)row * W + col) * pcp];
+  if (!(v >= thr)) return;
+  const int me = row * W + col;
+  for (int dy = -radius; dy <= radius; ++dy) {
+    const int y = row + dy;
+    if (y < 0 || y >= H) continue;
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int x = col + dx;
+      if (x < 0 || x >= W || (dy == 0 && dx == 0)) continue;
+      const float u = (float)base[((long)y * W + x) * pcp];
+      if (u > v || (u == v && y * W + x < me)) return;  // not the maximum of its window (ties: the lower cell index wins)
+    }
+  }
+  const int slot = atomicAdd(cnt + n * J + j, 1);
+  if (slot < cap) cand[(long)(n * J + j) * cap + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)me;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void part_emit_kernel(const T* __restrict__ loc, int lcp, int lc0, int H, int W, int J, double scale,
+                                                       int cap, int max_det, const int* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ cand, double* __restrict__ out) {
+  const int nj = blockIdx.x, n = nj / J, j = nj - n * J;
+  if (threadIdx.x != 0) return;  // lists are short (<= cap): one lane sorts
+  const int m = min(cnt[nj], cap);
+  unsigned long long* c = cand + (long)nj * cap;
+  // order: score descending (non-negative floats compare like their bit patterns), then cell index ascending
+  for (int a = 1; a < m; ++a) {
+    const unsigned long long key = c[a];
+    int b = a - 1;
+    auto before = [](unsigned long long p, unsigned long long q) {
+      const unsigned ps = (unsigned)(p >> 32), qs = (unsigned)(q >> 32);
+      return ps != qs ? ps > qs : (unsigned)p < (unsigned)q;
+    };
+    while (b >= 0 && before(key, c[b])) {
+      c[b + 1] = c[b];
+      --b;
+    }
+    c[b + 1] = key;
+  }
+  const double kLoc = 7.280109889280518;  // sqrt(53)
+  for (int k = 0; k < max_det; ++k) {
+    double* o = out + ((long)nj * max_det + k) * 5;
+    if (k >= m) {
+      o[0] = o[1] = o[2] = 0.0;
+      o[3] = o[4] = -1.0;
+      continue;
+    }
+    const int cell = (int)(unsigned)c[k];
+    const int row = cell / W, col = cell - row * W;
+    const T* l = loc + (((long)n * H + row) * W + col) * lcp + lc0 + 2 * j;
+    o[0] = ((double)col * 8.0 + 4.0 + (double)(float)l[0] * kLoc) / scale;
+    o[1] = ((double)row * 8.0 + 4.0 + (double)(float)l[1] * kLoc) / scale;
+    o[2] = (double)__uint_as_float((unsigned)(c[k] >> 32));
+    o[3] = (double)row;
+    o[4] = (double)col;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_decode_kernel(const T* __restrict__ next, int ncp, int nc0, int NB, int H, int W, int E,
+                                                              double scale, int ndet, const int* __restrict__ det,
+                                                              const double* __restrict__ mean, const double* __restrict__ stdev,
+                                                              double* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)ndet * E) return;
+  const int d = (int)(i / E), l = (int)(i - (long)d * E);
+  const int n = det[3 * d], row = det[3 * d + 1], col = det[3 * d + 2];
+  double* o = out + i * 2;
+  if (n < 0 || n >= NB || row < 0 || row >= H || col < 0 || col >= W) {
+    o[0] = o[1] = 0.0;
+    return;
+  }
+  const T* p = next + (((long)n * H + row) * W + col) * ncp + nc0 + 2 * l;
+  const double m0 = mean ? mean[2 * l] : 0.0, m1 = mean ? mean[2 * l + 1] : 0.0;
+  const double s0 = stdev ? stdev[2 * l] : 1.0, s1 = stdev ? stdev[2 * l + 1] : 1.0;
+  o[0] = ((double)col * 8.0 + 4.0 + (double)(float)p[0] * s0 + m0) / scale;
+  o[1] = ((double)row * 8.0 + 4.0 + (double)(float)p[1] * s1 + m1) / scale;
+}
+
+int launch_part_nms(const void* prob, int pcp, int pc0, int esize, int NB, int H, int W, int J, float thr, int radius, int cap,
+                    int* cnt, unsigned long long* cand, void* stream) {
+  const long total = (long)NB * J * H * W;
+  if (total <= 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (esize == 2)
+    hipLaunchKernelGGL(part_nms_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)prob, pcp, pc0, NB, H, W, J,
+                       thr, radius, cap, cnt, cand);
+  else
+    hipLaunchKernelGGL(part_nms_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)prob, pcp, pc0, NB, H, W, J, thr,
+                       radius, cap, cnt, cand);
+  return (int)hipGetLastError();
+}
+
+int launch_part_emit(const void* loc, int lcp, int lc0, int esize, int NB, int H, int W, int J, double scale, int cap, int max_det,
+                     int* cnt, unsigned long long* cand, double* out, void* stream) {
+  if (NB * J <= 0) return 0;
+  if (esize == 2)
+    hipLaunchKernelGGL(part_emit_kernel<_Float16>, dim3(NB * J), dim3(64), 0, (hipStream_t)stream, (const _Float16*)loc, lcp, lc0, H, W, J,
+                       scale, cap, max_det, cnt, cand, out);
+  else
+    hipLaunchKernelGGL(part_emit_kernel<float>, dim3(NB * J), dim3(64), 0, (hipStream_t)stream, (const float*)loc, lcp, lc0, H, W, J, scale,
+                       cap, max_det, cnt, cand, out);
+  return (int)hipGetLastError();
+}
+
+int launch_pairwise_decode(const void* next, int ncp, int nc0, int esize, int NB, int H, int W, int E, double scale, int ndet,
+                           const int* det, const double* mean, const double* stdev, double* out, void* stream) {
+  const long total = (long)ndet * E;
+  if (total <= 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (esize == 2)
+    hipLaunchKernelGGL(pairwise_decode_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)next, ncp, nc0, NB, H, W,
+                       E, scale, ndet, det, mean, stdev, out);
+  else
+    hipLaunchKernelGGL(pairwise_decode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)next, ncp, nc0, NB, H, W, E,
+                       scale, ndet, det, mean, stdev, out);
+  return (int)hipGetLastError();
+}
+
 // ---- image pre-processing -----------------------------------------------------------------------------------------
 // Integer work at a few bytes per pixel: HBM/latency-bound, one thread per output pixel, no LDS.
 __device__ __forceinline__ int clip8_fixed(int acc) {

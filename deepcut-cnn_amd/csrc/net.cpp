@@ -208,6 +208,7 @@ Net::~Net() {
   release_graph();
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
   if (pose_dev) (void)hipFree(pose_dev);
+  if (scratch_dev_) (void)hipFree(scratch_dev_);
   if (img_dev_) (void)hipFree(img_dev_);
   if (tmp_dev_) (void)hipFree(tmp_dev_);
 }
@@ -1953,6 +1954,85 @@ void Net::decode_pose(double scale, double* out, bool is_device, void* user_stre
   KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, pes, NB, H, W, J, scale, pose_dev, s));
   HIPCHECK(hipMemcpyAsync(out, pose_dev, cnt * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s));
   HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+Net::MapRef Net::map_ref(const char* blob_name) {
+  auto it = blob_index.find(blob_name);
+  if (it == blob_index.end()) throw DcError(DC_EINVAL, std::string("net has no '") + blob_name + "' blob");
+  Storage& s = *blobs[it->second]->st;
+  if (s.head == UNINITIALIZED) throw DcError(DC_EINVAL, std::string("'") + blob_name + "': run forward() first");
+  if (s.shape.size() != 4) throw DcError(DC_ESHAPE, std::string("'") + blob_name + "' is not a 4-D map");
+  MapRef r{};
+  if (s.view_of >= 0) {
+    Storage& b = *storages[s.view_of];
+    r.ptr = b.dev, r.cp = b.cp(), r.c0 = s.view_c0, r.es = b.esize;
+  } else {
+    if (s.head == HEAD_AT_CPU) sync_to_device(s);
+    r.ptr = s.dev, r.cp = s.cp(), r.c0 = 0, r.es = s.esize;
+  }
+  r.NB = s.dim(0), r.C = s.dim(1), r.H = s.dim(2), r.W = s.dim(3);
+  return r;
+}
+
+void* Net::scratch(size_t bytes) {
+  if (bytes > scratch_cap_) {
+    if (scratch_dev_) HIPCHECK(hipFree(scratch_dev_));
+    scratch_dev_ = nullptr;
+    HIPCHECK(hipMalloc((void**)&scratch_dev_, bytes));
+    scratch_cap_ = bytes;
+  }
+  return scratch_dev_;
+}
+
+// Part candidates: non-maximum suppression of every score map + location refinement, on the device.
+void Net::detect_parts(double scale, float thr, int radius, int max_det, int* counts, double* dets) {
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "detect_parts() in CPU mode");
+  if (!(scale > 0) || !(thr >= 0.f) || radius < 0 || radius > 64 || max_det < 1 || max_det > 4096)
+    throw DcError(DC_EINVAL, "detect_parts: scale > 0, threshold >= 0, 0 <= radius <= 64, 1 <= max_det <= 4096");
+  ensure_device();
+  const MapRef P = map_ref("prob"), L = map_ref("loc_pred");
+  if (L.C != 2 * P.C || L.H != P.H || L.W != P.W || L.NB != P.NB || L.es != P.es)
+    throw DcError(DC_ESHAPE, "detect_parts: loc_pred must have 2 channels per joint and the score map's size");
+  const int lists = P.NB * P.C;
+  const int cap = std::max(max_det, 1024);  // candidates kept per map before sorting
+  const size_t cnt_b = ((size_t)lists * sizeof(int) + 255) / 256 * 256, cand_b = (size_t)lists * cap * sizeof(unsigned long long);
+  const size_t out_b = (size_t)lists * max_det * 5 * sizeof(double);
+  unsigned char* base = (unsigned char*)scratch(cnt_b + cand_b + out_b);
+  int* cnt = (int*)base;
+  unsigned long long* cand = (unsigned long long*)(base + cnt_b);
+  double* out = (double*)(base + cnt_b + cand_b);
+  HIPCHECK(hipMemsetAsync(cnt, 0, cnt_b, (hipStream_t)stream));
+  KCHECK(launch_part_nms(P.ptr, P.cp, P.c0, P.es, P.NB, P.H, P.W, P.C, thr, radius, cap, cnt, cand, stream));
+  KCHECK(launch_part_emit(L.ptr, L.cp, L.c0, L.es, P.NB, P.H, P.W, P.C, scale, cap, max_det, cnt, cand, out, stream));
+  HIPCHECK(hipMemcpyAsync(counts, cnt, (size_t)lists * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHECK(hipMemcpyAsync(dets, out, out_b, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < lists; ++i) counts[i] = std::min(counts[i], max_det);  // (more than `cap` local maxima: the list was cut)
+}
+
+// Pairwise regression of the next joint from a set of detections (cells), on the device.
+void Net::decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out) {
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "decode_pairwise() in CPU mode");
+  if (!(scale > 0) || ndet < 0) throw DcError(DC_EINVAL, "decode_pairwise: scale > 0, ndet >= 0");
+  if (ndet == 0) return;
+  ensure_device();
+  const MapRef N = map_ref("next_pred");
+  if (N.C % 2) throw DcError(DC_ESHAPE, "decode_pairwise: next_pred must have 2 channels per regression edge");
+  const int E = N.C / 2;
+  const size_t det_b = ((size_t)ndet * 3 * sizeof(int) + 255) / 256 * 256, st_b = (size_t)E * 2 * sizeof(double);
+  const size_t out_b = (size_t)ndet * E * 2 * sizeof(double);
+  unsigned char* base = (unsigned char*)scratch(det_b + 2 * st_b + out_b);
+  int* ddet = (int*)base;
+  double* dmean = (double*)(base + det_b);
+  double* dstd = dmean + (size_t)E * 2;
+  double* dout = (double*)(base + det_b + 2 * st_b);
+  HIPCHECK(hipMemcpyAsync(ddet, det, (size_t)ndet * 3 * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (mean) HIPCHECK(hipMemcpyAsync(dmean, mean, st_b, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (stdev) HIPCHECK(hipMemcpyAsync(dstd, stdev, st_b, hipMemcpyHostToDevice, (hipStream_t)stream));
+  KCHECK(launch_pairwise_decode(N.ptr, N.cp, N.c0, N.es, N.NB, N.H, N.W, E, scale, ndet, ddet, mean ? dmean : nullptr,
+                                stdev ? dstd : nullptr, dout, stream));
+  HIPCHECK(hipMemcpyAsync(out, dout, out_b, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
 }
 
 std::string Net::plan_text() {

@@ -188,6 +188,9 @@ struct Net {
   void sync_to_host(Storage& s);       // SyncedMemory::to_cpu
   void sync_to_device(Storage& s);     // SyncedMemory::to_gpu
   void decode_pose(double scale, double* out, bool is_device, void* user_stream);  // after a forward
+  // multi-person consumers of the maps of the last forward (encoding: pose_data_layer.cpp:686-802)
+  void detect_parts(double scale, float thr, int radius, int max_det, int* counts, double* dets);
+  void decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out);
   std::string plan_text();
   std::string profile_text(int iters);
   int layer_index(const std::string& name) const;
@@ -207,6 +210,14 @@ struct Net {
   void emit_maps(float* prob, float* loc, float* next, bool is_device, void* s);
   std::shared_ptr<ResampleTable> resample_table(int in_size, int out_size);
   std::map<std::pair<int, int>, std::shared_ptr<ResampleTable>> resample_;
+  struct MapRef {
+    const void* ptr;
+    int cp, c0, es, NB, C, H, W;
+  };
+  MapRef map_ref(const char* blob_name);  // device image of an output map (channel views of the merged heads included)
+  unsigned char* scratch_dev_ = nullptr;  // candidates / detections / pairwise scratch
+  size_t scratch_cap_ = 0;
+  void* scratch(size_t bytes);
   unsigned char* img_dev_ = nullptr;  // uint8 source images uploaded from the host
   size_t img_cap_ = 0;
   unsigned char* tmp_dev_ = nullptr;  // horizontally resampled rows

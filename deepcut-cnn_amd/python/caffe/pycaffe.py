@@ -90,6 +90,8 @@ def _load():
         "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
         "dc_net_forward_images": (ci, [vp, vp, ci, ci, ci, C.c_double, ci, vp, vp, vp, vp, vp]),
         "dc_image_canvas_size": (ci, [ci, ci, C.c_double, C.POINTER(ci), C.POINTER(ci)]),
+        "dc_net_detect_parts": (ci, [vp, C.c_double, C.c_float, ci, ci, vp, vp]),
+        "dc_net_decode_pairwise": (ci, [vp, C.c_double, ci, vp, vp, vp, vp]),
         "dc_net_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_net_num_launches": (ci, [vp]),
         "dc_net_plan_text": (cp, [vp]),
@@ -403,6 +405,29 @@ class Net(object):
         _check(_lib.dc_net_forward_images(self._h, C.c_void_p(img_ptr), n, h, w, float(scale), 1, C.c_void_p(prob_ptr or 0),
                                           C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(pose_ptr or 0),
                                           C.c_void_p(stream or 0)))
+
+    def detect_parts(self, scale=1.0, threshold=0.1, radius=1, max_det=32):
+        """Part candidates of the last forward (NMS of every score map + location refinement, on the device).
+        -> (counts int32 [n, J], dets float64 [n, J, max_det, 5] = x, y, score, cell row, cell column)."""
+        n, j = self.blobs["prob"].shape[:2]
+        counts = np.zeros((n, j), np.int32)
+        dets = np.zeros((n, j, max_det, 5), np.float64)
+        _check(_lib.dc_net_detect_parts(self._h, float(scale), float(threshold), int(radius), int(max_det),
+                                        counts.ctypes.data_as(C.c_void_p), dets.ctypes.data_as(C.c_void_p)))
+        return counts, dets
+
+    def decode_pairwise(self, detections, scale=1.0, mean=None, std=None):
+        """detections: int [D, 3] (image, cell row, cell column) -> float64 [D, E, 2]: where every regression edge of
+        next_pred puts the next joint, seen from each detection's cell (mean / std: [E, 2] de-normalisation)."""
+        det = np.ascontiguousarray(detections, np.int32).reshape(-1, 3)
+        e = self.blobs["next_pred"].shape[1] // 2
+        out = np.zeros((det.shape[0], e, 2), np.float64)
+        m = None if mean is None else np.ascontiguousarray(mean, np.float64).reshape(e, 2)
+        s = None if std is None else np.ascontiguousarray(std, np.float64).reshape(e, 2)
+        _check(_lib.dc_net_decode_pairwise(self._h, float(scale), det.shape[0], det.ctypes.data_as(C.c_void_p),
+                                           None if m is None else m.ctypes.data_as(C.c_void_p),
+                                           None if s is None else s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def clone(self):
         """A second executor of the same model (own activations / stream / graph) sharing the parameters and

@@ -175,6 +175,24 @@ int dc_net_forward_images(dc_net* net, const unsigned char* images, int n, int h
 /* the canvas (= network input) height and width dc_net_forward_images uses for an image at `scale` */
 int dc_image_canvas_size(int height, int width, double scale, int* canvas_h, int* canvas_w);
 
+/* ---- multi-person consumers of the maps (no reference code: the reference repository stops at the maps) --------
+ * What they invert is the label encoding of the reference's training layer (src/caffe/layers/pose_data_layer.cpp:
+ * 686-802): a map cell (row, col) stands for the image point pt = (col*8+4, row*8+4)/scale; loc_pred holds
+ * (joint - pt)*scale/sqrt(53); next_pred channel pair l holds ((next joint - pt)*scale - mean[l]) / std[l] for
+ * regression edge l (edges, means and stds come from the model's `joint_pairs_stats` file, caffe.proto:1184).
+ *
+ * dc_net_detect_parts: non-maximum suppression of every score map of the last forward, on the device: a cell is a
+ * candidate if prob >= threshold and it is the maximum of its (2*radius+1)^2 window (ties: the lower row-major cell
+ * index).  Per image and joint the candidates are ordered by (score descending, cell ascending) and the first
+ * max_det are returned: counts[n*J + j] and dets[((n*J + j)*max_det + k)*5 + {0..4}] = x, y (refined with loc_pred,
+ * divided by scale), score, cell row, cell column.  Host buffers; synchronous.
+ * dc_net_decode_pairwise: for ndet detections given as (image, cell row, cell column) triples and every edge l,
+ * out[(d*E + l)*2 + {0,1}] = pt + (next_pred[2l + k] at the cell * std[l][k] + mean[l][k]) / scale, E = channels/2;
+ * mean / std may be NULL (0 / 1).  Host buffers; synchronous.                                               */
+int dc_net_detect_parts(dc_net* net, double scale, float threshold, int radius, int max_det, int* counts, double* dets);
+int dc_net_decode_pairwise(dc_net* net, double scale, int ndet, const int* detections, const double* mean,
+                           const double* stdev, double* out);
+
 /* ---- Layer::Forward_gpu surface ---------------------------------------------------------
  * One reference layer stand-alone = a one-layer prototxt given to dc_net_create_from_text with
  * DC_OPT_FUSE 0, weights injected through dc_net_param + dc_blob_mutable_cpu_data: the CDNA4
