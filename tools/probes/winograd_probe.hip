@@ -99,8 +99,10 @@ __global__ __launch_bounds__(NTH) void wino_kernel(const float* __restrict__ x, 
     }
   };
   auto compute = [&](int slot, int bslot) {
-    f32x2 tl[4], th[4];  // packed fp32 math where the compiler finds register pairs (forcing v_pk_* through inline asm
-                         // changed neither the time nor — for a reason not chased — gave right answers)
+    f32x2 tl[4], th[4];  // packed fp32 math where the compiler finds register pairs.  Forcing all 16 operations to v_pk_*
+                         // through inline asm needs explicit wait states before the MFMAs read the results (the hazard
+                         // recogniser does not see into asm: without them the answers are wrong) and is slower
+                         // (17.9 vs 17.2 us): the block cannot be interleaved with the MFMAs
     const f32x2 sb2 = {sb, sb};
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
