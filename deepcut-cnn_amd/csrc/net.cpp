@@ -1428,8 +1428,8 @@ void Net::autotune() {
       }
       it = tune_cache_.emplace(key, best).first;
     }
-    l.variant = it->second;
-    if (l.variant == kWinoVariant && l.wino_w < 0) l.variant = 0;  // a stale cache line: this build cannot run it
+    // a cache line naming the Winograd form while it is switched off (or not eligible any more): keep the cost model's tile
+    if (!(it->second == kWinoVariant && l.wino_w < 0)) l.variant = it->second;
     if (l.variant == kWinoVariant) {
       l.kernel = "wino_f23<4x8x16>";
       l.grid = wino_grid(l.cg);
