@@ -594,10 +594,12 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
 //    a wave owns the 4 positions (i, 0..3) of its fragment: 4 accumulators of v_mfma_f32_16x16x4_f32;
 //  * the 10 x 18 input pixels the block reads are staged ONCE per 32 channels in LDS (ring of 3, one barrier per 32
 //    channels); every wave reads the two patch rows its transform row needs and does B^T d B in registers (packed fp32)
-//    one sub-step ahead of its MFMAs — the transformed input never exists in memory;
+//    right before its MFMAs — the transformed input never exists in memory;
 //  * the transformed filters are the big stream (16/9 of the filter bytes, no reuse inside a workgroup): pre-packed on
-//    the host so that each wave reads its B fragments straight from global memory, 1 KB contiguous per load, two
-//    sub-steps ahead; workgroups that share them (same 16 output channels) are adjacent in the grid;
+//    the host so that each wave reads its B fragments straight from global memory, 1 KB contiguous per load, one
+//    sub-step ahead; workgroups that share them (same 16 output channels) are adjacent in the grid;
+//  * 110 VGPRs and 78 KB of LDS: two workgroups per CU, so that forwards in flight can share CUs (with the register-
+//    hungrier pipelined variant of the probe the kernel was as fast alone but worth nothing with three forwards in flight);
 //  * the inverse transform reduces over j in registers and over i (four waves) through LDS, then applies the folded
 //    BatchNorm/Scale affine, the shortcut and ReLU like the gather-GEMM's epilogue.
 // Measured on the res4 3x3 shape (1x34x46, 256 -> 256): 17.2 us vs 23.5 us for the direct kernel (tools/probes/winograd_probe.hip).
@@ -613,7 +615,7 @@ __device__ __forceinline__ f32x2 wlo(f32x4 v) { return __builtin_shufflevector(v
 __device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 }  // namespace
 
-__global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams p) {
   __shared__ __attribute__((aligned(16))) float stage[3][WRH * WRW * WPSTR + 8];
   // [i][b][tf][r][lane] partial inverse transforms: reuses the staging ring once the K loop is over (78 KB per
   // workgroup instead of 94: two workgroups fit the 160 KB of a CU)
@@ -659,7 +661,10 @@ __global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) 
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ub = up + ((long)(nt * 4 + i) * (C / 16)) * (4 * 64 * 4) + lane * 4;
-  f32x4 g[WNLD], b[3][4], da[2][4], db[2][4];
+  // Registers are kept to 110 per wave on purpose: four waves per SIMD = two workgroups per CU (this kernel's, or one of
+  // the gather-GEMM's), which is what lets forwards in flight share a CU; LDS reads are therefore issued right before
+  // their use (the other resident waves hide their latency) and only the filter fragments run one sub-step ahead.
+  f32x4 g[WNLD], b[2][4], da[4], db[4];
   auto gload = [&](int K) {
 #pragma unroll
     for (int q = 0; q < WNLD; ++q) g[q] = gofs[q] >= 0 ? *reinterpret_cast<const f32x4*>(xn + gofs[q] + K * WKC) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -673,20 +678,20 @@ __global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[slot][j] = *reinterpret_cast<const f32x4*>(ub + ((long)k16 * 4 + j) * 256);
   };
-  auto lread = [&](int slot, int buf, int h) {
+  auto lread = [&](int buf, int h) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      da[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_a + c4 * WPSTR + h * 16]);
-      db[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_b + c4 * WPSTR + h * 16]);
+      da[c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_a + c4 * WPSTR + h * 16]);
+      db[c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_b + c4 * WPSTR + h * 16]);
     }
   };
-  auto compute = [&](int slot, int bslot) {
+  auto compute = [&](int bslot) {
     f32x2 tl[4], th[4];
     const f32x2 sb2 = {sb, sb};
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      tl[c4] = wlo(da[slot][c4]) + sb2 * wlo(db[slot][c4]);
-      th[c4] = whi(da[slot][c4]) + sb2 * whi(db[slot][c4]);
+      tl[c4] = wlo(da[c4]) + sb2 * wlo(db[c4]);
+      th[c4] = whi(da[c4]) + sb2 * whi(db[c4]);
     }
     f32x2 vl[4], vh[4];
     vl[0] = tl[0] - tl[2], vh[0] = th[0] - th[2];
@@ -704,37 +709,27 @@ __global__ __launch_bounds__(WNTH) void wino_f23_kernel(const ConvGemmParams p) 
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vh[j][1], b[bslot][j][3], acc[j], 0, 0, 0);
   };
   const int NS = C / WKC;
-  // pipeline: global -> registers (3 steps ahead) -> LDS ring of 3 (2 steps ahead) -> registers (1 sub-step ahead) -> MFMA
+  // pipeline: global -> registers (3 steps ahead) -> LDS ring of 3 (2 steps ahead) -> MFMA; filters one sub-step ahead
   gload(0);
   bload(0, 0);
-  bload(1, 1);
   sstore(0);
   if (NS > 1) {
     gload(1);
     sstore(1);
   }
   if (NS > 2) gload(2);
-  __syncthreads();
-  lread(0, 0, 0);
-  // one staged step: U = K % 3 is a template-like constant so that every ring slot is a compile-time register name
+  // one staged step: U = K % 3 is a compile-time constant so that the ring buffer offsets fold into the instructions
   auto step = [&](int K, auto u_tag) {
     constexpr int U = decltype(u_tag)::value;
     __syncthreads();  // buffers <= K+1 are complete; buffer (K+2)%3 is free
-    __builtin_amdgcn_sched_barrier(0);
-    lread(1, U, 1);
-    bload((2 * U + 2) % 3, 2 * K + 2 < 2 * NS ? 2 * K + 2 : 0);  // the tail loads are harmless re-reads of step 0
-    __builtin_amdgcn_sched_barrier(0);
-    compute(0, (2 * U) % 3);
-    __builtin_amdgcn_sched_barrier(0);
+    lread(U, 0);
+    bload(1, 2 * K + 1);
+    compute(0);
     if (K + 2 < NS) sstore((U + 2) % 3);
-    __builtin_amdgcn_sched_barrier(0);
-    if (K + 1 < NS) lread(0, (U + 1) % 3, 0);
-    bload((2 * U + 3) % 3, 2 * K + 3 < 2 * NS ? 2 * K + 3 : 0);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(1, (2 * U + 1) % 3);
-    __builtin_amdgcn_sched_barrier(0);
+    lread(U, 1);
+    bload(0, 2 * K + 2 < 2 * NS ? 2 * K + 2 : 0);  // the tail load is a harmless re-read of step 0
+    compute(1);
     if (K + 3 < NS) gload(K + 3);
-    __builtin_amdgcn_sched_barrier(0);
   };
   for (int K0 = 0; K0 < NS; K0 += 3) {
     step(K0, std::integral_constant<int, 0>{});

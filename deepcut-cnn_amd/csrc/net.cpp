@@ -1387,8 +1387,9 @@ void Net::autotune() {
     if (l.kind != Launch::CONV) continue;
     const ConvGemmParams& g = l.cg;
     char key[160];
-    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
-                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW);
+    // "+w": the Winograd form competes for this layer (a different candidate set than with DC_WINOGRAD=0)
+    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
+                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w >= 0 ? "+w" : "");
     auto it = tune_cache_.find(key);
     if (it == tune_cache_.end()) {
       int best = l.variant;
