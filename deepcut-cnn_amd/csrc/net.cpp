@@ -1521,7 +1521,10 @@ void Net::run_launch(const Launch& l, void* s) {
         break;
       }
       static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
-      const int my_idx = (int)(&l - plan.data());
+      // index of this launch in the plan (autotuning passes copies, which have none)
+      const bool in_plan = !plan.empty() && std::greater_equal<const Launch*>()(&l, plan.data()) &&
+                           std::less<const Launch*>()(&l, plan.data() + plan.size());
+      const int my_idx = in_plan ? (int)(&l - plan.data()) : -1;
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
         // device-side phase timestamps of ONE launch (diagnostics only): wall clock (100 MHz) at
         // start / loop entry / loop exit / end, and the shader cycle counter at the same points
