@@ -13,6 +13,11 @@ for p in (ROOT, PKG, os.path.join(PKG, "python")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # test modules import `caffe` (the ctypes shim) at collection time: the native library has to exist before that.
+    # A no-op when the in-tree build is up to date (e.g. on the GPU box, where the prebuilt .so travels with the snapshot).
+    import __graft_entry__ as g
+
+    g.build()
 
 
 @pytest.fixture(scope="session", autouse=True)
