@@ -51,17 +51,61 @@ class ShardedPoseRunner(object):
     """`net`: a caffe.Net of this package (or anything with forward_batch(images)->dict and
     decode_pose(scale)->[n,5,J]).  `preprocess(image, scale) -> HxWx3 float32` defaults to pose.estimate_pose's."""
 
-    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True):
+    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True, depth=1):
+        """depth > 1 (image entry, poses only): that many batches are kept in flight on this GPU, each on its own
+        executor (`net.clone()`: shared weights) and stream — upload, pre-processing, forward and decode of one batch
+        overlap the others'; results are identical to depth 1."""
         self.net = net
         self.group = group
         self.max_batch = max_batch
         self.device = device
+        self.depth = max(1, int(depth))
+        self._execs = None
         self.image_entry = bool(device_preprocess and preprocess is None and hasattr(net, "forward_images"))
         if preprocess is None:
             from pose.estimate_pose import preprocess as _pp
 
             preprocess = _pp
         self.preprocess = preprocess
+
+    def _run_in_flight(self, images, items, by_source, poses):
+        """Poses of the local work items with `depth` batches in flight (device buffers through torch)."""
+        import torch
+
+        if self._execs is None:
+            self._execs = [self.net] + [self.net.clone() for _ in range(self.depth - 1)]
+            self._streams = [torch.cuda.Stream() for _ in self._execs]
+        nj = self.net.blobs["prob"].shape[1]
+        busy = [None] * self.depth
+
+        def finish(e):
+            if busy[e] is None:
+                return
+            chunk, pose_t, _img_t = busy[e]
+            self._streams[e].synchronize()
+            host = pose_t.cpu().numpy()
+            for j, k in enumerate(chunk):
+                poses[k] = host[j]
+            busy[e] = None
+
+        slot = 0
+        for key in sorted(by_source):
+            ks, s = by_source[key], key[1]
+            h, w = key[0]
+            for b0 in range(0, len(ks), self.max_batch):
+                chunk = ks[b0:b0 + self.max_batch]
+                e = slot % self.depth
+                slot += 1
+                finish(e)
+                st = self._streams[e]
+                with torch.cuda.stream(st):
+                    img_t = torch.from_numpy(np.stack([images[items[k][0]] for k in chunk])).cuda(non_blocking=True)
+                    pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device="cuda")
+                self._execs[e].forward_images_device(img_t.data_ptr(), len(chunk), h, w, s, pose_ptr=pose_t.data_ptr(),
+                                                     stream=st.cuda_stream)
+                busy[e] = (chunk, pose_t, img_t)
+        for e in range(self.depth):
+            finish(e)
 
     def run(self, images, scales, want_maps=False):
         """images: list of HxWx3 BGR uint8 (the same list on every rank).  Returns on rank 0 a dict
@@ -83,6 +127,9 @@ class ShardedPoseRunner(object):
                 by_shape.setdefault(items[k][2], []).append(k)
         poses = {}
         maps = {}
+        if by_source and self.depth > 1 and not want_maps and hasattr(self.net, "forward_images_device"):
+            self._run_in_flight(images, items, by_source, poses)
+            by_source = {}
         for key in sorted(by_source):
             ks, s = by_source[key], key[1]
             for b0 in range(0, len(ks), self.max_batch):

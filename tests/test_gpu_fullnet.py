@@ -297,6 +297,10 @@ def test_sharded_runner_on_the_hip_path(gpu_caffe, synth152):
     res = ShardedPoseRunner(net).run(imgs, scales, want_maps=True)
     assert len(res["items"]) == 6 and sorted(res["maps"]) == list(range(6))
     assert res["maps"][0]["next_pred"].shape[0] == 364
+    # several batches in flight (clones, one stream each): the same poses
+    piped = ShardedPoseRunner(net, max_batch=2, depth=3).run(imgs, scales)
+    base = ShardedPoseRunner(net, max_batch=2, depth=1).run(imgs, scales)
+    assert np.abs(piped["item_poses"] - base["item_poses"]).max() <= 1e-2 and piped["best_scale"] == base["best_scale"]
     net2 = gpu_caffe.Net(deepercut_prototxt(152, 96, 128), path, gpu_caffe.TEST, from_text=True)
     for i, im in enumerate(imgs):
         ref = ep.estimate_pose(im, None, None, scales, net=net2, on_device=False)  # Pillow + NumPy around net.forward()

@@ -70,6 +70,13 @@ def main():
     dt = timed(lambda: r.run(crops, scales), 3)
     out["config5_32_crops_4_scales_fp32_poses_only"] = {"seconds": dt, "crops_per_s": 32 / dt, "forwards_per_s": 128 / dt,
                                                         "tflops": 32 * 177.8e9 / dt / 1e12}
+    r3 = ShardedPoseRunner(full, max_batch=16, depth=3)
+    dt = timed(lambda: r3.run(crops, scales), 3)
+    out["config5_32_crops_4_scales_fp32_poses_only_3_batches_in_flight"] = {"seconds": dt, "crops_per_s": 32 / dt, "forwards_per_s": 128 / dt,
+                                                                            "tflops": 32 * 177.8e9 / dt / 1e12}
+    r3 = ShardedPoseRunner(full, max_batch=4, depth=3)
+    dt = timed(lambda: r3.run(imgs8, [1.0]), 10)
+    out["config4_share_8_images_fp32_3_batches_of_4_in_flight"] = {"seconds": dt, "images_per_s": 8 / dt}
     print(json.dumps(out, indent=1))
 
 
