@@ -106,7 +106,7 @@ int dc_net_set_option(dc_net* net, int key, int value) {
   return guard([&] {
     Net* n = N(net);
     if (key == DC_OPT_FUSE) {
-      if (n->fuse != value) n->plan_valid = false;
+      if (n->fuse != value) n->invalidate_plans();
       n->fuse = value;
     } else if (key == DC_OPT_HIPGRAPH) {
       n->use_graph = value;
@@ -232,7 +232,10 @@ static int blob_host(dc_blob* b, float** out, bool mut) {
     if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
     if (mut) {
       s.head = HEAD_AT_CPU;
-      if (s.is_param && s.owner) s.owner->weights_dirty = true;
+      if (s.is_param && s.shared) {  // a writable view was handed out: its content is re-checked before the next run
+        std::lock_guard<std::mutex> lk(s.shared->mu);
+        s.shared->touched.push_back(B(b)->st);
+      }
     }
   });
 }
@@ -328,11 +331,7 @@ int dc_net_flops(dc_net* net, double* flops) {
   REQUIRE(flops);
   return guard([&] {
     Net* n = N(net);
-    n->reshape();
-    std::vector<int> sig;
-    for (int bi : n->inputs)
-      for (int d : n->blobs[bi]->st->shape) sig.push_back(d);
-    if (!n->plan_valid || sig != n->plan_input_shape) n->build_plan();
+    n->ensure_plan();
     *flops = n->plan_flops;
   });
 }
@@ -348,16 +347,25 @@ int dc_net_num_launches(dc_net* net) {
 const char* dc_net_plan_text(dc_net* net) {
   if (!net) return nullptr;
   Net* n = N(net);
-  int rc = guard([&] {
-    n->reshape();
-    std::vector<int> sig;
-    for (int bi : n->inputs)
-      for (int d : n->blobs[bi]->st->shape) sig.push_back(d);
-    if (!n->plan_valid || sig != n->plan_input_shape) n->build_plan();
-    n->text_buf = n->plan_text();
-  });
+  int rc = guard([&] { n->text_buf = n->plan_text(); });
   return rc == DC_OK ? n->text_buf.c_str() : nullptr;
 }
+int dc_net_stats(dc_net* net, long long* out, int n) {
+  REQUIRE(net);
+  REQUIRE(out);
+  const NetStats& st = N(net)->stats;
+  const long long v[DC_NUM_STATS] = {st.lowerings,      st.graph_instantiations, st.plan_hits, st.autotune_runs,
+                                     st.buffer_growths, st.repacks,              (long long)N(net)->parked_.size() + (N(net)->plan_valid ? 1 : 0)};
+  for (int i = 0; i < n && i < DC_NUM_STATS; ++i) out[i] = v[i];
+  return DC_OK;
+}
+int dc_net_reserve(dc_net* net, int n, int h, int w) {
+  REQUIRE(net);
+  if (n <= 0 || h <= 0 || w <= 0) return fail(DC_EINVAL, "bad batch shape");
+  return guard([&] { N(net)->reserve(n, h, w); });
+}
+int dc_net_device(dc_net* net) { return net ? N(net)->device : -1; }
+
 const char* dc_net_profile_text(dc_net* net, int iters) {
   if (!net) return nullptr;
   Net* n = N(net);

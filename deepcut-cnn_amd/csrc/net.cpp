@@ -105,6 +105,10 @@ void Storage::ensure_dev(size_t n) {
   HIPCHECK(hipMalloc((void**)&dev, bytes));
   HIPCHECK(hipMemset(dev, 0, bytes));  // pitch-padding channels stay 0
   dev_cap = bytes;
+  if (owner) {  // captured graphs carry the old address: they are re-captured lazily (PlanState::graph_buf_gen)
+    ++owner->buf_gen_;
+    ++owner->stats.buffer_growths;
+  }
 }
 void Storage::ensure_stage(size_t n) {
   if (n <= stage_cap && stage) return;
@@ -206,6 +210,8 @@ DevVec::~DevVec() {
 
 Net::~Net() {
   release_graph();
+  for (auto& ps : parked_)
+    if (ps->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ps->graph_exec);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
   if (pose_dev) (void)hipFree(pose_dev);
   if (scratch_dev_) (void)hipFree(scratch_dev_);
@@ -213,27 +219,27 @@ Net::~Net() {
   if (tmp_dev_) (void)hipFree(tmp_dev_);
 }
 
-Net* Net::create(const std::string& text, int phase) {
+Net* Net::create(const std::string& text, int phase, const Net* clone_of) {
   std::unique_ptr<Net> n(new Net());
   n->phase = phase;
   n->proto_text = text;
+  n->clone_src_ = clone_of;  // a clone adopts the source's parameter blobs layer by layer instead of allocating its own
+  n->shared = clone_of ? clone_of->shared : std::make_shared<ModelShared>();
   TextMsg root = parse_text_proto(text);
   n->init_from(root);
+  n->clone_src_ = nullptr;
   return n.release();
 }
 
 // A clone runs the same model concurrently with its parent (own activations, own stream, own graph) while
 // sharing the parameter blobs and the packed filter images in HBM: this is how several independent forwards
 // are kept in flight on one GPU without paying 263 MB per copy (deepcut_tools.Pipeline, bench.py).
+// The parameter blobs, the packed images and the measured tile choices live in `shared` (ModelShared), owned jointly:
+// either side may be destroyed first, and a parameter write through either side reaches both (weights_gen).
 Net* Net::clone() {
   reshape();
-  std::vector<int> sig;
-  for (int bi : inputs)
-    for (int d : blobs[bi]->st->shape) sig.push_back(d);
-  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();  // host-side packing, shared below
-  std::unique_ptr<Net> c(Net::create(proto_text, phase));
+  std::unique_ptr<Net> c(Net::create(proto_text, phase, this));
   if (c->layers.size() != layers.size()) throw DcError(DC_EINVAL, "clone: graph mismatch");
-  for (size_t i = 0; i < layers.size(); ++i) c->layers[i].params = layers[i].params;  // shared host parameters
   for (size_t i = 0; i < inputs.size(); ++i) c->blobs[c->inputs[i]]->st->reshape(blobs[inputs[i]]->st->shape);
   c->fuse = fuse;
   c->use_graph = use_graph;
@@ -242,10 +248,6 @@ Net* Net::clone() {
     for (auto& st : c->storages)
       if (!st->is_param) st->esize = dtype == 1 ? 2 : 4;
   }
-  c->vecs = vecs;
-  c->vec_keys_ = vec_keys_;
-  c->tune_cache_ = tune_cache_;
-  c->weights_dirty = false;
   c->device = device;
   c->reshape();
   return c.release();
@@ -268,9 +270,7 @@ void Net::set_dtype(int d) {
     }
     st->esize = d == 1 ? 2 : 4;
   }
-  weights_dirty = true;
-  plan_valid = false;
-  release_graph();
+  invalidate_plans();  // packed images are keyed by dtype in the shared cache: no re-pack of the other type's images
 }
 
 void Net::synchronize() {
@@ -403,12 +403,24 @@ void Net::init_from(const TextMsg& root) {
 void Net::setup_layer(LayerRec& L) {
   const std::string& t = L.type;
   auto st_of = [&](int bi) -> Storage& { return *blobs[bi]->st; };
+  const LayerRec* src = nullptr;  // clone: adopt the source net's parameter blobs of this layer
+  if (clone_src_) {
+    const size_t idx = (size_t)(&L - layers.data());
+    if (idx >= clone_src_->layers.size() || clone_src_->layers[idx].name != L.name) throw DcError(DC_EINVAL, "clone: graph mismatch");
+    src = &clone_src_->layers[idx];
+  }
   auto add_param = [&](std::vector<int> shape, float fill) {
+    if (src) {
+      const size_t j = L.params.size();
+      if (j >= src->params.size() || src->params[j]->st->shape != shape) throw DcError(DC_EINVAL, "clone: parameter mismatch");
+      L.params.push_back(src->params[j]);
+      return;
+    }
     auto b = std::make_shared<NetBlob>();
     b->name = L.name;
     b->st = std::make_shared<Storage>();
     b->st->is_param = true;
-    b->st->owner = this;
+    b->st->shared = shared;
     b->st->reshape(shape);
     float* p = b->st->host_ptr();
     size_t n = b->st->count();
@@ -614,7 +626,7 @@ void Net::copy_from(const std::string& path) {
       dst.head = HEAD_AT_CPU;
     }
   }
-  weights_dirty = true;
+  mark_weights_changed();
 }
 
 void Net::save(const std::string& path) {
@@ -674,6 +686,17 @@ double variant_cost(const ConvGemmParams& p, int v) {
   return std::max(t_mfma, t_l2);
 }
 }  // namespace
+
+// 64-bit content hash of a parameter blob (four independent multiply-xor lanes so that it runs at memory speed)
+static uint64_t content_hash(const float* p, size_t n) {
+  uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+  const uint32_t* u = reinterpret_cast<const uint32_t*>(p);
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4)
+    for (int k = 0; k < 4; ++k) h[k] = (h[k] ^ u[i + k]) * 0x100000001b3ull + (h[k] >> 29);
+  for (; i < n; ++i) h[0] = (h[0] ^ u[i]) * 0x100000001b3ull + (h[0] >> 29);
+  return (h[0] * 31 + h[1]) * 31 + (h[2] * 31 + h[3]) + n;
+}
 
 static int env_int(const char* k, int def) {
   const char* v = std::getenv(k);
@@ -1010,20 +1033,24 @@ void Net::build_plan() {
   // finalize: launches
   plan.clear();
   plan_flops = 0;
-  if (weights_dirty) {
-    vecs.clear();  // shared images stay alive in clones that still reference them
-    vec_keys_.clear();
-    weights_dirty = false;
-    release_graph();
+  ++stats.lowerings;
+  // the packed-image cache is shared with the clones: the first executor to lower after a parameter change empties it
+  // (images still referenced by another executor's plans stay alive until that executor re-lowers too)
+  std::lock_guard<std::mutex> pack_lock(shared->mu);
+  if (shared->packed_gen != shared->weights_gen) {
+    shared->vec_by_key.clear();
+    shared->packed_gen = shared->weights_gen;
+    for (auto& L : layers)
+      for (auto& pb : L.params) pb->st->packed_hash = content_hash(pb->st->host_ptr(), pb->st->count());
+    ++stats.repacks;
   }
   auto get_vec = [&](const std::string& key, const std::function<void(std::vector<float>&)>& fill) {
-    auto it = vec_keys_.find(key);
-    if (it != vec_keys_.end()) return it->second;
+    auto it = shared->vec_by_key.find(key);
+    if (it != shared->vec_by_key.end()) return it->second;
     auto v = std::make_shared<DevVec>();
     fill(v->host);
-    vecs.push_back(std::move(v));
-    vec_keys_[key] = (int)vecs.size() - 1;
-    return (int)vecs.size() - 1;
+    shared->vec_by_key[key] = v;
+    return v;
   };
   auto label_of = [&](const LOp& op) {
     std::string s;
@@ -1177,7 +1204,7 @@ void Net::build_plan() {
       affine_vecs(op, l, OC);
       l.flops = 2.0 * g.M * (double)OC * C * c.kh * c.kw;
       plan_flops += l.flops;
-      vecs[l.w]->as_half = dtype == 1;
+      l.w->as_half = dtype == 1;
       choose_variant(l, kgcd);
       // stride-1 3x3 layers can also run as Winograd F(2x2,3x3): keep the transformed filters next to the direct ones
       // and let the per-shape timing decide (kernels.hip, wino_f23_kernel)
@@ -1282,7 +1309,7 @@ void Net::build_plan() {
                           }
                         });
           l.flops = 2.0 * g.M * (double)OC * C * ntaps;
-          vecs[l.w]->as_half = dtype == 1;
+          l.w->as_half = dtype == 1;
           choose_variant(l, CP);
           plan.push_back(std::move(l));
           any = true;
@@ -1317,8 +1344,123 @@ void Net::build_plan() {
   plan_input_shape.clear();
   for (int bi : inputs)
     for (int d : blobs[bi]->st->shape) plan_input_shape.push_back(d);
+  cur_last_use_ = ++use_clock_;
   release_graph();
 }
+
+// ---- per-shape plan cache -----------------------------------------------------------------------------
+static std::vector<int> input_signature(const Net& n) {
+  std::vector<int> sig;
+  for (int bi : n.inputs)
+    for (int d : n.blobs[bi]->st->shape) sig.push_back(d);
+  return sig;
+}
+
+void Net::mark_weights_changed() {
+  std::lock_guard<std::mutex> lk(shared->mu);
+  ++shared->weights_gen;
+}
+
+// Parameters are handed out writable on every access (pycaffe's Blob.data is mutable_cpu_data, _caffe.cpp:273), so an
+// access alone says nothing: the blobs touched since the last run are re-hashed here and only a CONTENT change moves
+// the shared generation.  Every executor of the model compares that generation with the one its plans came from.
+void Net::check_weights() {
+  uint64_t gen;
+  {
+    std::lock_guard<std::mutex> lk(shared->mu);
+    if (!shared->touched.empty()) {
+      bool changed = shared->packed_gen != shared->weights_gen;  // nothing packed yet: hashes are not meaningful
+      for (auto& w : shared->touched)
+        if (auto st = w.lock())
+          if (!changed && content_hash(st->host_ptr(), st->count()) != st->packed_hash) changed = true;
+      shared->touched.clear();
+      if (changed && shared->packed_gen == shared->weights_gen) ++shared->weights_gen;
+    }
+    gen = shared->weights_gen;
+  }
+  if (gen != seen_weights_gen) {
+    invalidate_plans();
+    seen_weights_gen = gen;
+  }
+}
+
+void Net::invalidate_plans() {
+  if (stream && (plan_valid || !parked_.empty())) (void)hipStreamSynchronize((hipStream_t)stream);  // nothing in flight reads them
+  release_graph();
+  for (auto& ps : parked_)
+    if (ps->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ps->graph_exec);
+  parked_.clear();
+  plan.clear();
+  plan_valid = false;
+  tuned = false;
+}
+
+void Net::park_current() {
+  if (!plan_valid) return;
+  std::unique_ptr<PlanState> ps(new PlanState());
+  ps->input_shape = plan_input_shape;
+  ps->plan.swap(plan);
+  ps->flops = plan_flops;
+  ps->views.swap(plan_views_);
+  for (auto& st : storages) ps->sstate.push_back({st->id, st->view_of, st->view_c0, st->elided});
+  for (auto& kv : aux_index_) ps->aux_shapes.push_back({kv.second, storages[kv.second]->shape});
+  ps->graph_exec = graph_exec;
+  ps->graph_buf_gen = graph_buf_gen;
+  ps->tuned = tuned;
+  ps->last_use = cur_last_use_;
+  graph_exec = nullptr;
+  plan_valid = false;
+  parked_.push_back(std::move(ps));
+  static const int cap = std::max(1, env_int("DC_PLAN_CACHE", 16));
+  while ((int)parked_.size() > cap) {  // least recently used shape goes
+    size_t lru = 0;
+    for (size_t i = 1; i < parked_.size(); ++i)
+      if (parked_[i]->last_use < parked_[lru]->last_use) lru = i;
+    if (parked_[lru]->graph_exec) {
+      if (stream) (void)hipStreamSynchronize((hipStream_t)stream);
+      (void)hipGraphExecDestroy((hipGraphExec_t)parked_[lru]->graph_exec);
+    }
+    parked_.erase(parked_.begin() + lru);
+  }
+}
+
+// Make the plan of the CURRENT input shape the active one.  Shapes of every blob are re-derived first (Layer::Forward
+// calls Reshape on every forward, layer.hpp:451-456); a shape met before costs that walk and a swap, nothing else.
+void Net::ensure_plan() {
+  check_weights();
+  reshape();
+  const std::vector<int> sig = input_signature(*this);
+  if (plan_valid && sig == plan_input_shape) {
+    cur_last_use_ = ++use_clock_;
+    return;
+  }
+  for (size_t i = 0; i < parked_.size(); ++i) {
+    if (parked_[i]->input_shape != sig) continue;
+    std::unique_ptr<PlanState> ps = std::move(parked_[i]);
+    parked_.erase(parked_.begin() + i);
+    park_current();
+    plan_input_shape = ps->input_shape;
+    plan.swap(ps->plan);
+    plan_flops = ps->flops;
+    plan_views_.swap(ps->views);
+    for (auto& ss : ps->sstate) {
+      Storage& st = *storages[ss.id];
+      st.view_of = ss.view_of, st.view_c0 = ss.view_c0, st.elided = ss.elided;
+    }
+    for (auto& as : ps->aux_shapes) storages[as.first]->reshape(as.second);
+    graph_exec = ps->graph_exec;
+    graph_buf_gen = ps->graph_buf_gen;
+    tuned = ps->tuned;
+    plan_valid = true;
+    cur_last_use_ = ++use_clock_;
+    ++stats.plan_hits;
+    return;
+  }
+  park_current();
+  build_plan();
+}
+
+void Net::reserve(int n, int h, int w) { begin_batch(n, h, w); }
 
 // ---- execution ----------------------------------------------------------------------------------------
 void Net::ensure_device() {
@@ -1336,8 +1478,13 @@ void Net::ensure_device() {
 }
 
 void Net::upload_vecs() {
-  for (auto& vp : vecs) {
-    DevVec& v = *vp;
+  std::lock_guard<std::mutex> lk(shared->mu);  // an image may be shared with a clone that uploads at the same moment
+  std::vector<DevVec*> todo;
+  for (auto& l : plan)
+    for (const std::shared_ptr<DevVec>* vp : {&l.w, &l.scale, &l.shift, &l.wino_w})
+      if (*vp && !(*vp)->dev && !(*vp)->host.empty()) todo.push_back(vp->get());
+  for (DevVec* vq : todo) {
+    DevVec& v = *vq;
     if (!v.dev && !v.host.empty()) {
       if (v.as_half) {  // filter image of an fp16 net: upload as float, convert on the device, keep the half copy
         float* tmp = nullptr;
@@ -1366,8 +1513,11 @@ void Net::autotune() {
   if (env_int("DC_AUTOTUNE", 1) == 0 || env_int("DC_CONV_VARIANT", -1) >= 0) return;
   // DC_TUNE_CACHE=<file>: tuning results persist across processes ("signature variant-name" per line), so
   // a service (or a profiling run) starts without the timing launches
+  std::lock_guard<std::mutex> tune_lock(shared->mu);  // one executor times a shape, the clones reuse its choices
+  std::map<std::string, int>& tune_cache_ = shared->tune_cache;
   const char* cache_path = std::getenv("DC_TUNE_CACHE");
-  if (cache_path && tune_cache_.empty()) {
+  if (cache_path && !shared->tune_file_loaded) {
+    shared->tune_file_loaded = true;
     if (FILE* f = std::fopen(cache_path, "r")) {
       char key[200], vname[64];
       while (std::fscanf(f, "%199s %63s", key, vname) == 2) {
@@ -1379,6 +1529,7 @@ void Net::autotune() {
     }
   }
   size_t cached_before = tune_cache_.size();
+  bool timed_any = false;
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
@@ -1389,9 +1540,10 @@ void Net::autotune() {
     char key[160];
     // "+w": the Winograd form competes for this layer (a different candidate set than with DC_WINOGRAD=0)
     std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
-                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w >= 0 ? "+w" : "");
+                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w ? "+w" : "");
     auto it = tune_cache_.find(key);
     if (it == tune_cache_.end()) {
+      timed_any = true;
       int best = l.variant;
       float best_ms = 1e30f;
       for (int v = 0; v < conv_num_variants(); ++v) {
@@ -1411,7 +1563,7 @@ void Net::autotune() {
         }
         if (ms < best_ms) best_ms = ms, best = v;
       }
-      if (l.wino_w >= 0) {  // the Winograd form of this layer competes with the best direct tile
+      if (l.wino_w) {  // the Winograd form of this layer competes with the best direct tile
         Launch trial = l;
         trial.variant = kWinoVariant;
         run_launch(trial, stream);
@@ -1430,7 +1582,7 @@ void Net::autotune() {
       it = tune_cache_.emplace(key, best).first;
     }
     // a cache line naming the Winograd form while it is switched off (or not eligible any more): keep the cost model's tile
-    if (!(it->second == kWinoVariant && l.wino_w < 0)) l.variant = it->second;
+    if (!(it->second == kWinoVariant && !l.wino_w)) l.variant = it->second;
     if (l.variant == kWinoVariant) {
       l.kernel = "wino_f23<4x8x16>";
       l.grid = wino_grid(l.cg);
@@ -1441,6 +1593,7 @@ void Net::autotune() {
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (timed_any) ++stats.autotune_runs;
   if (cache_path && tune_cache_.size() != cached_before) {
     if (FILE* f = std::fopen(cache_path, "w")) {
       for (auto& kv : tune_cache_)
@@ -1511,12 +1664,12 @@ void Net::run_launch(const Launch& l, void* s) {
       g.x = X.dev;
       g.y = Y.dev_at(l.y_off);
       g.resid = l.in2 >= 0 ? storages[l.in2]->dev_at(l.y_off) : nullptr;
-      g.w = vecs[l.w]->dev;
-      g.scale = l.scale >= 0 ? vecs[l.scale]->dev : nullptr;
-      g.shift = l.shift >= 0 ? vecs[l.shift]->dev : nullptr;
+      g.w = l.w->dev;
+      g.scale = l.scale ? l.scale->dev : nullptr;
+      g.shift = l.shift ? l.shift->dev : nullptr;
       if (l.variant == kWinoVariant) {  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
-        if (l.wino_w < 0) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
-        g.w = vecs[l.wino_w]->dev;
+        if (!l.wino_w) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
+        g.w = l.wino_w->dev;
         KCHECK(launch_wino_conv(g, s));
         break;
       }
@@ -1572,8 +1725,8 @@ void Net::run_launch(const Launch& l, void* s) {
       KCHECK(launch_maxpool(X.dev, Y.dev, X.esize, X.dim(0), X.dim(2), X.dim(3), X.cp(), Y.dim(2), Y.dim(3), l.pk, l.ps, l.pp, s));
       break;
     case Launch::ELT:
-      KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale >= 0 ? vecs[l.scale]->dev : nullptr,
-                            l.shift >= 0 ? vecs[l.shift]->dev : nullptr, Y.dev, Y.esize, (long)Y.dev_count(), Y.cp(), l.relu,
+      KCHECK(launch_eltwise(X.dev, l.in2 >= 0 ? storages[l.in2]->dev : nullptr, l.scale ? l.scale->dev : nullptr,
+                            l.shift ? l.shift->dev : nullptr, Y.dev, Y.esize, (long)Y.dev_count(), Y.cp(), l.relu,
                             l.sigmoid, s));
       break;
     case Launch::CROP:
@@ -1613,16 +1766,11 @@ void Net::forward(int start, int end) {
   if (Context::get().mode != DC_MODE_GPU)
     throw DcError(DC_ENOCPU, "forward() in CPU mode: libdeepcut_hip provides the MI355X path only — call set_mode_gpu() "
                              "(the CPU restatement of the reference is test infrastructure under oracle/)");
-  reshape();
-  std::vector<int> sig;
-  for (int bi : inputs)
-    for (int d : blobs[bi]->st->shape) sig.push_back(d);
-  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();
+  ensure_plan();
   ensure_device();
   upload_vecs();
   bool grew;
   prepare_buffers(*this, grew);
-  if (grew) release_graph();
   if (!tuned) autotune();
   // inputs of the executed range whose host copy is authoritative go up first (SyncedMemory::to_gpu)
   for (auto& l : plan) {
@@ -1643,6 +1791,7 @@ void Net::forward(int start, int end) {
   }
   const bool whole = start <= 0 && end >= (int)layers.size() - 1;
   if (use_graph && whole) {
+    if (graph_exec && graph_buf_gen != buf_gen_) release_graph();  // a buffer it addresses was reallocated since
     if (!graph_exec) {
       hipGraph_t graph;
       HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
@@ -1658,6 +1807,8 @@ void Net::forward(int start, int end) {
       HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
       graph_exec = ge;
+      graph_buf_gen = buf_gen_;
+      ++stats.graph_instantiations;
     }
     HIPCHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
   } else {
@@ -1679,14 +1830,11 @@ Storage& Net::begin_batch(int n, int h, int w) {
   Storage& in = *blobs[inputs[0]]->st;
   int C = in.dim(1);
   in.reshape({n, C, h, w});
-  reshape();
-  std::vector<int> sig = in.shape;
-  if (!plan_valid || weights_dirty || sig != plan_input_shape) build_plan();
+  ensure_plan();
   ensure_device();
   upload_vecs();
   bool grew;
   prepare_buffers(*this, grew);
-  if (grew) release_graph();
   if (!tuned) autotune();
   return in;
 }
@@ -1697,6 +1845,7 @@ void Net::enqueue_plan(void* s) {
   if (use_graph) {
     // the launch sequence is captured once on the net's own stream and replayed on whichever stream
     // the caller works on (a graph is not tied to its capture stream)
+    if (graph_exec && graph_buf_gen != buf_gen_) release_graph();  // a buffer it addresses was reallocated since
     if (!graph_exec) {
       hipGraph_t graph;
       HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
@@ -1712,6 +1861,8 @@ void Net::enqueue_plan(void* s) {
       HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
       graph_exec = ge;
+      graph_buf_gen = buf_gen_;
+      ++stats.graph_instantiations;
     }
     HIPCHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)s));
   } else {
@@ -2040,10 +2191,7 @@ void Net::decode_pairwise(double scale, int ndet, const int* det, const double* 
 }
 
 std::string Net::plan_text() {
-  if (!plan_valid) {
-    reshape();
-    build_plan();
-  }
+  ensure_plan();
   std::ostringstream os;
   os << "# plan for input";
   for (int d : plan_input_shape) os << " " << d;

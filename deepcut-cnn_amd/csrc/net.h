@@ -11,9 +11,11 @@
 // deconvolution is one launch (4 for a stride-2 deconvolution: one per output parity class) of the
 // gather-GEMM MFMA kernel in kernels.hip.
 #pragma once
+#include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,6 +36,7 @@ int device_count();  // 0 without a GPU; never throws
 enum Head { UNINITIALIZED = 0, HEAD_AT_CPU = 1, HEAD_AT_GPU = 2, SYNCED = 3 };
 
 struct Net;
+struct ModelShared;
 struct Storage {
   std::vector<int> shape;  // logical Caffe shape (N,C,H,W for activations)
   float* host = nullptr;
@@ -50,7 +53,9 @@ struct Storage {
   bool elided = false;  // absorbed by fusion in the current plan: never materialised
   int view_of = -1;     // >= 0: this blob is channels [view_c0, view_c0+C) of storage `view_of` (merged heads)
   int view_c0 = 0, view_cp = 0;
-  Net* owner = nullptr;  // params: owning net (marks packed weights stale on mutable access)
+  Net* owner = nullptr;  // activations: the net whose stream moves this blob between host and device (null: stand-alone blob)
+  std::shared_ptr<ModelShared> shared;  // params: the model state a net and its clones own jointly (outlives any one of them)
+  uint64_t packed_hash = 0;  // params: content hash when the filter images were last packed (see ModelShared::touched)
   int id = -1;
 
   ~Storage();
@@ -102,6 +107,21 @@ struct DevVec {  // a packed filter / affine vector; shared between a Net and it
   ~DevVec();
 };
 
+// What a Net and its clones own JOINTLY (shared_ptr): the packed filter / affine images in HBM, the tile choices measured
+// on the device, and the generation counter of the parameters.  Parameter blobs point here (not at a Net), so a blob
+// obtained through one executor stays safe to touch after that executor is gone, and a parameter write reaches every
+// executor: each compares `weights_gen` with the generation its plans were lowered from before it runs.
+struct ModelShared {
+  std::mutex mu;
+  std::map<std::string, std::shared_ptr<DevVec>> vec_by_key;  // packed-weight cache (plans hold the images they use alive)
+  uint64_t weights_gen = 1;   // bumped when parameter CONTENT changed (copy_from, a write through params that changed bytes)
+  uint64_t packed_gen = 0;    // generation vec_by_key was packed from
+  std::vector<std::weak_ptr<Storage>> touched;  // params handed out writable since the last check (Blob.data is always mutable
+                                                // in pycaffe, _caffe.cpp:273: a read must not cost a 263 MB re-pack)
+  std::map<std::string, int> tune_cache;        // GEMM signature -> fastest variant, one timing per process and model
+  bool tune_file_loaded = false;
+};
+
 struct ResampleTable {  // Pillow-style 8-bit bilinear resample of one axis: taps and 22-bit weights, on the device
   int ksize = 0;
   std::vector<int> bounds;  // host copy of [out][2] (first tap, tap count)
@@ -126,8 +146,8 @@ struct Launch {
   // CONV
   ConvGemmParams cg{};  // pointers filled at launch time
   int variant = 0;
-  int w = -1, scale = -1, shift = -1;  // DevVec ids
-  int wino_w = -1;                     // DevVec id of the Winograd-transformed filters (eligible 3x3 layers), else -1
+  std::shared_ptr<DevVec> w, scale, shift;  // packed filters / folded affine (kept alive by the plan)
+  std::shared_ptr<DevVec> wino_w;           // Winograd-transformed filters (eligible 3x3 layers), else null
   long y_off = 0;                      // element offset of this launch's first output (deconvolution classes)
   double flops = 0;                    // algorithmic 2*MAC
   long grid = 0;
@@ -137,6 +157,31 @@ struct Launch {
   int relu = 0, sigmoid = 0;
   // CROP
   int oh = 0, ow = 0;
+};
+
+// Everything that depends on the INPUT SHAPE: the lowered launches, which storages are views / elided, the captured
+// hipGraph.  A Net keeps one per shape it has met (LRU): Layer::Forward re-derives shapes on every call
+// (layer.hpp:451-456) and the demo's scale loop changes the shape on every iteration (estimate_pose.py:81-128), so a
+// 4-scale pyramid must not re-lower 734 layers and re-instantiate a 160-node graph four times per image.
+struct PlanState {
+  std::vector<int> input_shape;
+  std::vector<Launch> plan;
+  double flops = 0;
+  std::vector<int> views;  // storages that are channel views in this plan
+  struct StorageState {
+    int id, view_of, view_c0;
+    bool elided;
+  };
+  std::vector<StorageState> sstate;                       // per-storage fusion state to restore on activation
+  std::vector<std::pair<int, std::vector<int>>> aux_shapes;  // tensors created by the lowering (merged heads)
+  void* graph_exec = nullptr;
+  uint64_t graph_buf_gen = 0;  // Net::buf_gen_ when the graph was captured (a reallocated buffer makes it stale)
+  bool tuned = false;
+  uint64_t last_use = 0;
+};
+
+struct NetStats {  // dc_net_stats
+  long long lowerings = 0, graph_instantiations = 0, plan_hits = 0, autotune_runs = 0, buffer_growths = 0, repacks = 0;
 };
 
 struct Net {
@@ -151,27 +196,31 @@ struct Net {
   int fuse = 2;
   int dtype = 0;  // 0: float activations/filters; 1: _Float16 activations/filters, fp32 accumulate + epilogue
   int use_graph = 0;
-  bool weights_dirty = true;
+  std::shared_ptr<ModelShared> shared;   // joint with every clone
+  uint64_t seen_weights_gen = 0;         // generation the cached plans were lowered from
+  // the ACTIVE plan (the fields below are swapped with a parked PlanState when the input shape changes)
   bool plan_valid = false;
   std::vector<int> plan_input_shape;
   std::vector<Launch> plan;
-  std::vector<std::shared_ptr<DevVec>> vecs;
-  std::map<std::string, int> vec_keys_;  // packed-weight cache: key -> index in vecs
-  std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
   std::vector<int> plan_views_;          // storages that are channel views in the current plan
   double plan_flops = 0;
+  void* graph_exec = nullptr;
+  uint64_t graph_buf_gen = 0;
+  bool tuned = false;                    // tile variants of the current plan were timed on the device
+  std::vector<std::unique_ptr<PlanState>> parked_;  // plans of the other shapes met so far (LRU, DC_PLAN_CACHE entries)
+  uint64_t use_clock_ = 0, cur_last_use_ = 0;
+  uint64_t buf_gen_ = 1;                 // bumped whenever a device buffer of this net is reallocated
+  NetStats stats;
+  std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
   void* stream = nullptr;
   int device = -1;
-  void* graph_exec = nullptr;
   double* pose_dev = nullptr;
   size_t pose_cap = 0;
-  bool tuned = false;                       // tile variants of the current plan were timed on the device
-  std::map<std::string, int> tune_cache_;   // GEMM signature -> fastest variant (per process)
   std::string text_buf;
   std::string proto_text;  // kept for clone()
 
   ~Net();
-  static Net* create(const std::string& prototxt_text, int phase);
+  static Net* create(const std::string& prototxt_text, int phase, const Net* clone_of = nullptr);
   Net* clone();           // same graph and input shape, SHARED parameters and packed device weights
   void synchronize();     // wait for everything enqueued on the net's own stream
   void set_dtype(int d);  // 0 float32 / 1 float16 device images (DC_OPT_DTYPE)
@@ -179,6 +228,10 @@ struct Net {
   void save(const std::string& path);
   void reshape();         // propagate input shapes through every layer (Net::Reshape)
   void build_plan();      // lower to launches for the current shapes (host only; no device needed)
+  void ensure_plan();     // make the plan of the current input shape the active one: cache hit, or build_plan()
+  void invalidate_plans();  // drop every cached plan and graph (option / weight change)
+  void mark_weights_changed();  // parameter content changed: every executor re-packs and re-lowers before its next run
+  void reserve(int n, int h, int w);  // lower + allocate + tune for a shape without running it
   void forward(int start, int end);
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
                      float* next, void* user_stream);
@@ -203,7 +256,10 @@ struct Net {
   void upload_vecs();
   void run_launch(const Launch& l, void* s);
   void run_plan(int start, int end, void* s);
+  const Net* clone_src_ = nullptr;  // during create() of a clone only
   void release_graph();
+  void check_weights();   // compare the shared weight generation / touched parameters with what the plans were built from
+  void park_current();
   void autotune();
   Storage& begin_batch(int n, int h, int w);
   void enqueue_plan(void* s);

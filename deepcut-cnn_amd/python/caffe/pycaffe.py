@@ -96,6 +96,9 @@ def _load():
         "dc_net_num_launches": (ci, [vp]),
         "dc_net_plan_text": (cp, [vp]),
         "dc_net_profile_text": (cp, [vp, ci]),
+        "dc_net_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
+        "dc_net_reserve": (ci, [vp, ci, ci, ci]),
+        "dc_net_device": (ci, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -438,6 +441,25 @@ class Net(object):
 
     def synchronize(self):
         _check(_lib.dc_net_synchronize(self._h))
+
+    STAT_NAMES = ("lowerings", "graph_instantiations", "plan_hits", "autotune_runs", "buffer_growths", "repacks",
+                  "cached_plans")
+
+    def stats(self):
+        """Counters of the per-shape plan cache (dc_net_stats): dict name -> int."""
+        v = (C.c_longlong * len(self.STAT_NAMES))()
+        _check(_lib.dc_net_stats(self._h, v, len(self.STAT_NAMES)))
+        return dict(zip(self.STAT_NAMES, [int(x) for x in v]))
+
+    def reserve(self, n, h, w):
+        """Lower, allocate and tune the plan of an [n,3,h,w] input without running it (largest shape of a pyramid first:
+        nothing grows afterwards, so no captured graph goes stale)."""
+        _check(_lib.dc_net_reserve(self._h, int(n), int(h), int(w)))
+
+    @property
+    def device(self):
+        """HIP device this net executes on (-1 before its first device use)."""
+        return _lib.dc_net_device(self._h)
 
     def flops(self):
         v = C.c_double()

@@ -204,6 +204,23 @@ int dc_net_decode_pairwise(dc_net* net, double scale, int ndet, const int* detec
 int dc_net_flops(dc_net* net, double* flops);
 /* number of kernel launches in the current plan                                           */
 int dc_net_num_launches(dc_net* net);
+/* counters of the per-shape plan cache: Layer::Forward re-derives every shape on every call (layer.hpp:451-456) and the
+ * demo changes the input shape once per scale (estimate_pose.py:81-128); a shape met before must cost neither a
+ * re-lowering nor a graph instantiation.  out[i] for i < n:                                                     */
+#define DC_STAT_LOWERINGS 0        /* times the layer graph was lowered to a launch plan                  */
+#define DC_STAT_GRAPH_INSTANTIATIONS 1 /* hipGraph captures + instantiations                              */
+#define DC_STAT_PLAN_HITS 2        /* shape changes served from the cache                                 */
+#define DC_STAT_AUTOTUNE_RUNS 3    /* plans for which at least one GEMM signature had to be timed         */
+#define DC_STAT_BUFFER_GROWTHS 4   /* device buffers (re)allocated                                        */
+#define DC_STAT_REPACKS 5          /* times the filter images were re-packed from the parameter blobs     */
+#define DC_STAT_CACHED_PLANS 6     /* shapes currently cached (LRU of DC_PLAN_CACHE, default 16)          */
+#define DC_NUM_STATS 7
+int dc_net_stats(dc_net* net, long long* out, int n);
+/* lower, allocate and tune the plan of an [n,3,h,w] input without running it: reserving the LARGEST shape of a
+ * pyramid first means no buffer grows (and no captured graph goes stale) while the smaller ones are met        */
+int dc_net_reserve(dc_net* net, int n, int h, int w);
+/* the HIP device this net executes on (-1 until its first device use: then Caffe::SetDevice's value, common.cpp:140) */
+int dc_net_device(dc_net* net);
 /* human-readable launch plan of the current shape (kernel variant, tile, grid per op);
  * pointer valid until the next call on this net                                           */
 const char* dc_net_plan_text(dc_net* net);

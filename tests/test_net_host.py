@@ -272,3 +272,87 @@ def test_fp16_lowering_on_the_host():
     assert "dtype=f32" in net.plan_text() and "K=224 taps=7" in net.plan_text()
     with pytest.raises(caffe.DeepcutError):
         net.set_option(3, 7)
+
+
+def test_plan_cache_serves_shapes_met_before_without_relowering():
+    # Layer::Forward re-derives shapes on every call (layer.hpp:451-456); the demo changes the shape once per scale
+    # (estimate_pose.py:81-128): the four pyramid shapes are lowered once each, then served from the cache
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    shapes = [(1, 3, 272, 368), (1, 3, 408, 552), (1, 3, 544, 736), (1, 3, 680, 920)]
+    texts = {}
+    for s in shapes:
+        net.blobs["data"].reshape(*s)
+        texts[s] = net.plan_text()
+    st = net.stats()
+    assert st["lowerings"] == 4 and st["cached_plans"] == 4 and st["plan_hits"] == 0
+    for _ in range(3):
+        for s in shapes:
+            net.blobs["data"].reshape(*s)
+            assert net.plan_text() == texts[s]
+            assert abs(net.flops() - float(texts[s].split(" launches, ")[1].split(" GFLOP")[0]) * 1e9) < 1e6 * net.flops() / 1e9
+    st = net.stats()
+    assert st["lowerings"] == 4 and st["plan_hits"] == 12 and st["repacks"] == 1
+    # the views / elided blobs of a plan are restored with it
+    net.blobs["data"].reshape(1, 3, 272, 368)
+    net.plan_text()
+    assert net.blobs["prob"].shape == (1, 14, 34, 46)
+    # an option that changes the lowering drops every cached plan
+    net.set_option(1, 0)
+    assert len([l for l in net.plan_text().splitlines() if not l.startswith("#")]) > 161
+    assert net.stats()["cached_plans"] == 1
+
+
+def test_plan_cache_is_bounded_lru(monkeypatch):
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    for k in range(20):
+        net.blobs["data"].reshape(1, 3, 64 + 8 * k, 64)
+        net.plan_text()
+    assert net.stats()["cached_plans"] == 17  # the active plan + DC_PLAN_CACHE (16) parked ones
+    net.blobs["data"].reshape(1, 3, 64 + 8 * 19, 64)
+    net.plan_text()
+    net.blobs["data"].reshape(1, 3, 64 + 8 * 18, 64)
+    net.plan_text()
+    assert net.stats()["lowerings"] == 20  # the two most recent shapes were still cached
+    net.blobs["data"].reshape(1, 3, 64, 64)  # the oldest was evicted
+    net.plan_text()
+    assert net.stats()["lowerings"] == 21
+
+
+def test_reading_a_parameter_does_not_repack_but_writing_does():
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    net.plan_text()
+    assert net.stats()["repacks"] == 1
+    _ = net.params["conv1"][0].data.shape  # pycaffe's .data is mutable_cpu_data: an access alone must not cost a re-pack
+    _ = [l.blobs for l in net.layers]
+    float(net.params["bn_conv1"][0].data.sum())
+    net.plan_text()
+    assert net.stats()["repacks"] == 1 and net.stats()["lowerings"] == 1
+    net.params["conv1"][0].data[0, 0, 0, 0] = 3.0  # a content change
+    net.plan_text()
+    assert net.stats()["repacks"] == 2 and net.stats()["lowerings"] == 2
+    net.params["conv1"][0].data[0, 0, 0, 0] = 3.0  # same bytes again
+    net.plan_text()
+    assert net.stats()["repacks"] == 2
+
+
+def test_parameter_write_reaches_every_executor_and_survives_the_parent():
+    import gc
+
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    c = net.clone()
+    net.plan_text()
+    c.plan_text()
+    assert c.stats()["lowerings"] == 1 and c.stats()["repacks"] == 0  # the clone found the images its parent packed
+    net.params["conv1"][0].data[...] = 0.25  # written through the PARENT ...
+    c.plan_text()                            # ... the clone re-lowers from the new generation
+    assert c.stats()["lowerings"] == 2 and c.stats()["repacks"] == 1
+    net.plan_text()
+    assert net.stats()["lowerings"] == 2 and net.stats()["repacks"] == 1  # packed once for both
+    w = c.params["conv1"][0]
+    del net
+    gc.collect()
+    w.data[...] = 0.5  # the blob's model state is owned jointly: no dangling owner after the parent is gone
+    c.plan_text()
+    assert c.stats()["lowerings"] == 3
+    c2 = c.clone()
+    assert (c2.params["conv1"][0].data == 0.5).all()
