@@ -16,6 +16,21 @@ constexpr int kMaxTaps = 32;  // tap-validity masks are one 32-bit word per stag
 // Covers every Convolution of the path (1x1, 1x1 stride 2, 3x3, dilated 3x3, the 7x7 stem seen as
 // 7 row-taps of 8 NHWC4 pixels) and, per output-parity class, the stride-2 Deconvolution heads.
 // The tap grid is arithmetic so the kernel advances it with scalar adds (no table loads in the K loop).
+constexpr int kMaxClasses = 4;
+// One output-residue class of a strided Deconvolution inside a MULTI-CLASS launch: the classes of a stride-s transposed
+// convolution are s*s ordinary gather-GEMMs over the same input that differ only in tap grid, K, filter image and the
+// interleaved output pixels they own, so they run as ONE launch (class = a range of the grid, heaviest class first so
+// that its workgroups start first).  Fields mean what the same-named ConvGemmParams fields mean.
+struct ConvClass {
+  int nty, ntx, dy0, ddy, x0, ddx, Ktot, x_bias;
+  int OH, OW, M;
+  int blk0;             // first workgroup of the class (filled by launch_conv_gemm)
+  unsigned div_ohw[2];  // (filled by launch_conv_gemm)
+  unsigned div_ow[2];
+  long w_off;           // element offset of the class's filter image inside `w`
+  long y_off;           // element offset of the class's first output inside `y` (and `resid`)
+};
+
 struct ConvGemmParams {
   int esize;          // bytes per activation / filter element: 4 (float) or 2 (_Float16); strides are in elements
   const void* x;
@@ -51,6 +66,10 @@ struct ConvGemmParams {
   unsigned div_tn[2];      // ... for block / tiles_n (linear map)
   int tiles_n;
   long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
+  // --- multi-class launches (the stride-2 deconvolution heads): ncls > 1 and cls[0..ncls) replace the single-problem
+  //     fields nty..x_bias / Ktot / OH / OW / M above; sy, sx, klen, strides, Cout, epilogue are common to all classes
+  int ncls;
+  ConvClass cls[kMaxClasses];
 };
 
 // Tile variants of conv_gemm.  BM x BN output tile per 256-thread workgroup, 4 waves arranged
@@ -64,6 +83,7 @@ const ConvVariant& conv_variant(int i);
 // workgroups this variant launches for the problem
 int conv_variant_bk(int i);
 int conv_variant_esize(int i);
+bool conv_variant_multiclass(int i);  // has a multi-class instantiation (ConvGemmParams::ncls > 1)
 long conv_grid(const ConvGemmParams& p, int variant);
 // returns hipError_t as int
 int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream);

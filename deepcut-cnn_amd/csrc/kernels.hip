@@ -73,7 +73,8 @@ struct Elem<_Float16> {
   }
 };
 
-template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF>
+// MC: multi-class launch (ConvGemmParams::ncls > 1): the class-dependent scalars come from p.cls[class of this block].
+template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false>
 __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int ES = sizeof(T);          // bytes per element
   constexpr int VEC = 16 / ES;           // elements per 16-byte vector
@@ -117,8 +118,26 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // tile grid is cut into 8 rectangles (gx x gy chosen on the host to minimise filters*gy + pixels*gx)
   // and XCD q walks rectangle q, so an L2 only fetches its rectangle's share of both operands.
   // Correctness does not depend on the placement (it is only a locality hint).
+  // class-dependent scalars (uniform: SGPRs).  Single-problem launches read them from the parameter block itself.
+  int c_Ktot = p.Ktot, c_nty = p.nty, c_ntx = p.ntx, c_dy0 = p.dy0, c_ddy = p.ddy, c_x0 = p.x0, c_ddx = p.ddx, c_xbias = p.x_bias;
+  int c_OH = p.OH, c_OW = p.OW, c_M = p.M;
+  unsigned c_dohw[2] = {p.div_ohw[0], p.div_ohw[1]}, c_dow[2] = {p.div_ow[0], p.div_ow[1]};
+  long c_woff = 0, c_yoff = 0;
   int tile_n, tile_m;
-  if (p.xcd_on) {
+  if constexpr (MC) {
+    int c = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxClasses; ++k)
+      if (k < p.ncls && (int)blockIdx.x >= p.cls[k].blk0) c = k;
+    const ConvClass& q = p.cls[c];
+    c_Ktot = q.Ktot, c_nty = q.nty, c_ntx = q.ntx, c_dy0 = q.dy0, c_ddy = q.ddy, c_x0 = q.x0, c_ddx = q.ddx, c_xbias = q.x_bias;
+    c_OH = q.OH, c_OW = q.OW, c_M = q.M;
+    c_dohw[0] = q.div_ohw[0], c_dohw[1] = q.div_ohw[1], c_dow[0] = q.div_ow[0], c_dow[1] = q.div_ow[1];
+    c_woff = q.w_off, c_yoff = q.y_off;
+    const int local = (int)blockIdx.x - q.blk0;  // n-fastest inside the class: neighbours share the pixel rows
+    tile_m = dc_fastdiv(local, p.div_tn);
+    tile_n = local - tile_m * p.tiles_n;
+  } else if (p.xcd_on) {
     const int q = blockIdx.x & 7, slot = blockIdx.x >> 3;  // XCD, position inside its rectangle
     const int n_lo = p.xcd_rect[q][0], rw = p.xcd_rect[q][1], m_lo = p.xcd_rect[q][2], rh = p.xcd_rect[q][3];
     if (slot >= rw * rh) return;  // grid is padded to 8 x the largest rectangle
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
-  const int T_ = p.Ktot / BK;
+  const int T_ = c_Ktot / BK;
   auto stamp = [&](int slot) {
     if (p.dbg && lane == 0) {
       long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
@@ -149,9 +168,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
   for (int j = 0; j < NBV; ++j) {
     const int n = n0 + lrow + RPP * j;
-    bvoff[j] = n < p.Cout ? (unsigned)(n * p.Ktot + lce) * ES : kOOB;  // rows past Cout read as zeros
+    bvoff[j] = n < p.Cout ? (unsigned)(n * c_Ktot + lce) * ES : kOOB;  // rows past Cout read as zeros
   }
-  const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(p.w, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(reinterpret_cast<const T*>(p.w) + c_woff, 0x7fffffffu);
   f32x4 ra[PF][NA], rb[PF][NBV];  // 16-byte containers (4 floats or 8 halves)
   int kg = 0;
   auto gload_b = [&](int slot) {
@@ -178,11 +197,11 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   if (t < BM) {
     const int m = m0 + t;
     i32x4 ri = {(int)kOOB, -(1 << 28), 0, -1};
-    if (m < p.M) {
-      const int n = dc_fastdiv(m, p.div_ohw);
-      const int rem = m - n * (p.OH * p.OW);
-      const int oy = dc_fastdiv(rem, p.div_ow);
-      const int ox = rem - oy * p.OW;
+    if (m < c_M) {
+      const int n = dc_fastdiv(m, c_dohw);
+      const int rem = m - n * (c_OH * c_OW);
+      const int oy = dc_fastdiv(rem, c_dow);
+      const int ox = rem - oy * c_OW;
       ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES);
       ri.y = oy * p.sy;
       ri.z = ox * p.sx;
@@ -200,18 +219,18 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     const i32x4 ri = rowinfo[lrow + RPP * i];
     avoff[i] = (unsigned)ri.x + lcb;
     unsigned colmask = 0, mk = 0;  // validity of a tap = (row tap valid) x (column tap valid)
-    for (int tx = 0; tx < p.ntx; ++tx)
-      colmask |= ((unsigned)(ri.z + lce + p.x0 + tx * p.ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
-    for (int ty = 0; ty < p.nty; ++ty)
-      if ((unsigned)(ri.y + p.dy0 + ty * p.ddy) < (unsigned)p.x_rows) mk |= colmask << (ty * p.ntx);
+    for (int tx = 0; tx < c_ntx; ++tx)
+      colmask |= ((unsigned)(ri.z + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
+    for (int ty = 0; ty < c_nty; ++ty)
+      if ((unsigned)(ri.y + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows) mk |= colmask << (ty * c_ntx);
     amask[i] = mk;
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
   // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
-  const __amdgpu_buffer_rsrc_t xr = dc_rsrc(px + p.x_bias, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t xr = dc_rsrc(px + c_xbias, 0x7fffffffu);
   // tap cursor, all uniform (SALU): (tx, c0, running bit) and the element displacement of the current tap
   int tx = 0, c0 = 0, tbit = 0;
-  int row_soff = p.dy0 * p.x_row_stride + p.x0 - p.x_bias;  // displacement of tap (ty, 0)
+  int row_soff = c_dy0 * p.x_row_stride + c_x0 - c_xbias;  // displacement of tap (ty, 0)
   int tap_soff = row_soff;
   auto gload_a = [&](int slot) {
     const unsigned soff = (unsigned)(tap_soff + c0) * ES;
@@ -223,10 +242,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       c0 = 0;
       ++tbit;
       ++tx;
-      tap_soff += p.ddx;
-      if (tx >= p.ntx) {
+      tap_soff += c_ddx;
+      if (tx >= c_ntx) {
         tx = 0;
-        row_soff += p.ddy * p.x_row_stride;
+        row_soff += c_ddy * p.x_row_stride;
         tap_soff = row_soff;
       }
     }
@@ -239,8 +258,8 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // (5) output addressing of the rows this wave will finalise, and (small tiles) the shortcut itself.
   //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
   //     With in-workgroup split-K every one of the WK waves finalises RPW of the 16 accumulator registers.
-  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(p.y, 0x7fffffffu);
-  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(p.resid ? p.resid : p.y, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(reinterpret_cast<T*>(p.y) + c_yoff, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(reinterpret_cast<const T*>(p.resid ? p.resid : p.y) + c_yoff, 0x7fffffffu);
   float rs[EARLY_RESID ? FM * FN * RPW : 1];
   if (EARLY_RESID && p.resid) {
 #pragma unroll
@@ -448,47 +467,60 @@ struct VariantEntry {
   void (*kernel)(const ConvGemmParams);
   int BK;
   int esize;
+  void (*kernel_mc)(const ConvGemmParams);  // multi-class instantiation (the deconvolution heads), or null
 };
 #define DC_VARIANT(BM, BN, BK, WR, WC, WK, PF)                                     \
   {                                                                                \
     {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
-        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4                 \
+        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4, nullptr        \
+  }
+#define DC_VARIANT_MC(BM, BN, BK, WR, WC, WK, PF)                                  \
+  {                                                                                \
+    {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
+        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4,                \
+        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF, true>                  \
   }
 #define DC_VARIANT_H(BM, BN, BK, WR, WC, WK, PF)                                   \
   {                                                                                \
     {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},         \
-        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2              \
+        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2, nullptr     \
+  }
+#define DC_VARIANT_H_MC(BM, BN, BK, WR, WC, WK, PF)                                \
+  {                                                                                \
+    {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},         \
+        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2,             \
+        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF, true>               \
   }
 const VariantEntry kVariants[] = {
     DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
     DC_VARIANT(128, 64, 32, 2, 2, 1, 2),   // 1
     DC_VARIANT(64, 128, 32, 2, 2, 1, 2),   // 2
-    DC_VARIANT(64, 64, 32, 2, 2, 1, 3),    // 3
-    DC_VARIANT(64, 64, 64, 2, 2, 1, 3),    // 4
-    DC_VARIANT(32, 64, 64, 1, 2, 2, 4),    // 5: in-workgroup split-K 2
+    DC_VARIANT_MC(64, 64, 32, 2, 2, 1, 3), // 3
+    DC_VARIANT_MC(64, 64, 64, 2, 2, 1, 3), // 4
+    DC_VARIANT_MC(32, 64, 64, 1, 2, 2, 4), // 5: in-workgroup split-K 2
     DC_VARIANT(64, 32, 64, 2, 1, 2, 4),    // 6
-    DC_VARIANT(32, 32, 128, 1, 1, 4, 3),   // 7: split-K 4 (tiny M*N, long K: res4/res5)
-    DC_VARIANT(32, 32, 64, 1, 1, 4, 4),    // 8: same for K segments that are only multiples of 64
+    DC_VARIANT_MC(32, 32, 128, 1, 1, 4, 3), // 7: split-K 4 (tiny M*N, long K: res4/res5)
+    DC_VARIANT_MC(32, 32, 64, 1, 1, 4, 4), // 8: same for K segments that are only multiples of 64
     DC_VARIANT(32, 64, 32, 1, 2, 2, 4),    // 9: K segments that are only multiples of 32 (the stem)
     // 8-wave workgroups: two waves per SIMD, so one wave's LDS/global/SALU work hides under the other's MFMAs
-    DC_VARIANT(32, 64, 64, 1, 2, 4, 4),    // 10
-    DC_VARIANT(64, 64, 64, 2, 2, 2, 3),    // 11
+    DC_VARIANT_MC(32, 64, 64, 1, 2, 4, 4), // 10
+    DC_VARIANT_MC(64, 64, 64, 2, 2, 2, 3), // 11
     DC_VARIANT(128, 64, 32, 2, 2, 2, 2),   // 12
     DC_VARIANT(128, 128, 32, 2, 2, 2, 2),  // 13
     DC_VARIANT(64, 64, 32, 2, 2, 2, 3),    // 14
-    DC_VARIANT(32, 32, 128, 1, 1, 8, 3),   // 15
+    DC_VARIANT_MC(32, 32, 128, 1, 1, 8, 3), // 15
     DC_VARIANT(64, 128, 32, 2, 2, 2, 2),   // 16
     // fp16 operands (v_mfma_f32_32x32x16_f16, fp32 accumulate); BK in halves: 64 = one 128-B line per row
     DC_VARIANT_H(128, 128, 64, 2, 2, 1, 2),   // 17
     DC_VARIANT_H(128, 64, 64, 2, 2, 1, 2),    // 18
     DC_VARIANT_H(64, 128, 64, 2, 2, 1, 2),    // 19
-    DC_VARIANT_H(64, 64, 64, 2, 2, 1, 3),     // 20
-    DC_VARIANT_H(64, 64, 128, 2, 2, 2, 2),    // 21: 8 waves
-    DC_VARIANT_H(32, 64, 128, 1, 2, 2, 3),    // 22
+    DC_VARIANT_H_MC(64, 64, 64, 2, 2, 1, 3),  // 20
+    DC_VARIANT_H_MC(64, 64, 128, 2, 2, 2, 2), // 21: 8 waves
+    DC_VARIANT_H_MC(32, 64, 128, 1, 2, 2, 3), // 22
     DC_VARIANT_H(64, 32, 128, 2, 1, 2, 3),    // 23
-    DC_VARIANT_H(32, 64, 256, 1, 2, 4, 2),    // 24: 8 waves, split-K 4
+    DC_VARIANT_H_MC(32, 64, 256, 1, 2, 4, 2), // 24: 8 waves, split-K 4
     DC_VARIANT_H(128, 128, 128, 2, 2, 2, 2),  // 25: 8 waves
-    DC_VARIANT_H(32, 32, 256, 1, 1, 4, 2),    // 26
+    DC_VARIANT_H_MC(32, 32, 256, 1, 1, 4, 2), // 26
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -497,10 +529,17 @@ int conv_num_variants() { return kNumVariants; }
 const ConvVariant& conv_variant(int i) { return kVariants[i].v; }
 int conv_variant_bk(int i) { return kVariants[i].BK; }
 int conv_variant_esize(int i) { return kVariants[i].esize; }
+bool conv_variant_multiclass(int i) { return kVariants[i].kernel_mc != nullptr; }
 
 long conv_grid(const ConvGemmParams& p, int variant) {
   const ConvVariant& v = kVariants[variant].v;
-  long tm = (p.M + v.BM - 1) / v.BM, tn = (p.Cout + v.BN - 1) / v.BN;
+  const long tn = (p.Cout + v.BN - 1) / v.BN;
+  if (p.ncls > 1) {
+    long g = 0;
+    for (int c = 0; c < p.ncls; ++c) g += (p.cls[c].M + v.BM - 1) / v.BM * tn;
+    return g;
+  }
+  long tm = (p.M + v.BM - 1) / v.BM;
   return tm * tn;
 }
 
@@ -509,6 +548,51 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   const VariantEntry& e = kVariants[variant];
   ConvGemmParams p = p_in;
   if (p.esize != e.esize) return (int)hipErrorInvalidValue;
+  // n / d magic: sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1, n/d = (n*mul) >> sh for 0 <= n < 2^31
+  auto magic_of = [](unsigned d, unsigned (&mg)[2]) {
+    if (d <= 1) {
+      mg[0] = 0;
+      mg[1] = 0x80000000u;
+      return;
+    }
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    const int sh = 31 + l;
+    const unsigned long long q = (((unsigned __int128)1) << sh) / d;
+    mg[0] = (unsigned)(q + 1);
+    mg[1] = (unsigned)(sh - 32);
+  };
+  if (p.ncls > 1) {
+    // multi-class launch: the residue classes of a strided deconvolution as consecutive ranges of ONE grid
+    if (p.ncls > kMaxClasses || !e.kernel_mc) return (int)hipErrorInvalidValue;
+    const double lim = 2147483647.0;
+    if ((double)e.esize * p.NB * (double)p.x_img_stride >= lim || (double)e.esize * p.NB * (double)p.y_img_stride >= lim)
+      return (int)hipErrorInvalidValue;
+    const long tn = (p.Cout + e.v.BN - 1) / e.v.BN;
+    long blk = 0;
+    double wtot = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+      ConvClass& q = p.cls[c];
+      const int ntaps = q.nty * q.ntx;
+      if (ntaps < 1 || ntaps > kMaxTaps || p.klen % e.BK != 0 || q.Ktot != ntaps * p.klen || q.M <= 0) return (int)hipErrorInvalidValue;
+      int bias = 0;
+      for (int ty : {0, q.nty - 1})
+        for (int tx : {0, q.ntx - 1}) bias = std::min(bias, (q.dy0 + ty * q.ddy) * p.x_row_stride + q.x0 + tx * q.ddx);
+      q.x_bias = bias;
+      magic_of((unsigned)(q.OH * q.OW), q.div_ohw);
+      magic_of((unsigned)q.OW, q.div_ow);
+      q.blk0 = (int)blk;
+      blk += (q.M + e.v.BM - 1) / e.v.BM * tn;
+      wtot += (double)e.esize * p.Cout * (double)q.Ktot;
+    }
+    if (wtot >= lim || blk > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    p.tiles_n = (int)tn;
+    magic_of((unsigned)tn, p.div_tn);
+    p.xcd_on = 0;
+    const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
+    hipLaunchKernelGGL(e.kernel_mc, dim3((unsigned)blk), dim3(nt), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+  }
   const int ntaps = p.nty * p.ntx;
   if (ntaps < 1 || ntaps > kMaxTaps || p.klen % e.BK != 0 || p.Ktot != ntaps * p.klen) return (int)hipErrorInvalidValue;
   // buffer (V#) addressing carries 32-bit byte offsets: every tensor of a launch must stay below 2 GiB
@@ -526,20 +610,7 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   p.x_bias = bias;
   long grid = conv_grid(p, variant);
   if (grid <= 0) return 0;
-  // magic numbers for n / d, 0 <= n < 2^31: sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1, n/d = (n*mul) >> sh
-  auto magic = [](unsigned d, unsigned (&mg)[2]) {
-    if (d <= 1) {
-      mg[0] = 0;
-      mg[1] = 0x80000000u;
-      return;
-    }
-    int l = 0;
-    while ((1ull << l) < d) ++l;
-    const int sh = 31 + l;
-    const unsigned long long q = (((unsigned __int128)1) << sh) / d;
-    mg[0] = (unsigned)(q + 1);
-    mg[1] = (unsigned)(sh - 32);
-  };
+  auto& magic = magic_of;
   const long tn = (p.Cout + e.v.BN - 1) / e.v.BN, tm = (p.M + e.v.BM - 1) / e.v.BM;
   p.tiles_n = (int)tn;
   magic((unsigned)tn, p.div_tn);

@@ -1081,15 +1081,16 @@ void Net::build_plan() {
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
     double bc = 0;
+    const bool mc = l.cg.ncls > 1;  // multi-class launches need a tile with a multi-class instantiation
     for (int v = 0; v < conv_num_variants(); ++v) {
-      if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es) continue;
+      if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es || (mc && !conv_variant_multiclass(v))) continue;
       if (force_variant >= 0 && v != force_variant) continue;
       double c = variant_cost(l.cg, v);
       if (best < 0 || c < bc) best = v, bc = c;
     }
     if (best < 0)
       for (int v = 0; v < conv_num_variants(); ++v) {
-        if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es) continue;
+        if (kgcd % conv_variant_bk(v) != 0 || conv_variant_esize(v) != es || (mc && !conv_variant_multiclass(v))) continue;
         double c = variant_cost(l.cg, v);
         if (best < 0 || c < bc) best = v, bc = c;
       }
@@ -1228,7 +1229,15 @@ void Net::build_plan() {
       const int DW = c.sw * (W - 1) + c.dw * (c.kw - 1) + 1 - 2 * c.pw;
       const int oh = op.fused_crop ? op.oh : 0, ow = op.fused_crop ? op.ow : 0;
       plan_flops += 2.0 * (double)C * H * W * N * OC * c.kh * c.kw;  // SURVEY §8(d) definition (OC = all member heads)
-      bool any = false;
+      // one record per residue class; they become ONE multi-class launch (kernels.h ConvClass) when a multi-class
+      // instantiation of the chosen tile exists, else one launch each
+      struct ClassRec {
+        ConvGemmParams g;
+        long y_off;
+        int ry, rx;
+        std::vector<std::pair<int, int>> tky, tkx;
+      };
+      std::vector<ClassRec> recs;
       for (int ry = 0; ry < c.sh; ++ry)
         for (int rx = 0; rx < c.sw; ++rx) {
           // rows of this class inside the (cropped) output window: Y = s*i + ry, y = Y - oh in [0, OHt)
@@ -1243,15 +1252,15 @@ void Net::build_plan() {
           range(ry, c.sh, oh, OHt, DH, i0, nh);
           range(rx, c.sw, ow, OWt, DW, j0, nw);
           if (nh <= 0 || nw <= 0) continue;
-          std::vector<std::pair<int, int>> tky, tkx;  // (k, source offset)
+          ClassRec rec;
+          rec.ry = ry, rec.rx = rx;
+          auto &tky = rec.tky, &tkx = rec.tkx;  // (k, source offset)
           for (int k = 0; k < c.kh; ++k)
             if ((ry + c.ph - k * c.dh) % c.sh == 0) tky.push_back({k, (ry + c.ph - k * c.dh) / c.sh});
           for (int k = 0; k < c.kw; ++k)
             if ((rx + c.pw - k * c.dw) % c.sw == 0) tkx.push_back({k, (rx + c.pw - k * c.dw) / c.sw});
-          Launch l = base;
-          l.kind = Launch::CONV;
-          l.label += " [class " + std::to_string(ry) + "," + std::to_string(rx) + "]";
-          ConvGemmParams& g = l.cg;
+          ConvGemmParams& g = rec.g;
+          g = ConvGemmParams{};
           g.esize = es;
           g.x_img_stride = (long)H * W * CP;
           g.x_row_stride = W * CP;
@@ -1283,38 +1292,88 @@ void Net::build_plan() {
           g.y_img_stride = (long)OHt * OWt * OCP;
           g.y_row_stride = c.sh * OWt * OCP;
           g.y_pix_stride = c.sw * OCP;
-          l.y_off = ((long)(c.sh * i0 + ry - oh) * OWt + (c.sw * j0 + rx - ow)) * OCP;
+          rec.y_off = ((long)(c.sh * i0 + ry - oh) * OWt + (c.sw * j0 + rx - ow)) * OCP;
           g.relu = op.relu;
           g.sigmoid_ch = op.sigmoid_ch >= 0 ? op.sigmoid_ch : (op.sigmoid ? OC : 0);
-          affine_vecs(op, l, OC);
-          const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
-          l.w = get_vec(dkey + "w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()) + ":" + std::to_string(ry) +
-                            "," + std::to_string(rx),
-                        [&](std::vector<float>& h) {
-                          h.assign((size_t)OC * g.Ktot, 0.f);
-                          int cbase = 0;
-                          for (int ml : members) {  // sibling layers concatenated along Cout
-                            const float* w = layers[ml].params[0]->st->host_ptr();  // [Cin][Cout][kh][kw]
-                            const int cm = layers[ml].conv.num_output;
-                            int t2 = 0;
-                            for (auto& a : tky)
-                              for (auto& b : tkx) {
-                                for (int co = 0; co < cm; ++co)
-                                  for (int ci = 0; ci < C; ++ci)
-                                    h[(size_t)(cbase + co) * g.Ktot + (size_t)t2 * CP + ci] =
-                                        w[(((size_t)ci * cm + co) * c.kh + a.first) * c.kw + b.first];
-                                ++t2;
-                              }
-                            cbase += cm;
-                          }
-                        });
-          l.flops = 2.0 * g.M * (double)OC * C * ntaps;
+          recs.push_back(std::move(rec));
+        }
+      if (recs.empty()) throw DcError(DC_ESHAPE, "layer '" + L.name + "': empty deconvolution output");
+      const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
+      // filter image of one class: [OC][taps of the class][CP], sibling layers concatenated along Cout
+      auto fill_class = [&](const ClassRec& rec, float* h) {
+        int cbase = 0;
+        for (int ml : members) {
+          const float* w = layers[ml].params[0]->st->host_ptr();  // [Cin][Cout][kh][kw]
+          const int cm = layers[ml].conv.num_output;
+          int t2 = 0;
+          for (auto& a : rec.tky)
+            for (auto& b : rec.tkx) {
+              for (int co = 0; co < cm; ++co)
+                for (int ci = 0; ci < C; ++ci)
+                  h[(size_t)(cbase + co) * rec.g.Ktot + (size_t)t2 * CP + ci] = w[(((size_t)ci * cm + co) * c.kh + a.first) * c.kw + b.first];
+              ++t2;
+            }
+          cbase += cm;
+        }
+      };
+      const std::string wkey = dkey + "w:" + std::to_string(members.front()) + "x" + std::to_string(members.size());
+      bool merged = false;
+      if (recs.size() > 1 && (int)recs.size() <= kMaxClasses && env_int("DC_DECONV_MERGE", 1) != 0) {
+        // heaviest class first: its workgroups are dispatched first, the light classes fill the tail
+        std::stable_sort(recs.begin(), recs.end(), [](const ClassRec& a, const ClassRec& b) { return a.g.Ktot > b.g.Ktot; });
+        Launch l = base;
+        l.kind = Launch::CONV;
+        l.label += " [" + std::to_string(recs.size()) + " classes]";
+        l.cg = recs[0].g;
+        l.cg.ncls = (int)recs.size();
+        long woff = 0;
+        for (size_t q = 0; q < recs.size(); ++q) {
+          const ConvGemmParams& g = recs[q].g;
+          ConvClass& k = l.cg.cls[q];
+          k.nty = g.nty, k.ntx = g.ntx, k.dy0 = g.dy0, k.ddy = g.ddy, k.x0 = g.x0, k.ddx = g.ddx, k.Ktot = g.Ktot;
+          k.OH = g.OH, k.OW = g.OW, k.M = g.M;
+          k.w_off = woff;
+          k.y_off = recs[q].y_off;
+          woff += (long)OC * g.Ktot;
+          l.flops += 2.0 * g.M * (double)OC * C * g.nty * g.ntx;
+        }
+        affine_vecs(op, l, OC);
+        // a multi-class tile must exist among the candidates of this K granularity (or be the forced one)
+        bool have_mc = false;
+        for (int v = 0; v < conv_num_variants(); ++v)
+          if (CP % conv_variant_bk(v) == 0 && conv_variant_esize(v) == es && conv_variant_multiclass(v) &&
+              (force_variant < 0 || force_variant == v))
+            have_mc = true;
+        if (have_mc) {
+          std::string key = wkey + ":mc";
+          for (auto& r : recs) key += ":" + std::to_string(r.ry) + "," + std::to_string(r.rx);
+          l.w = get_vec(key, [&](std::vector<float>& h) {
+            h.assign((size_t)woff, 0.f);
+            for (size_t q = 0; q < recs.size(); ++q) fill_class(recs[q], h.data() + l.cg.cls[q].w_off);
+          });
           l.w->as_half = dtype == 1;
           choose_variant(l, CP);
           plan.push_back(std::move(l));
-          any = true;
+          merged = true;
         }
-      if (!any) throw DcError(DC_ESHAPE, "layer '" + L.name + "': empty deconvolution output");
+      }
+      if (!merged)
+        for (auto& rec : recs) {
+          Launch l = base;
+          l.kind = Launch::CONV;
+          l.label += " [class " + std::to_string(rec.ry) + "," + std::to_string(rec.rx) + "]";
+          l.cg = rec.g;
+          l.y_off = rec.y_off;
+          affine_vecs(op, l, OC);
+          l.w = get_vec(wkey + ":" + std::to_string(rec.ry) + "," + std::to_string(rec.rx), [&](std::vector<float>& h) {
+            h.assign((size_t)OC * rec.g.Ktot, 0.f);
+            fill_class(rec, h.data());
+          });
+          l.flops = 2.0 * rec.g.M * (double)OC * C * rec.g.nty * rec.g.ntx;
+          l.w->as_half = dtype == 1;
+          choose_variant(l, CP);
+          plan.push_back(std::move(l));
+        }
     } else if (op.kind == LOp::POOL) {
       const LayerRec& L = layers[op.lids[0]];
       Launch l = base;
@@ -1537,10 +1596,16 @@ void Net::autotune() {
   for (auto& l : plan) {
     if (l.kind != Launch::CONV) continue;
     const ConvGemmParams& g = l.cg;
-    char key[160];
-    // "+w": the Winograd form competes for this layer (a different candidate set than with DC_WINOGRAD=0)
-    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
-                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w ? "+w" : "");
+    char key[200];
+    // "+w": the Winograd form competes for this layer (a different candidate set than with DC_WINOGRAD=0);
+    // "+mcN:K..": a multi-class launch (N classes with these K)
+    std::string mck;
+    if (g.ncls > 1) {
+      mck = "+mc" + std::to_string(g.ncls);
+      for (int c = 0; c < g.ncls; ++c) mck += ":" + std::to_string(g.cls[c].Ktot) + "m" + std::to_string(g.cls[c].M);
+    }
+    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
+                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w ? "+w" : "", mck.c_str());
     auto it = tune_cache_.find(key);
     if (it == tune_cache_.end()) {
       timed_any = true;
@@ -1548,6 +1613,7 @@ void Net::autotune() {
       float best_ms = 1e30f;
       for (int v = 0; v < conv_num_variants(); ++v) {
         if (g.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != g.esize) continue;
+        if (g.ncls > 1 && !conv_variant_multiclass(v)) continue;
         Launch trial = l;
         trial.variant = v;
         run_launch(trial, stream);  // warm
@@ -1582,7 +1648,8 @@ void Net::autotune() {
       it = tune_cache_.emplace(key, best).first;
     }
     // a cache line naming the Winograd form while it is switched off (or not eligible any more): keep the cost model's tile
-    if (!(it->second == kWinoVariant && !l.wino_w)) l.variant = it->second;
+    if (!(it->second == kWinoVariant && !l.wino_w) && !(g.ncls > 1 && (it->second == kWinoVariant || !conv_variant_multiclass(it->second))))
+      l.variant = it->second;
     if (l.variant == kWinoVariant) {
       l.kernel = "wino_f23<4x8x16>";
       l.grid = wino_grid(l.cg);
@@ -2201,7 +2268,8 @@ std::string Net::plan_text() {
     const Launch& l = plan[i];
     os << i << "\t" << l.kernel << "\t";
     if (l.kind == Launch::CONV)
-      os << "M=" << l.cg.M << " N=" << l.cg.Cout << " K=" << l.cg.Ktot << " taps=" << l.cg.nty * l.cg.ntx << " grid=" << l.grid
+      os << "M=" << l.cg.M << " N=" << l.cg.Cout << " K=" << l.cg.Ktot << " taps=" << l.cg.nty * l.cg.ntx
+         << (l.cg.ncls > 1 ? " classes=" + std::to_string(l.cg.ncls) : std::string()) << " grid=" << l.grid
          << (l.in2 >= 0 ? " +resid" : "") << (l.relu ? " +relu" : "") << (l.cg.sigmoid_ch ? " +sigmoid" : "");
     os << "\t" << l.label << "\n";
   }

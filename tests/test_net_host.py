@@ -66,27 +66,38 @@ def test_lowering_fuses_the_whole_graph_into_gemm_launches(net152):
     net152.blobs["data"].reshape(1, 3, 240, 320)
     net152.set_option(1, 1)
     lines = [l for l in net152.plan_text().splitlines() if not l.startswith("#")]
-    # 158 convolutions + 3 deconvolutions x 4 parity classes + pool + sigmoid
-    assert len(lines) == 172
-    assert sum("conv_gemm<" in l for l in lines) == 170
-    assert sum("+resid" in l for l in lines) == 50 + 12
+    # 158 convolutions + 3 deconvolutions (the 4 output-parity classes of each are ONE multi-class launch) + pool + sigmoid
+    assert len(lines) == 163
+    assert sum("conv_gemm<" in l for l in lines) == 161
+    assert sum("+resid" in l for l in lines) == 50 + 3
     assert any(l.endswith("conv1+bn_conv1+scale_conv1+conv1_relu") for l in lines)
     assert any("res2a_branch2c+bn2a_branch2c+scale2a_branch2c+res2a+res2a_relu" in l for l in lines)
-    assert any("res5c_up_next+crop_next+next_pred [class 1,1]" in l for l in lines)
+    assert any("res5c_up_next+crop_next+next_pred [4 classes]" in l and "classes=4" in l and "K=8192 taps=4" in l for l in lines)
     # level 2: the three sibling heads run as one 406-channel skip GEMM + one 406-channel deconvolution
     net152.set_option(1, 2)
     lines2 = [l for l in net152.plan_text().splitlines() if not l.startswith("#")]
-    assert len(lines2) == 172 - 2 - 8 - 1  # 3 skip convs -> 1, 12 deconv classes -> 4, sigmoid folded
-    assert sum("N=406" in l for l in lines2) == 5 and sum("+sigmoid" in l for l in lines2) == 4
+    assert len(lines2) == 163 - 2 - 2 - 1 == 158  # 3 skip convs -> 1, 3 deconvolutions -> 1, sigmoid folded
+    assert sum("N=406" in l for l in lines2) == 2 and sum("+sigmoid" in l for l in lines2) == 1
     assert any(l.endswith("res3d_pose+res3d_locref+res3d_next") for l in lines2)
     assert abs(net152.flops() / 1e9 - 46.24) < 0.01  # algorithmic FLOPs do not depend on the fusion level
     net152.set_option(1, 0)
     lines0 = [l for l in net152.plan_text().splitlines() if not l.startswith("#")]
     # unfused: + 53 eltwise, 3 crop; every Caffe-visible blob materialised
-    assert len(lines0) == 172 + 50 + 3 + 3
+    assert len(lines0) == 163 + 50 + 3 + 3
     assert sum("eltwise" in l for l in lines0) == 54
     assert sum("crop" in l.split("\t")[1] for l in lines0) == 3
     net152.set_option(1, 2)
+
+
+def test_deconvolution_classes_as_separate_launches(monkeypatch):
+    # DC_DECONV_MERGE=0 keeps the one-launch-per-parity-class lowering (what a tile without a multi-class instantiation gets)
+    monkeypatch.setenv("DC_DECONV_MERGE", "0")
+    net = caffe.Net(deepercut_prototxt(152, 240, 320), caffe.TEST, from_text=True)
+    lines = [l for l in net.plan_text().splitlines() if not l.startswith("#")]
+    assert len(lines) == 161 and sum("N=406" in l for l in lines) == 5 and sum("+sigmoid" in l for l in lines) == 4
+    # k3 s2 p0: even output rows/columns receive kernel taps 0 and 2, odd ones tap 1 only
+    assert any("[class 0,0]" in l and "K=8192 taps=4" in l for l in lines)
+    assert any("[class 1,1]" in l and "K=2048 taps=1" in l for l in lines)
 
 
 def test_forward_without_gpu_fails_loudly(net152):
@@ -264,7 +275,7 @@ def test_fp16_lowering_on_the_host():
     net = caffe.Net(deepercut_prototxt(152, 240, 320), caffe.TEST, from_text=True, dtype="f16")
     text = net.plan_text()
     lines = [l for l in text.splitlines() if not l.startswith("#")]
-    assert "dtype=f16" in text.splitlines()[0] and len(lines) == 161
+    assert "dtype=f16" in text.splitlines()[0] and len(lines) == 158
     assert all("conv_gemm<h" in l for l in lines if "conv_gemm" in l)
     assert "K=448 taps=7" in lines[0]  # stem: 7 row taps of 8 pixels x 8 channels (3 padded to one 16-byte vector)
     assert abs(net.flops() / 1e9 - 46.24) < 0.01
@@ -298,7 +309,7 @@ def test_plan_cache_serves_shapes_met_before_without_relowering():
     assert net.blobs["prob"].shape == (1, 14, 34, 46)
     # an option that changes the lowering drops every cached plan
     net.set_option(1, 0)
-    assert len([l for l in net.plan_text().splitlines() if not l.startswith("#")]) > 161
+    assert len([l for l in net.plan_text().splitlines() if not l.startswith("#")]) > 200
     assert net.stats()["cached_plans"] == 1
 
 
