@@ -106,11 +106,57 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
 def hbm_traffic_from_profile():
     """HBM bytes per conv_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     corrected as MI355X_MICROARCH.md prescribes) — counters cannot be read inside the timed run."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        return json.load(open(path))["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
+
+
+def config2_f16_line(caffe, layers, depth, steps, dev, inject):
+    """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
+    680x920), float16 operands with float32 accumulation, device-resident, one pyramid batch at a time.  A step = the
+    four batch-8 forwards of one pyramid batch (32 forwards = 8 images); shapes come from the per-shape plan cache."""
+    import torch
+    from deepcut_tools import deepercut_prototxt
+
+    shapes = [(272, 368), (408, 552), (544, 736), (680, 920)]
+    net = caffe.Net(deepercut_prototxt(depth, 544, 736, 8), caffe.TEST, from_text=True, hipgraph=1, dtype="f16")
+    inject(net, layers)
+    net.reserve(8, *shapes[-1])
+    g = torch.Generator(device="cpu").manual_seed(10)
+    xs = {s: (torch.randn(8, 3, s[0], s[1], generator=g) * 50).to(dev) for s in shapes}
+    outs = {s: [torch.empty(8, c, s[0] // 8, s[1] // 8, device=dev) for c in (14, 28, 364)] for s in shapes}
+    st = torch.cuda.current_stream(dev)
+    flops = 0.0
+
+    def pyramid():
+        for s in shapes:
+            o = outs[s]
+            net.forward_device(xs[s].data_ptr(), 8, s[0], s[1], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), st.cuda_stream)
+
+    for s in shapes:  # lower, tune and capture every shape once
+        net.blobs["data"].reshape(8, 3, *s)
+        flops += net.flops()
+    pyramid()
+    pyramid()
+    torch.cuda.synchronize(dev)
+    before = net.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pyramid()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    after = net.stats()
+    tf = steps * flops / dt / 1e12
+    return {"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
+                        "accumulate (BASELINE configs[2]), one batch-8 forward at a time",
+            "value": steps * 8 / dt, "unit": "image-pyramids/s", "forwards_per_s": steps * 32 / dt, "steps": steps,
+            "ms_per_pyramid_batch": dt / steps * 1e3, "gflop_per_image_pyramid": flops / 8 / 1e9, "tflops": tf,
+            "roofline_frac_f16": tf / PEAK_FP16_MFMA_TFLOPS,
+            "relowerings_in_timed_region": after["lowerings"] - before["lowerings"],
+            "graph_instantiations_in_timed_region": after["graph_instantiations"] - before["graph_instantiations"]}
 
 
 def main():
@@ -120,7 +166,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=544)
     ap.add_argument("--width", type=int, default=736)
-    ap.add_argument("--batch", type=int, default=1, help="images per rank per step")
+    ap.add_argument("--batch", type=int, default=0, help="images per rank per step (default: 1, or 8 with --config 3)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3],
+                    help="BASELINE.json configs index: 1 = batch 1 per GPU (the headline), 3 = 8 images of 736x544 per GPU "
+                         "(batch 64 sharded 8-way) with the gather of the maps to rank 0")
+    ap.add_argument("--no-f16-line", action="store_true", help="skip the configs[2] (fp16 pyramid) measurement printed beside the headline")
     ap.add_argument("--depth", type=int, default=152)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
@@ -128,12 +178,16 @@ def main():
                          "accumulation (BASELINE configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--breakdown", default="", help="write the per-launch hipEvent table to this file")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "0")),
                     help="independent batch-B forwards kept in flight per GPU (each on its own HIP stream and Net)")
     ap.add_argument("--backend", default=os.environ.get("DC_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real thing) or gloo (lets two ranks share one "
                          "GPU to smoke-test the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 8 if args.config == 3 else 1
+    if args.streams <= 0:  # forwards kept in flight: 3 at batch 1, 2 at batch 8
+        args.streams = 3 if args.batch < 4 else 2
 
     import numpy as np
     import torch
@@ -187,21 +241,31 @@ def main():
     main = torch.cuda.current_stream(dev)
     streams = [main] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     xs = [(torch.randn(B, 3, H, W, generator=g) * 50).to(dev) for _ in range(S)]
-    outs = [torch.empty(sum(nel.values()), dtype=torch.float32, device=dev) for _ in range(S)]
+    # the maps leave the net in its own element type: float16 payloads from a float16 net (half the gather bytes)
+    half = args.dtype == "f16"
+    outs = [torch.empty(sum(nel.values()), dtype=torch.float16 if half else torch.float32, device=dev) for _ in range(S)]
     a, b = nel["prob"], nel["prob"] + nel["loc_pred"]
     recvs = [None] * S
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo moves host buffers
     if world > 1 and rank == 0:  # one set of receive buffers per in-flight forward
-        recvs = [[torch.empty_like(outs[0]) for _ in range(world)] for _ in range(S)]
+        recvs = [[torch.empty_like(outs[0], device=comm_dev) for _ in range(world)] for _ in range(S)]
     sizes = [outs[0].numel()] * world
 
     def step(i, nstreams):
         # asynchronous on stream i % nstreams; inputs and outputs stay in HBM
         k = i % nstreams
         st, out, x = streams[k], outs[k], xs[k]
-        nets[k].forward_device(x.data_ptr(), B, H, W, out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(),
-                               st.cuda_stream)
+        if half:
+            nets[k].forward_device(x.data_ptr(), B, H, W, None, None, None, st.cuda_stream)
+            nets[k].emit_maps_device(out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(), half=True, stream=st.cuda_stream)
+        else:
+            nets[k].forward_device(x.data_ptr(), B, H, W, out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(),
+                                   st.cuda_stream)
         if world > 1:
             with torch.cuda.stream(st):
+                if args.backend != "nccl":  # smoke-test transport: through the host
+                    st.synchronize()
+                    out = out.cpu()
                 gather_maps_known(out, sizes, 0, None, out=recvs[k])
 
     def fence():
@@ -228,7 +292,7 @@ def main():
         e1.record(main)
         fence()
         dt = time.perf_counter() - t0
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), e0.elapsed_time(e1)
@@ -268,8 +332,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (randn*50 images resident in HBM; conditioned random-init weights, seed 0)",
             "config": {
-                "workload": "batch=%d single-scale %dx%d (WxH) ResNet-%d DeeperCut forward per GPU, fp32 "
-                            "(BASELINE configs[1]%s)" % (B, W, H, args.depth, "" if (B, H, W) == (1, 544, 736) else ", resized"),
+                "workload": "batch=%d single-scale %dx%d (WxH) ResNet-%d DeeperCut forward per GPU, %s "
+                            "(BASELINE configs[%d]%s)" % (B, W, H, args.depth, "fp16 MFMA / fp32 accumulate" if args.dtype == "f16" else "fp32",
+                                                         args.config, "" if (H, W) == (544, 736) and B == (8 if args.config == 3 else 1) else ", resized"),
                 "per_gpu_batch": B,
                 "global_batch": B * world,
                 "input": [B, 3, H, W],
@@ -294,9 +359,10 @@ def main():
                 "flops_per_launch": per_launch_flops,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_image": conv_launches,
-                "traffic": hbm_traffic_from_profile() if args.dtype == "f32" else None,
-                "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json); "
-                                "algorithmic minimum %.1f MB" % ((2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) / conv_launches / 1e6),
+                "traffic": hbm_traffic_from_profile()[0] if (args.dtype, B, H, W) == ("f32", 1, 544, 736) else None,
+                "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s); "
+                                "algorithmic minimum %.1f MB" % (hbm_traffic_from_profile()[1],
+                                                                 (2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) / conv_launches / 1e6),
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
             },
         }
@@ -324,6 +390,9 @@ def main():
             res["pcie_inclusive_image_entry"] = {"value": n_pcie * B / dt_img, "unit": "images/s",
                                                  "ms_per_forward": dt_img / n_pcie * 1e3,
                                                  "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
+        if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
+            # the other single-GPU configuration of BASELINE.json, timed by the same run (never `value`)
+            res["config2_f16"] = config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights)
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()

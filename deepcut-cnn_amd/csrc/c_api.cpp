@@ -117,6 +117,16 @@ int dc_net_set_option(dc_net* net, int key, int value) {
     }
   });
 }
+int dc_net_get_option(dc_net* net, int key, int* value) {
+  REQUIRE(net);
+  REQUIRE(value);
+  Net* n = N(net);
+  if (key == DC_OPT_FUSE) *value = n->fuse;
+  else if (key == DC_OPT_HIPGRAPH) *value = n->use_graph;
+  else if (key == DC_OPT_DTYPE) *value = n->dtype;
+  else return fail(DC_EINVAL, "unknown option " + std::to_string(key));
+  return DC_OK;
+}
 int dc_net_copy_from(dc_net* net, const char* path) {
   REQUIRE(net);
   REQUIRE(path);
@@ -287,6 +297,11 @@ int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, v
   REQUIRE(pose);
   if (!(scale > 0)) return fail(DC_EINVAL, "scale must be positive");
   return guard([&] { N(net)->decode_pose(scale, pose, is_device != 0, stream); });
+}
+
+int dc_net_emit_maps(dc_net* net, void* prob, void* loc_pred, void* next_pred, int elem, int is_device, void* stream) {
+  REQUIRE(net);
+  return guard([&] { N(net)->emit_last_maps(prob, loc_pred, next_pred, elem, is_device != 0, stream); });
 }
 
 int dc_net_forward_images(dc_net* net, const unsigned char* images, int n, int height, int width, double scale,

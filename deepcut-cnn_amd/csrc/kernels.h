@@ -119,9 +119,10 @@ int launch_crop(const void* x, void* y, int esize, int NB, int H, int W, int C, 
 // layout changes at the Blob boundary (host side is NCHW float, blob.hpp:153-164)
 // src NCHW [NB,C,H,W] -> dst NHWC with channel pitch CP (>= C, extra channels zeroed)
 int launch_nchw_to_nhwc(const float* src, void* dst, int esize, int NB, int C, int H, int W, int CP, void* stream);
-// src NHWC pitch CP, channels [c0, c0+C) -> dst NCHW [NB,C,H,W]
-int launch_nhwc_to_nchw(const void* src, float* dst, int esize, int NB, int C, int H, int W, int CP, int c0,
-                        void* stream);
+// src NHWC pitch CP, channels [c0, c0+C) -> dst NCHW [NB,C,H,W], float (dst_esize 4) or — from a half image only —
+// _Float16 (dst_esize 2: the gather payload of an fp16 net)
+int launch_nhwc_to_nchw(const void* src, void* dst, int esize, int NB, int C, int H, int W, int CP, int c0,
+                        void* stream, int dst_esize = 4);
 // packed filter image float -> half (fp16 nets)
 int launch_f32_to_f16(const float* src, void* dst, long n, void* stream);
 

@@ -1939,12 +1939,15 @@ void Net::enqueue_plan(void* s) {
   for (int v : plan_views_) storages[v]->head = HEAD_AT_GPU;
 }
 
-// Copy the three output maps out as NCHW float32 (host or device destination), enqueued on s.
-void Net::emit_maps(float* prob, float* loc, float* next, bool is_device, void* s) {
+// Copy the three output maps out as NCHW (host or device destination), enqueued on s: float32, or — dst_esize 2, fp16
+// nets only — the half values as they are in HBM (half the gather payload).
+void Net::emit_maps(void* prob, void* loc, void* next, bool is_device, void* s, int dst_esize) {
   struct Out {
     const char* name;
-    float* dst;
+    void* dst;
   } outs[3] = {{"prob", prob}, {"loc_pred", loc}, {"next_pred", next}};
+  if (dst_esize != 4 && !(dst_esize == 2 && dtype == 1))
+    throw DcError(DC_EINVAL, "maps are emitted as float32, or as float16 from a float16 net (DC_OPT_DTYPE 1)");
   for (auto& o : outs) {
     if (!o.dst) continue;
     auto it = blob_index.find(o.name);
@@ -1955,14 +1958,26 @@ void Net::emit_maps(float* prob, float* loc, float* next, bool is_device, void* 
     const int ses = st.view_of >= 0 ? storages[st.view_of]->esize : st.esize;
     const int scp = st.view_of >= 0 ? storages[st.view_of]->cp() : st.cp();
     const int sc0 = st.view_of >= 0 ? st.view_c0 : 0;
+    if (st.head == UNINITIALIZED) throw DcError(DC_EINVAL, std::string("'") + o.name + "': run a forward first");
     if (is_device) {
-      KCHECK(launch_nhwc_to_nchw(src, o.dst, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
+      KCHECK(launch_nhwc_to_nchw(src, o.dst, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s, dst_esize));
     } else {
-      st.ensure_stage(m);
-      KCHECK(launch_nhwc_to_nchw(src, st.stage, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s));
-      HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s));
+      st.ensure_stage(m);  // sized in floats: large enough for either element type
+      KCHECK(launch_nhwc_to_nchw(src, st.stage, ses, st.dim(0), st.dim(1), st.dim(2), st.dim(3), scp, sc0, s, dst_esize));
+      HIPCHECK(hipMemcpyAsync(o.dst, st.stage, m * (size_t)dst_esize, hipMemcpyDeviceToHost, (hipStream_t)s));
     }
   }
+}
+
+void Net::emit_last_maps(void* prob, void* loc, void* next, int elem, bool is_device, void* user_stream) {
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "emit_maps() in CPU mode");
+  if (elem != 0 && elem != 1) throw DcError(DC_EINVAL, "element type must be 0 (float32) or 1 (float16)");
+  ensure_device();
+  const bool own_async = user_stream == (void*)-1;
+  if (own_async) user_stream = nullptr;
+  void* s = user_stream ? user_stream : stream;
+  emit_maps(prob, loc, next, is_device, s, elem == 1 ? 2 : 4);
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
 void Net::forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc, float* next,

@@ -241,6 +241,8 @@ struct Net {
   void sync_to_host(Storage& s);       // SyncedMemory::to_cpu
   void sync_to_device(Storage& s);     // SyncedMemory::to_gpu
   void decode_pose(double scale, double* out, bool is_device, void* user_stream);  // after a forward
+  // the maps of the last forward as NCHW float32 (elem 0) or float16 (elem 1, fp16 nets), host or device destination
+  void emit_last_maps(void* prob, void* loc, void* next, int elem, bool is_device, void* user_stream);
   // multi-person consumers of the maps of the last forward (encoding: pose_data_layer.cpp:686-802)
   void detect_parts(double scale, float thr, int radius, int max_det, int* counts, double* dets);
   void decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out);
@@ -263,7 +265,7 @@ struct Net {
   void autotune();
   Storage& begin_batch(int n, int h, int w);
   void enqueue_plan(void* s);
-  void emit_maps(float* prob, float* loc, float* next, bool is_device, void* s);
+  void emit_maps(void* prob, void* loc, void* next, bool is_device, void* s, int dst_esize = 4);
   std::shared_ptr<ResampleTable> resample_table(int in_size, int out_size);
   std::map<std::pair<int, int>, std::shared_ptr<ResampleTable>> resample_;
   struct MapRef {

@@ -60,6 +60,7 @@ def _load():
         "dc_net_clone": (ci, [vp, C.POINTER(vp)]),
         "dc_net_synchronize": (ci, [vp]),
         "dc_net_set_option": (ci, [vp, ci, ci]),
+        "dc_net_get_option": (ci, [vp, ci, C.POINTER(ci)]),
         "dc_net_copy_from": (ci, [vp, cp]),
         "dc_net_save": (ci, [vp, cp]),
         "dc_net_name": (cp, [vp]),
@@ -88,6 +89,7 @@ def _load():
         "dc_blob_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
         "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
         "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
+        "dc_net_emit_maps": (ci, [vp, vp, vp, vp, ci, ci, vp]),
         "dc_net_forward_images": (ci, [vp, vp, ci, ci, ci, C.c_double, ci, vp, vp, vp, vp, vp]),
         "dc_image_canvas_size": (ci, [ci, ci, C.c_double, C.POINTER(ci), C.POINTER(ci)]),
         "dc_net_detect_parts": (ci, [vp, C.c_double, C.c_float, ci, ci, vp, vp]),
@@ -245,6 +247,16 @@ class Net(object):
 
     def set_option(self, key, value):
         _check(_lib.dc_net_set_option(self._h, int(key), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        _check(_lib.dc_net_get_option(self._h, int(key), C.byref(v)))
+        return v.value
+
+    @property
+    def dtype(self):
+        """'f32' or 'f16': the element type of activations and filters in HBM (DC_OPT_DTYPE)."""
+        return "f16" if self.get_option(3) == 1 else "f32"
 
     # --- pycaffe.py:22-59 -----------------------------------------------------------------
     @property
@@ -408,6 +420,14 @@ class Net(object):
         _check(_lib.dc_net_forward_images(self._h, C.c_void_p(img_ptr), n, h, w, float(scale), 1, C.c_void_p(prob_ptr or 0),
                                           C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(pose_ptr or 0),
                                           C.c_void_p(stream or 0)))
+
+    def emit_maps_device(self, prob_ptr=None, loc_ptr=None, next_ptr=None, half=False, stream=None):
+        """Copy the maps of the last forward into device buffers as NCHW float32, or (half=True, fp16 nets) float16 —
+        the gather payload in the net's own element type.  Asynchronous on `stream` ("own" = the net's)."""
+        if stream == "own":
+            stream = C.c_void_p(-1).value
+        _check(_lib.dc_net_emit_maps(self._h, C.c_void_p(prob_ptr or 0), C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0),
+                                     1 if half else 0, 1, C.c_void_p(stream or 0)))
 
     def detect_parts(self, scale=1.0, threshold=0.1, radius=1, max_det=32):
         """Part candidates of the last forward (NMS of every score map + location refinement, on the device).

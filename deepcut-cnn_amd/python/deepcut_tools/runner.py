@@ -3,21 +3,26 @@
 Every (image, scale) pair is an independent forward, so the work is dealt out statically:
   1. work items = (image index, scale), cost ~ pixels of the net input;
   2. longest-processing-time-first assignment to ranks (`lpt_shards`, identical on every rank — no
-     scheduling traffic);
-  3. on each rank, items with the same net-input shape are forwarded as ONE batch
-     (`Net.forward_batch`), the pose is decoded on the device (`Net.decode_pose`: arg-max + location
-     refinement, estimate_pose.py:131-143), optionally the three maps are kept (multi-person consumers
-     need `next_pred`).  With the default pre-processing and a net that has `forward_images`, items of the
-     same source size and scale go through the image entry instead: uint8 pixels up, pre-processing
-     (estimate_pose.py:83-103, bit-exact) + forward + decode on the device, 70 doubles per item back;
-  4. ONE exchange: poses (70 doubles per item) and, if asked for, the maps are gathered to rank 0
-     (`gather_maps`: grouped send/recv, variable sizes);
+     scheduling traffic); on a rank, items of the same source size and scale form batches (`rank_batches`);
+     every rank can therefore compute every other rank's batch list and buffer sizes;
+  3. device pipeline (a caffe.Net of this package on a GPU): per batch the uint8 pixels go up, pre-processing
+     (estimate_pose.py:83-103, bit-exact), forward and pose decode (estimate_pose.py:131-143) run on the device,
+     `depth` batches in flight on executor clones; poses and — if asked for — the three maps stay in HBM
+     (maps in the net's own element type: float16 payloads from a float16 net);
+  4. exchange: the maps of batch k are sent to rank 0 as soon as batch k is done, on a side stream, while batch
+     k+1 computes (round k = one grouped send/recv: every rank that has a k-th batch sends it, rank 0 posts the
+     matching receives; sizes come from the schedule, no headers); the poses (70 doubles per item) follow in one
+     final gather;
   5. rank 0 keeps, per image, the scale whose minimum joint confidence is highest (estimate_pose.py:119-126).
-Single-process use (no process group) is the world-size-1 case of the same code.
+A host pipeline (any object with forward_batch(images)->dict and decode_pose(scale)->[n,5,J], or a custom
+`preprocess`) does the same with NumPy buffers and one gather at the end; single-process use (no process
+group) is the world-size-1 case of the same code.
 """
 import numpy as np
 
-from .shard import gather_maps, lpt_shards
+from .shard import gather_maps, gather_maps_known, lpt_shards
+
+MAP_NAMES = ("prob", "loc_pred", "next_pred")
 
 
 def _dist():
@@ -47,20 +52,40 @@ def plan_work(image_shapes, scales, world):
     return items, lpt_shards(costs, world)
 
 
+def rank_batches(image_shapes, items, shard, max_batch):
+    """Batches of one rank, in execution order: [(source (h, w), scale, net input (H, W), [item indices])].  A pure
+    function of the schedule, so every rank knows every other rank's batches (and the size of every payload)."""
+    groups = {}
+    for k in shard:
+        groups.setdefault((tuple(image_shapes[items[k][0]]), items[k][1]), []).append(k)
+    out = []
+    # largest net input first: its buffers are allocated before the smaller shapes are met, so nothing grows later
+    # (a reallocated buffer makes the captured graphs of the other shapes stale)
+    for key in sorted(groups, key=lambda g: (-items[groups[g][0]][2][0] * items[groups[g][0]][2][1], g)):
+        ks = groups[key]
+        for b0 in range(0, len(ks), max_batch):
+            out.append((key[0], key[1], items[ks[0]][2], ks[b0:b0 + max_batch]))
+    return out
+
+
 class ShardedPoseRunner(object):
     """`net`: a caffe.Net of this package (or anything with forward_batch(images)->dict and
     decode_pose(scale)->[n,5,J]).  `preprocess(image, scale) -> HxWx3 float32` defaults to pose.estimate_pose's."""
 
-    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True, depth=1):
-        """depth > 1 (image entry, poses only): that many batches are kept in flight on this GPU, each on its own
-        executor (`net.clone()`: shared weights) and stream — upload, pre-processing, forward and decode of one batch
-        overlap the others'; results are identical to depth 1."""
+    def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True, depth=1,
+                 half_maps=None):
+        """depth > 1 (device pipeline): that many batches are kept in flight on this GPU, each on its own executor
+        (`net.clone()`: shared weights, shared tile choices) and stream — upload, pre-processing, forward and decode of
+        one batch overlap the others'; results equal depth 1 up to the batch composition (same kernels, same order).
+        half_maps: send float16 maps (default: whenever the net computes in float16)."""
         self.net = net
         self.group = group
         self.max_batch = max_batch
         self.device = device
         self.depth = max(1, int(depth))
+        self.half_maps = half_maps
         self._execs = None
+        self._seen = set()
         self.image_entry = bool(device_preprocess and preprocess is None and hasattr(net, "forward_images"))
         if preprocess is None:
             from pose.estimate_pose import preprocess as _pp
@@ -68,15 +93,48 @@ class ShardedPoseRunner(object):
             preprocess = _pp
         self.preprocess = preprocess
 
-    def _run_in_flight(self, images, items, by_source, poses):
-        """Poses of the local work items with `depth` batches in flight (device buffers through torch)."""
+    # ------------------------------------------------------------------------------------------------------------
+    def _torch_device(self):
+        """The torch device of this runner's GPU work: the device the NET executes on (caffe.set_device), never torch's
+        current device — a rank that set one and not the other must not hand cuda:0 buffers to kernels on another GPU."""
         import torch
 
-        if self._execs is None:
-            self._execs = [self.net] + [self.net.clone() for _ in range(self.depth - 1)]
-            self._streams = [torch.cuda.Stream() for _ in self._execs]
-        nj = self.net.blobs["prob"].shape[1]
+        idx = getattr(self.net, "device", -1)
+        if idx is None or idx < 0:
+            import caffe
+
+            idx = caffe.pycaffe._lib.dc_get_device()
+        return torch.device("cuda", int(idx))
+
+    def _comm_device(self, dist, dev):
+        if self.device is not None:
+            return self.device
+        if dist is not None and dist.get_backend(self.group) == "nccl":
+            return dev  # RCCL moves device buffers
+        return "cpu"
+
+    def _run_device(self, images, items, batches_of, rank, world, want_maps, dist):
+        """The device pipeline of this rank.  Returns (poses {item: [5,J]}, maps {item: dict of arrays} on rank 0 or {})."""
+        import torch
+
+        dev = self._torch_device()
+        comm_dev = self._comm_device(dist, dev) if world > 1 else None
+        with torch.cuda.device(dev):
+            if self._execs is None:
+                self._execs = [self.net] + [self.net.clone() for _ in range(self.depth - 1)]
+                self._streams = [torch.cuda.Stream(dev) for _ in self._execs]
+                self._comm_stream = torch.cuda.Stream(dev)
+        chans = [self.net.blobs[n].shape[1] for n in MAP_NAMES]
+        nj, ctot = chans[0], sum(chans)
+        half = self.half_maps if self.half_maps is not None else getattr(self.net, "dtype", "f32") == "f16"
+        mdtype = torch.float16 if half else torch.float32
+        mine = batches_of[rank]
         busy = [None] * self.depth
+        poses, payload, recv = {}, {}, {}
+        reqs = []
+
+        def msize(b):
+            return len(b[3]) * ctot * (b[2][0] // 8) * (b[2][1] // 8)
 
         def finish(e):
             if busy[e] is None:
@@ -88,24 +146,133 @@ class ShardedPoseRunner(object):
                 poses[k] = host[j]
             busy[e] = None
 
-        slot = 0
-        for key in sorted(by_source):
-            ks, s = by_source[key], key[1]
-            h, w = key[0]
-            for b0 in range(0, len(ks), self.max_batch):
-                chunk = ks[b0:b0 + self.max_batch]
-                e = slot % self.depth
-                slot += 1
-                finish(e)
-                st = self._streams[e]
-                with torch.cuda.stream(st):
-                    img_t = torch.from_numpy(np.stack([images[items[k][0]] for k in chunk])).cuda(non_blocking=True)
-                    pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device="cuda")
-                self._execs[e].forward_images_device(img_t.data_ptr(), len(chunk), h, w, s, pose_ptr=pose_t.data_ptr(),
-                                                     stream=st.cuda_stream)
-                busy[e] = (chunk, pose_t, img_t)
+        def exchange_round(k, done_event):
+            """Round k of the map exchange on the side stream: this rank's k-th batch goes to rank 0 (if it has one),
+            rank 0 receives the k-th batch of every rank that has one."""
+            ops = []
+            with torch.cuda.stream(self._comm_stream):
+                if done_event is not None:
+                    self._comm_stream.wait_event(done_event)
+                if rank != 0 and k < len(mine):
+                    buf = payload[k]
+                    if str(comm_dev) == "cpu":
+                        self._comm_stream.synchronize()
+                        buf = buf.cpu()
+                        payload[k] = buf  # keep the sent tensor alive until the request completes
+                    ops.append(dist.P2POp(dist.isend, buf, 0, self.group))
+                if rank == 0:
+                    for r in range(1, world):
+                        if k < len(batches_of[r]):
+                            recv[(r, k)] = torch.empty(msize(batches_of[r][k]), dtype=mdtype, device=comm_dev)
+                            ops.append(dist.P2POp(dist.irecv, recv[(r, k)], r, self.group))
+                if ops:
+                    reqs.extend(dist.batch_isend_irecv(ops))
+
+        rounds = max([len(b) for b in batches_of]) if want_maps and world > 1 else 0
+        for bi, (src_hw, s, in_hw, chunk) in enumerate(mine):
+            e = bi % self.depth
+            finish(e)
+            key = (len(chunk), in_hw)
+            if key not in self._seen:
+                # first meeting of a shape: its tiles are timed on the device inside this call — with the GPU to itself
+                # (timings taken under the other executors' kernels are noise, and every executor shares the choice)
+                for q in range(self.depth):
+                    finish(q)
+                self._seen.add(key)
+            st = self._streams[e]
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                img_t = torch.from_numpy(np.stack([images[items[k][0]] for k in chunk])).to(dev, non_blocking=True)
+                pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device=dev)
+                mbuf = torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None
+            assert img_t.device == dev and pose_t.device == dev
+            ex = self._execs[e]
+            ex.forward_images_device(img_t.data_ptr(), len(chunk), src_hw[0], src_hw[1], s, pose_ptr=pose_t.data_ptr(),
+                                     stream=st.cuda_stream)
+            done = None
+            if want_maps:
+                hw8 = (in_hw[0] // 8) * (in_hw[1] // 8) * len(chunk)
+                o1, o2 = chans[0] * hw8, (chans[0] + chans[1]) * hw8
+                ex.emit_maps_device(mbuf[:o1].data_ptr(), mbuf[o1:o2].data_ptr(), mbuf[o2:].data_ptr(), half=half,
+                                    stream=st.cuda_stream)
+                payload[bi] = mbuf
+                done = torch.cuda.Event()
+                done.record(st)
+            busy[e] = (chunk, pose_t, img_t)
+            if bi < rounds:
+                exchange_round(bi, done)
         for e in range(self.depth):
             finish(e)
+        for k in range(len(mine), rounds):  # rounds in which this rank has nothing to send (rank 0 may still receive)
+            exchange_round(k, None)
+        for q in reqs:
+            q.wait()
+        if reqs:
+            self._comm_stream.synchronize()
+        maps = {}
+        if want_maps and rank == 0:
+            def unpack(buf, b):
+                n, (h, w) = len(b[3]), (b[2][0] // 8, b[2][1] // 8)
+                a = buf.float().cpu().numpy()
+                p = 0
+                parts = []
+                for c in chans:
+                    parts.append(a[p:p + n * c * h * w].reshape(n, c, h, w))
+                    p += n * c * h * w
+                for j, k in enumerate(b[3]):
+                    maps[k] = {name: parts[q][j] for q, name in enumerate(MAP_NAMES)}
+
+            for bi, b in enumerate(mine):
+                unpack(payload[bi], b)
+            for (r, k), buf in recv.items():
+                unpack(buf, batches_of[r][k])
+        return poses, maps
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _run_host(self, images, items, mine, want_maps):
+        """Host pipeline of this rank: pre-processing in NumPy (or the net's synchronous image entry), one batch at a time."""
+        by_shape, by_source = {}, {}
+        for k in mine:
+            if self.image_entry:
+                by_source.setdefault((images[items[k][0]].shape[:2], items[k][1]), []).append(k)
+            else:
+                by_shape.setdefault(items[k][2], []).append(k)
+        poses, maps = {}, {}
+        for key in sorted(by_source):
+            ks, s = by_source[key], key[1]
+            for b0 in range(0, len(ks), self.max_batch):
+                chunk = ks[b0:b0 + self.max_batch]
+                out = self.net.forward_images(np.stack([images[items[k][0]] for k in chunk]), s,
+                                              want=MAP_NAMES if want_maps else (), pose=True)
+                for j, k in enumerate(chunk):
+                    poses[k] = out["pose"][j]
+                    if want_maps:
+                        maps[k] = {name: out[name][j].copy() for name in MAP_NAMES}
+        for hw in sorted(by_shape):
+            ks = by_shape[hw]
+            for b0 in range(0, len(ks), self.max_batch):
+                chunk = ks[b0:b0 + self.max_batch]
+                batch = np.stack([self.preprocess(images[items[k][0]], items[k][1]).transpose(2, 0, 1) for k in chunk])
+                out = self.net.forward_batch(np.ascontiguousarray(batch, np.float32), want=MAP_NAMES if want_maps else ())
+                # one decode per distinct scale in the chunk (the division by the scale is part of the decode)
+                for s in sorted(set(items[k][1] for k in chunk)):
+                    dec = self.net.decode_pose(s)
+                    for j, k in enumerate(chunk):
+                        if items[k][1] == s:
+                            poses[k] = dec[j]
+                if want_maps:
+                    for j, k in enumerate(chunk):
+                        maps[k] = {name: out[name][j].copy() for name in out}
+        return poses, maps
+
+    def _use_device_pipeline(self):
+        if not (self.image_entry and hasattr(self.net, "forward_images_device") and hasattr(self.net, "emit_maps_device")):
+            return False
+        try:
+            import torch
+
+            return torch.cuda.is_available()
+        except Exception:
+            return False
 
     def run(self, images, scales, want_maps=False):
         """images: list of HxWx3 BGR uint8 (the same list on every rank).  Returns on rank 0 a dict
@@ -116,65 +283,43 @@ class ShardedPoseRunner(object):
         dist = _dist()
         world = dist.get_world_size(self.group) if dist else 1
         rank = dist.get_rank(self.group) if dist else 0
-        items, shards = plan_work([im.shape[:2] for im in images], scales, world)
+        shapes = [im.shape[:2] for im in images]
+        items, shards = plan_work(shapes, scales, world)
         mine = shards[rank]
-        by_shape = {}
-        by_source = {}
-        for k in mine:
-            if self.image_entry:
-                by_source.setdefault((images[items[k][0]].shape[:2], items[k][1]), []).append(k)
-            else:
-                by_shape.setdefault(items[k][2], []).append(k)
-        poses = {}
-        maps = {}
-        if by_source and self.depth > 1 and not want_maps and hasattr(self.net, "forward_images_device"):
-            self._run_in_flight(images, items, by_source, poses)
-            by_source = {}
-        for key in sorted(by_source):
-            ks, s = by_source[key], key[1]
-            for b0 in range(0, len(ks), self.max_batch):
-                chunk = ks[b0:b0 + self.max_batch]
-                out = self.net.forward_images(np.stack([images[items[k][0]] for k in chunk]), s,
-                                              want=("prob", "loc_pred", "next_pred") if want_maps else (), pose=True)
-                for j, k in enumerate(chunk):
-                    poses[k] = out["pose"][j]
-                    if want_maps:
-                        maps[k] = {name: out[name][j].copy() for name in ("prob", "loc_pred", "next_pred")}
-        for hw in sorted(by_shape):
-            ks = by_shape[hw]
-            for b0 in range(0, len(ks), self.max_batch):
-                chunk = ks[b0:b0 + self.max_batch]
-                batch = np.stack([self.preprocess(images[items[k][0]], items[k][1]).transpose(2, 0, 1) for k in chunk])
-                out = self.net.forward_batch(np.ascontiguousarray(batch, np.float32),
-                                             want=("prob", "loc_pred", "next_pred") if want_maps else ())
-                # one decode per distinct scale in the chunk (the division by the scale is part of the decode)
-                for s in sorted(set(items[k][1] for k in chunk)):
-                    dec = self.net.decode_pose(s)
-                    for j, k in enumerate(chunk):
-                        if items[k][1] == s:
-                            poses[k] = dec[j]
-                if want_maps:
-                    for j, k in enumerate(chunk):
-                        maps[k] = {name: out[name][j].copy() for name in out}
-        nj = next(iter(poses.values())).shape[1] if poses else 14
+        on_device = self._use_device_pipeline()
+        if on_device:
+            batches_of = [rank_batches(shapes, items, shards[r], self.max_batch) for r in range(world)]
+            poses, maps = self._run_device(images, items, batches_of, rank, world, want_maps, dist)
+        else:
+            poses, maps = self._run_host(images, items, mine, want_maps)
+        if poses:
+            nj = next(iter(poses.values())).shape[1]
+        elif hasattr(self.net, "blobs"):
+            nj = self.net.blobs["prob"].shape[1]  # a rank without work items still sizes the table from the model
+        else:
+            nj = 14
         ncol = 2 + 5 * nj  # item index, channels of next_pred (0 when maps are not kept), the pose
         local = np.zeros((len(mine), ncol), np.float64)
         for row, k in enumerate(mine):
             local[row, 0] = k
-            local[row, 1] = maps[k]["next_pred"].shape[0] if want_maps else 0
+            local[row, 1] = maps[k]["next_pred"].shape[0] if (want_maps and k in maps) else 0
             local[row, 2:] = poses[k].reshape(-1)
         if world > 1:
-            dev = self.device if self.device is not None else "cpu"
-            got = gather_maps(torch.from_numpy(local).to(dev), dst=0, group=self.group)
+            dev = self._comm_device(dist, self._torch_device() if on_device else None)
+            if dev is None:
+                dev = "cpu"
+            sizes = [len(shards[r]) * ncol for r in range(world)]  # known from the schedule: no header exchange
+            got = gather_maps_known(torch.from_numpy(local).reshape(-1).to(dev), sizes, 0, self.group)
             map_bufs = None
-            if want_maps:
-                flat = np.concatenate([np.concatenate([maps[k][n].reshape(-1) for n in ("prob", "loc_pred", "next_pred")])
+            if want_maps and not on_device:  # host pipeline: the maps follow in one gather at the end
+                flat = np.concatenate([np.concatenate([maps[k][n].reshape(-1) for n in MAP_NAMES])
                                        for k in mine]) if mine else np.zeros(0, np.float32)
                 map_bufs = gather_maps(torch.from_numpy(flat.astype(np.float32)).to(dev), dst=0, group=self.group)
             if rank != 0:
                 return None
-            table = np.concatenate([g.cpu().numpy().reshape(-1, ncol) for g in got if g.numel()], axis=0)
-            if want_maps:
+            rows = [g.cpu().numpy().reshape(-1, ncol) for g in got if g.numel()]
+            table = np.concatenate(rows, axis=0) if rows else np.zeros((0, ncol))
+            if map_bufs is not None:
                 next_ch = {int(row[0]): int(row[1]) for row in table}
                 maps = {}
                 for r in range(world):

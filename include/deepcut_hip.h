@@ -84,6 +84,7 @@ int dc_net_clone(dc_net* net, dc_net** out);
 /* wait for everything enqueued on the net's own stream (see DC_STREAM_OWN)                                */
 int dc_net_synchronize(dc_net* net);
 int dc_net_set_option(dc_net* net, int key, int value);
+int dc_net_get_option(dc_net* net, int key, int* value);
 /* Net::CopyTrainedLayersFrom(file) (net.cpp:805-858): match by layer name, check blob
  * count and shape, ignore unmatched source layers.  Formats: binary NetParameter in the current
  * `layer` form or the deprecated V1 / V0 `layers` form (upgraded as upgrade_proto.cpp:19-78 does),
@@ -153,6 +154,12 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev_ptr, int* channel_pitch);
 #define DC_STREAM_OWN ((void*)-1)
 int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
                          float* prob, float* loc_pred, float* next_pred, void* stream);
+
+/* The maps of the LAST forward copied out as NCHW, host or device destination, any pointer NULL to skip: elem 0 =
+ * float32; elem 1 = float16, offered by fp16 nets (DC_OPT_DTYPE 1) only — the values as they are in HBM, i.e. half the
+ * bytes for the gather of the maps to rank 0 (no reference counterpart; Blob::cpu_data of the three outputs).
+ * stream as dc_net_forward_batch.                                                                             */
+int dc_net_emit_maps(dc_net* net, void* prob, void* loc_pred, void* next_pred, int elem, int is_device, void* stream);
 
 /* ---- pose decoding on the device (python/pose/estimate_pose.py:131-143 `_pose_from_mats`): after a
  * forward, writes pose[n][5][J] doubles (x, y, confidence, and the refinement vector in the reference's
