@@ -108,12 +108,12 @@ def test_config2_fp16_batch8_every_pyramid_scale(gpu_caffe, synth152, scale_hw):
     j = 3
     ref = O.OracleNet(deepercut_prototxt(152, h, w, 1), layers).forward(data=imgs[j:j + 1])
     _fp16_check({k: v[j:j + 1] for k, v in a.items()}, ref)
+    pose = net.decode_pose(h / 544.0)  # the device decode reads the half maps of the batch
+    assert pose.shape == (8, 5, 14) and np.isfinite(pose).all()
     one = net.forward_batch(imgs[5:6])
     for k in a:
         rng = max(1.0, float(np.abs(a[k]).max()))
         assert float(np.abs(a[k][5] - one[k][0]).max()) <= 4e-3 * rng, k
-    pose = net.decode_pose(h / 544.0)
-    assert pose.shape == (8, 5, 14) and np.isfinite(pose).all()
 
 
 def _crowd_crops():
@@ -201,11 +201,14 @@ def test_pyramid_shapes_are_lowered_and_captured_once(gpu_caffe, synth152):
     assert st["buffer_growths"] == st1["buffer_growths"] and st["repacks"] == 1
     # without the reservation a growing buffer costs re-captures of the stale graphs, never a re-lowering
     net2 = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    own = {}
     for cycle in range(3):
         for s in shapes:
             out = net2.forward_batch(imgs[s])
             for k in out:
-                assert np.array_equal(out[k], first[s][k])
+                # another net times its tiles itself: equal to the first net up to fp32 summation order, bit-identical to itself
+                assert np.abs(out[k] - first[s][k]).max() <= 1e-4, (s, k)
+                assert np.array_equal(out[k], own.setdefault((s, k), out[k].copy())), (cycle, s, k)
     assert net2.stats()["lowerings"] == 4 and net2.stats()["graph_instantiations"] <= 8
 
 
