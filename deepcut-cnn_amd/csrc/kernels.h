@@ -24,7 +24,7 @@ constexpr int kMaxClasses = 4;
 struct ConvClass {
   int nty, ntx, dy0, ddy, x0, ddx, Ktot, x_bias;
   int OH, OW, M;
-  int blk0;             // first workgroup of the class (filled by launch_conv_gemm)
+  int tiles_m;          // m tiles of the class (filled by launch_conv_gemm)
   unsigned div_ohw[2];  // (filled by launch_conv_gemm)
   unsigned div_ow[2];
   long w_off;           // element offset of the class's filter image inside `w`
@@ -69,6 +69,7 @@ struct ConvGemmParams {
   // --- multi-class launches (the stride-2 deconvolution heads): ncls > 1 and cls[0..ncls) replace the single-problem
   //     fields nty..x_bias / Ktot / OH / OW / M above; sy, sx, klen, strides, Cout, epilogue are common to all classes
   int ncls;
+  int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)
   ConvClass cls[kMaxClasses];
 };
 

@@ -125,18 +125,31 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   long c_woff = 0, c_yoff = 0;
   int tile_n, tile_m;
   if constexpr (MC) {
-    int c = 0;
+    // Workgroup b runs on XCD (b % 8), each with its own L2.  XCD (qx, qy) of a gx x gy arrangement owns the n tiles
+    // [tn*qx/gx, tn*(qx+1)/gx) and, of EVERY class, the m tiles [tm*qy/gy, tm*(qy+1)/gy); it walks its classes heaviest
+    // first.  So an L2 fetches 1/gx of the filter images and 1/gy of the pixels instead of everything (the heads'
+    // filters alone are 30 MB against 4 MB of L2).  The grid is 8 x the longest XCD list; surplus workgroups exit.
+    const int xq = blockIdx.x & 7, lgx = p.mc_lgx, lgy = 3 - lgx;
+    const int qx = xq & ((1 << lgx) - 1), qy = xq >> lgx;
+    const int n_lo = (p.tiles_n * qx) >> lgx, n_cnt = ((p.tiles_n * (qx + 1)) >> lgx) - n_lo;
+    int slot = blockIdx.x >> 3, c = -1, m_lo = 0;
 #pragma unroll
-    for (int k = 1; k < kMaxClasses; ++k)
-      if (k < p.ncls && (int)blockIdx.x >= p.cls[k].blk0) c = k;
+    for (int k = 0; k < kMaxClasses; ++k)
+      if (k < p.ncls && c < 0) {
+        const int lo = (p.cls[k].tiles_m * qy) >> lgy;
+        const int cnt = (((p.cls[k].tiles_m * (qy + 1)) >> lgy) - lo) * n_cnt;
+        if (slot < cnt) c = k, m_lo = lo;
+        else slot -= cnt;
+      }
+    if (c < 0) return;
     const ConvClass& q = p.cls[c];
     c_Ktot = q.Ktot, c_nty = q.nty, c_ntx = q.ntx, c_dy0 = q.dy0, c_ddy = q.ddy, c_x0 = q.x0, c_ddx = q.ddx, c_xbias = q.x_bias;
     c_OH = q.OH, c_OW = q.OW, c_M = q.M;
     c_dohw[0] = q.div_ohw[0], c_dohw[1] = q.div_ohw[1], c_dow[0] = q.div_ow[0], c_dow[1] = q.div_ow[1];
     c_woff = q.w_off, c_yoff = q.y_off;
-    const int local = (int)blockIdx.x - q.blk0;  // n-fastest inside the class: neighbours share the pixel rows
-    tile_m = dc_fastdiv(local, p.div_tn);
-    tile_n = local - tile_m * p.tiles_n;
+    const int sr = slot / n_cnt;  // uniform
+    tile_m = m_lo + sr;
+    tile_n = n_lo + (slot - sr * n_cnt);
   } else if (p.xcd_on) {
     const int q = blockIdx.x & 7, slot = blockIdx.x >> 3;  // XCD, position inside its rectangle
     const int n_lo = p.xcd_rect[q][0], rw = p.xcd_rect[q][1], m_lo = p.xcd_rect[q][2], rh = p.xcd_rect[q][3];
@@ -569,8 +582,7 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
     if ((double)e.esize * p.NB * (double)p.x_img_stride >= lim || (double)e.esize * p.NB * (double)p.y_img_stride >= lim)
       return (int)hipErrorInvalidValue;
     const long tn = (p.Cout + e.v.BN - 1) / e.v.BN;
-    long blk = 0;
-    double wtot = 0;
+    double wtot = 0, atot = 0;
     for (int c = 0; c < p.ncls; ++c) {
       ConvClass& q = p.cls[c];
       const int ntaps = q.nty * q.ntx;
@@ -581,14 +593,36 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
       q.x_bias = bias;
       magic_of((unsigned)(q.OH * q.OW), q.div_ohw);
       magic_of((unsigned)q.OW, q.div_ow);
-      q.blk0 = (int)blk;
-      blk += (q.M + e.v.BM - 1) / e.v.BM * tn;
+      q.tiles_m = (q.M + e.v.BM - 1) / e.v.BM;
       wtot += (double)e.esize * p.Cout * (double)q.Ktot;
+      atot += (double)e.esize * q.M * (double)p.klen * q.nty;
     }
-    if (wtot >= lim || blk > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    if (wtot >= lim) return (int)hipErrorInvalidValue;
     p.tiles_n = (int)tn;
     magic_of((unsigned)tn, p.div_tn);
     p.xcd_on = 0;
+    // XCD arrangement gx x gy minimising what one L2 has to fetch (its share of the filters + its share of the pixels)
+    long blk = 0;
+    {
+      double best = 1e300;
+      for (int lgx = 0; lgx <= 3; ++lgx) {
+        const int gx = 1 << lgx, gy = 8 >> lgx;
+        if (gx > tn) continue;
+        long longest = 0;
+        for (int xq = 0; xq < 8; ++xq) {
+          const int qx = xq & (gx - 1), qy = xq >> lgx;
+          const long ncnt = ((tn * (qx + 1)) >> lgx) - ((tn * qx) >> lgx);
+          long cnt = 0;
+          for (int c = 0; c < p.ncls; ++c) cnt += ((((long)p.cls[c].tiles_m * (qy + 1)) >> (3 - lgx)) - (((long)p.cls[c].tiles_m * qy) >> (3 - lgx))) * ncnt;
+          longest = std::max(longest, cnt);
+        }
+        long total = 0;
+        for (int c = 0; c < p.ncls; ++c) total += p.cls[c].tiles_m * tn;
+        const double cost = (wtot / gx + atot / gy) * (1.0 + 0.02 * (longest * 8 - total) / (double)std::max(total, 1L));
+        if (cost < best) best = cost, p.mc_lgx = lgx, blk = longest * 8;
+      }
+    }
+    if (blk <= 0 || blk > 0x7fffffffL) return (int)hipErrorInvalidValue;
     const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
     hipLaunchKernelGGL(e.kernel_mc, dim3((unsigned)blk), dim3(nt), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
@@ -702,7 +736,16 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
   const int TY = ((p.OH + d - 1) / d + 1) >> 1, TX = ((p.OW + d - 1) / d + 1) >> 1;
   const int NBY = (TY + WBTY - 1) / WBTY, NBX = (TX + WBTX - 1) / WBTX;
   const int nblk = p.NB * d * d * NBY * NBX;
-  const int nt = blockIdx.x / nblk, blk = blockIdx.x - nt * nblk;  // same-filter workgroups are adjacent
+  // Workgroup b runs on XCD (b % 8), each XCD with its own L2.  The transformed filters are the big stream (16/9 of the
+  // filter bytes), shared by the nblk workgroups of a 16-channel slice: hand every XCD a CONTIGUOUS range of the
+  // (slice-major) logical grid, so that a slice is fetched from HBM by one L2 (two at a range boundary) instead of by
+  // all eight.  A locality hint only: any bijection of the grid computes the same result.
+  int lb = blockIdx.x;
+  if (p.xcd_on) {
+    const int g8 = gridDim.x >> 3, r8 = gridDim.x & 7, q = blockIdx.x & 7;
+    lb = q * g8 + min(q, r8) + (blockIdx.x >> 3);
+  }
+  const int nt = lb / nblk, blk = lb - nt * nblk;  // same-filter workgroups are adjacent in the logical grid
   const int nph = blk / (NBY * NBX), brem = blk - nph * (NBY * NBX);
   const int n = nph / (d * d), ph = nph - n * (d * d);
   const int phy = ph / d, phx = ph - phy * d;
@@ -879,7 +922,10 @@ int launch_wino_conv(const ConvGemmParams& p, void* stream) {
   const long grid = wino_grid(p);
   if (grid <= 0) return 0;
   if (grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(wino_f23_kernel, dim3((unsigned)grid), dim3(WNTH), 0, (hipStream_t)stream, p);
+  ConvGemmParams q = p;
+  static const int xcd_map = getenv("DC_XCD_MAP") ? atoi(getenv("DC_XCD_MAP")) : 1;
+  q.xcd_on = xcd_map && grid >= 16;
+  hipLaunchKernelGGL(wino_f23_kernel, dim3((unsigned)grid), dim3(WNTH), 0, (hipStream_t)stream, q);
   return (int)hipGetLastError();
 }
 

@@ -1749,7 +1749,7 @@ void Net::run_launch(const Launch& l, void* s) {
         // device-side phase timestamps of ONE launch (diagnostics only): wall clock (100 MHz) at
         // start / loop entry / loop exit / end, and the shader cycle counter at the same points
         const int nwv = conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
-        const long n = l.grid * nwv * 8;
+        const long n = (l.grid * 2 + 64) * nwv * 8;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
         HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
@@ -1766,7 +1766,7 @@ void Net::run_launch(const Launch& l, void* s) {
         // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
         double dsum[8] = {0};
         long cnt = 0;
-        for (long i = 0; i < l.grid * nwv; ++i) {
+        for (long i = 0; i < (l.grid * 2 + 64) * nwv; ++i) {
           const long long* w = &h[i * 8];
           if (w[7] == 0) continue;  // workgroup of the padded XCD grid that exited at once
           for (int k = 1; k < 8; ++k) dsum[k] += (double)(w[k] - w[k - 1]);
