@@ -33,6 +33,11 @@ int guard(F&& f) {
     return fail(DC_EINVAL, e.what());
   }
 }
+// stand-alone blobs (dc_blob_create) move on the default stream of the calling thread's device (Caffe::SetDevice)
+void standalone_device() {
+  if (device_count() <= 0) throw DcError(DC_EDEVICE, "no HIP device visible");
+  if (hipSetDevice(Context::get().device) != hipSuccess) throw DcError(DC_EDEVICE, "hipSetDevice failed");
+}
 inline Net* N(dc_net* n) { return reinterpret_cast<Net*>(n); }
 inline NetBlob* B(dc_blob* b) { return reinterpret_cast<NetBlob*>(b); }
 #define REQUIRE(p)                                                   \
@@ -235,8 +240,8 @@ static int blob_host(dc_blob* b, float** out, bool mut) {
       throw DcError(DC_EUNSUP, "blob '" + B(b)->name + "' is folded into a fused kernel in the current plan and never "
                                 "materialised; create the net with DC_OPT_FUSE 0 to observe it");
     if (s.head == HEAD_AT_GPU) {
-      if (!s.owner) throw DcError(DC_EINVAL, "orphan blob");
-      s.owner->sync_to_host(s);
+      if (s.owner) s.owner->sync_to_host(s);
+      else standalone_device(), storage_to_host(s, nullptr, nullptr);
     }
     *out = s.host_ptr();
     if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
@@ -270,8 +275,8 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev, int* pitch) {
     Storage& s = *B(b)->st;
     if (s.is_param) throw DcError(DC_EUNSUP, "parameters are packed per kernel on the device; no NHWC image exists");
     if (s.view_of < 0 && (s.head == HEAD_AT_CPU || s.head == UNINITIALIZED)) {
-      if (!s.owner) throw DcError(DC_EINVAL, "orphan blob");
-      s.owner->sync_to_device(s);
+      if (s.owner) s.owner->sync_to_device(s);
+      else standalone_device(), storage_to_device(s, nullptr);
     }
     if (s.view_of >= 0) {  // channel slice of a concatenated head tensor
       Storage& base = *s.owner->storages[s.view_of];
@@ -281,6 +286,87 @@ int dc_blob_gpu_data(dc_blob* b, const void** dev, int* pitch) {
       *dev = s.dev;
       if (pitch) *pitch = s.cp();
     }
+  });
+}
+
+int dc_blob_create(int ndim, const int* dims, dc_blob** out) {
+  REQUIRE(out);
+  *out = nullptr;
+  if (ndim < 0 || ndim > 8 || (ndim > 0 && !dims)) return fail(DC_EINVAL, "bad number of axes");
+  return guard([&] {
+    std::unique_ptr<NetBlob> b(new NetBlob());
+    b->standalone = true;
+    b->st = std::make_shared<Storage>();
+    b->st->reshape(std::vector<int>(dims, dims + ndim));
+    *out = reinterpret_cast<dc_blob*>(b.release());
+  });
+}
+int dc_blob_destroy(dc_blob* b) {
+  if (!b) return DC_OK;
+  if (!B(b)->standalone) return fail(DC_EINVAL, "this blob belongs to a net");
+  delete B(b);
+  return DC_OK;
+}
+int dc_blob_mutable_gpu_data(dc_blob* b, void** dev, int* pitch) {
+  REQUIRE(b);
+  REQUIRE(dev);
+  return guard([&] {
+    Storage& s = *B(b)->st;
+    if (s.is_param) throw DcError(DC_EUNSUP, "parameters are packed per kernel on the device; no NHWC image exists");
+    if (s.view_of >= 0 || s.elided)
+      throw DcError(DC_EUNSUP, "blob '" + B(b)->name + "' is fused into another tensor in the current plan; use DC_OPT_FUSE 0");
+    if (s.owner) {
+      s.owner->sync_to_device(s);
+      s.head = HEAD_AT_GPU;
+    } else {
+      standalone_device();
+      storage_mutable_device(s, nullptr);
+    }
+    *dev = s.dev;
+    if (pitch) *pitch = s.cp();
+  });
+}
+int dc_blob_copy_from(dc_blob* dst, dc_blob* src, int reshape) {
+  REQUIRE(dst);
+  REQUIRE(src);
+  return guard([&] {
+    Storage &d = *B(dst)->st, &s = *B(src)->st;
+    if (s.elided && !s.is_param) throw DcError(DC_EUNSUP, "source blob '" + B(src)->name + "' is never materialised in the current plan");
+    if (d.shape != s.shape) {  // Blob::CopyFrom (blob.cpp:435-443)
+      if (!reshape) throw DcError(DC_ESHAPE, "Trying to copy blobs of different sizes.");
+      if (d.is_param) throw DcError(DC_EINVAL, "parameter blobs cannot be reshaped");
+      d.reshape(s.shape);
+    }
+    Net* own = d.owner ? d.owner : s.owner;
+    void* stream = nullptr;
+    if (s.head == HEAD_AT_GPU) {
+      if (own) {
+        own->synchronize();
+        stream = own->stream;
+        if (hipSetDevice(own->device >= 0 ? own->device : Context::get().device) != hipSuccess) throw DcError(DC_EDEVICE, "hipSetDevice failed");
+      } else {
+        standalone_device();
+      }
+    }
+    storage_copy(d, s, s.view_of >= 0 && s.owner ? s.owner->storages[s.view_of].get() : nullptr, stream);
+    if (d.is_param && d.shared) {
+      std::lock_guard<std::mutex> lk(d.shared->mu);
+      d.shared->touched.push_back(B(dst)->st);
+    }
+  });
+}
+int dc_net_create_for_layer(const char* layer_text, int phase, int nbottom, dc_blob* const* bottoms, dc_net** out) {
+  REQUIRE(layer_text);
+  REQUIRE(out);
+  *out = nullptr;
+  if (nbottom < 0 || (nbottom > 0 && !bottoms)) return fail(DC_EINVAL, "bad bottom list");
+  return guard([&] {
+    std::vector<std::vector<int>> shapes;
+    for (int i = 0; i < nbottom; ++i) {
+      if (!bottoms[i]) throw DcError(DC_EINVAL, "null bottom blob");
+      shapes.push_back(B(bottoms[i])->st->shape);
+    }
+    *out = reinterpret_cast<dc_net*>(Net::create_for_layer(layer_text, phase, shapes));
   });
 }
 

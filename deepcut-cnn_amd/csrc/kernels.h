@@ -132,14 +132,13 @@ int launch_f32_to_f16(const float* src, void* dst, long n, void* stream);
 // invert is the label ENCODING of its training layer (src/caffe/layers/pose_data_layer.cpp:686-802): a cell (row, col)
 // stands for the image point pt = (col*8 + 4, row*8 + 4) / scale; loc_pred holds (joint - pt)*scale / sqrt(53);
 // next_pred channel pair l holds ((next joint - pt)*scale - mean[l]) / std[l] for regression edge l.
-// part_nms: local maxima of every score map (value >= thr, maximal in the (2r+1)^2 window, ties to the lower cell index),
-//           appended unordered to cand[(n*J+j)*cap ...] as (score bits, cell index); cnt[(n*J+j)] counts them (may exceed cap).
-int launch_part_nms(const void* prob, int pcp, int pc0, int esize, int NB, int H, int W, int J, float thr, int radius, int cap,
-                    int* cnt, unsigned long long* cand, void* stream);
-// part_emit: per (n, j) sorts its candidates by (score desc, cell asc) and writes the first max_det as
-//           out[((n*J+j)*max_det + k)*5 + {0..4}] = x, y, score, row, col  (x, y refined with loc_pred and divided by scale)
-int launch_part_emit(const void* loc, int lcp, int lc0, int esize, int NB, int H, int W, int J, double scale, int cap, int max_det,
-                     int* cnt, unsigned long long* cand, double* out, void* stream);
+// part_select: per (image, joint) map, the local maxima (value >= thr, maximal in the (2r+1)^2 window, ties to the lower
+//           cell index) ordered by (score desc, cell asc); the first max_det go to
+//           out[((n*J+j)*max_det + k)*5 + {0..4}] = x, y, score, row, col (x, y refined with loc_pred and divided by scale),
+//           counts[n*J+j] = how many were written.  Deterministic for every input (no arrival-order truncation).
+//           spill: NB*J*H*W keys of scratch.
+int launch_part_select(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H, int W, int J, float thr,
+                       int radius, double scale, int max_det, unsigned long long* spill, int* counts, double* out, void* stream);
 // pairwise: out[(d*E + l)*2 + k] = pt_k + (next_pred[2l+k] at the detection's cell * std[l][k] + mean[l][k]) / scale
 int launch_pairwise_decode(const void* next, int ncp, int nc0, int esize, int NB, int H, int W, int E, double scale, int ndet,
                            const int* det /* [ndet][3] image, row, col */, const double* mean, const double* stdev, double* out,

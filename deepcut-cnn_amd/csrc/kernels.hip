@@ -1264,74 +1264,110 @@ int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int 
 }
 
 // ---- multi-person consumers: part candidates (NMS) and pairwise regression decode ------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void part_nms_kernel(const T* __restrict__ prob, int pcp, int pc0, int NB, int H, int W, int J,
-                                                       float thr, int radius, int cap, int* __restrict__ cnt,
-                                                       unsigned long long* __restrict__ cand) {
-  const long total = (long)NB * J * H * W;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int col = (int)(i % W);
-  long t = i / W;
-  const int row = (int)(t % H);
-  t /= H;
-  const int j = (int)(t % J), n = (int)(t / J);
-  const T* base = prob + ((long)n * H * W) * pcp + pc0 + j;
-  const float v = (float)base[((long)row * W + col) * pcp];
-  if (!(v >= thr)) return;
-  const int me = row * W + col;
-  for (int dy = -radius; dy <= radius; ++dy) {
-    const int y = row + dy;
-    if (y < 0 || y >= H) continue;
-    for (int dx = -radius; dx <= radius; ++dx) {
-      const int x = col + dx;
-      if (x < 0 || x >= W || (dy == 0 && dx == 0)) continue;
-      const float u = (float)base[((long)y * W + x) * pcp];
-      if (u > v || (u == v && y * W + x < me)) return;  // not the maximum of its window (ties: the lower cell index wins)
-    }
-  }
-  const int slot = atomicAdd(cnt + n * J + j, 1);
-  if (slot < cap) cand[(long)(n * J + j) * cap + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)me;
-}
+// One workgroup per (image, joint) score map.  Every cell is tested for being the maximum of its (2r+1)^2 window (ties: the
+// lower cell index wins) and, if so, becomes the 64-bit key (score bits << 32 | ~cell): keys are unique, and descending key
+// order IS the output order (score descending, cell ascending).  The candidate SET does not depend on thread timing, and
+// the list is then ordered by the whole workgroup: up to kPartLds keys by a bitonic sort in LDS; a map with more local
+// maxima than that (threshold 0, radius 0) spills its keys to global memory and takes the first max_det by repeated
+// workgroup-wide maximum.  Nothing is dropped in arrival order, so the result is deterministic for every input.
+constexpr int kPartLds = 4096;  // keys sorted in LDS (32 KB)
 
 template <typename T>
-__global__ __launch_bounds__(64) void part_emit_kernel(const T* __restrict__ loc, int lcp, int lc0, int H, int W, int J, double scale,
-                                                       int cap, int max_det, const int* __restrict__ cnt,
-                                                       unsigned long long* __restrict__ cand, double* __restrict__ out) {
-  const int nj = blockIdx.x, n = nj / J, j = nj - n * J;
-  if (threadIdx.x != 0) return;  // lists are short (<= cap): one lane sorts
-  const int m = min(cnt[nj], cap);
-  unsigned long long* c = cand + (long)nj * cap;
-  // order: score descending (non-negative floats compare like their bit patterns), then cell index ascending
-  for (int a = 1; a < m; ++a) {
-    const unsigned long long key = c[a];
-    int b = a - 1;
-    auto before = [](unsigned long long p, unsigned long long q) {
-      const unsigned ps = (unsigned)(p >> 32), qs = (unsigned)(q >> 32);
-      return ps != qs ? ps > qs : (unsigned)p < (unsigned)q;
-    };
-    while (b >= 0 && before(key, c[b])) {
-      c[b + 1] = c[b];
-      --b;
+__global__ __launch_bounds__(256) void part_select_kernel(const T* __restrict__ prob, int pcp, int pc0, const T* __restrict__ loc, int lcp,
+                                                          int lc0, int H, int W, int J, float thr, int radius, double scale, int max_det,
+                                                          unsigned long long* __restrict__ spill, int* __restrict__ counts,
+                                                          double* __restrict__ out) {
+  __shared__ unsigned long long keys[kPartLds];
+  __shared__ unsigned long long red[256];
+  __shared__ int cnt;
+  const int nj = blockIdx.x, n = nj / J, j = nj - n * J, t = threadIdx.x, HW = H * W;
+  const T* base = prob + ((long)n * HW) * pcp + pc0 + j;
+  unsigned long long* mine = spill + (long)nj * HW;
+  if (t == 0) cnt = 0;
+  __syncthreads();
+  for (int cell = t; cell < HW; cell += 256) {
+    const int row = cell / W, col = cell - row * W;
+    const float v = (float)base[(long)cell * pcp];
+    bool ok = v >= thr;
+    for (int dy = -radius; ok && dy <= radius; ++dy) {
+      const int y = row + dy;
+      if (y < 0 || y >= H) continue;
+      for (int dx = -radius; dx <= radius; ++dx) {
+        const int x = col + dx;
+        if (x < 0 || x >= W || (dy == 0 && dx == 0)) continue;
+        const float u = (float)base[((long)y * W + x) * pcp];
+        if (u > v || (u == v && y * W + x < cell)) {
+          ok = false;
+          break;
+        }
+      }
     }
-    c[b + 1] = key;
+    if (ok) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)cell);
+      const int slot = atomicAdd(&cnt, 1);  // LDS counter: the slot order varies, the set and (after sorting) the result do not
+      if (slot < kPartLds) keys[slot] = key;
+      mine[slot] = key;
+    }
   }
-  const double kLoc = 7.280109889280518;  // sqrt(53)
-  for (int k = 0; k < max_det; ++k) {
-    double* o = out + ((long)nj * max_det + k) * 5;
-    if (k >= m) {
-      o[0] = o[1] = o[2] = 0.0;
-      o[3] = o[4] = -1.0;
-      continue;
-    }
-    const int cell = (int)(unsigned)c[k];
+  __syncthreads();
+  const int m = cnt;
+  const int take = min(m, max_det);
+  if (t == 0) counts[nj] = take;
+  double* o = out + (long)nj * max_det * 5;
+  auto emit = [&](int k, unsigned long long key) {
+    const double kLoc = 7.280109889280518;  // sqrt(53)
+    const int cell = (int)(0xffffffffu - (unsigned)key);
     const int row = cell / W, col = cell - row * W;
     const T* l = loc + (((long)n * H + row) * W + col) * lcp + lc0 + 2 * j;
-    o[0] = ((double)col * 8.0 + 4.0 + (double)(float)l[0] * kLoc) / scale;
-    o[1] = ((double)row * 8.0 + 4.0 + (double)(float)l[1] * kLoc) / scale;
-    o[2] = (double)__uint_as_float((unsigned)(c[k] >> 32));
-    o[3] = (double)row;
-    o[4] = (double)col;
+    double* q = o + (long)k * 5;
+    q[0] = ((double)col * 8.0 + 4.0 + (double)(float)l[0] * kLoc) / scale;
+    q[1] = ((double)row * 8.0 + 4.0 + (double)(float)l[1] * kLoc) / scale;
+    q[2] = (double)__uint_as_float((unsigned)(key >> 32));
+    q[3] = (double)row;
+    q[4] = (double)col;
+  };
+  for (int k = take + t; k < max_det; k += 256) {
+    double* q = o + (long)k * 5;
+    q[0] = q[1] = q[2] = 0.0;
+    q[3] = q[4] = -1.0;
+  }
+  if (m <= kPartLds) {
+    int P = 1;
+    while (P < m) P <<= 1;
+    for (int i = m + t; i < P; i += 256) keys[i] = 0ull;  // below every real key (scores >= 0, cell term > 0)
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+      for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        for (int i = t; i < P; i += 256) {
+          const int ixj = i ^ j2;
+          if (ixj > i) {
+            const unsigned long long a = keys[i], b = keys[ixj];
+            const bool desc = (i & k2) == 0;  // descending overall
+            if (desc ? a < b : a > b) keys[i] = b, keys[ixj] = a;
+          }
+        }
+        __syncthreads();
+      }
+    for (int k = t; k < take; k += 256) emit(k, keys[k]);
+  } else {
+    __threadfence_block();
+    unsigned long long prev = ~0ull;
+    for (int k = 0; k < take; ++k) {  // k-th largest key = the largest key below the previous one
+      unsigned long long best = 0ull;
+      for (int i = t; i < m; i += 256) {
+        const unsigned long long v = mine[i];
+        if (v < prev && v > best) best = v;
+      }
+      red[t] = best;
+      __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (t < s2 && red[t + s2] > red[t]) red[t] = red[t + s2];
+        __syncthreads();
+      }
+      prev = red[0];
+      if (t == 0) emit(k, prev);
+      __syncthreads();
+    }
   }
 }
 
@@ -1356,29 +1392,15 @@ __global__ __launch_bounds__(256) void pairwise_decode_kernel(const T* __restric
   o[1] = ((double)row * 8.0 + 4.0 + (double)(float)p[1] * s1 + m1) / scale;
 }
 
-int launch_part_nms(const void* prob, int pcp, int pc0, int esize, int NB, int H, int W, int J, float thr, int radius, int cap,
-                    int* cnt, unsigned long long* cand, void* stream) {
-  const long total = (long)NB * J * H * W;
-  if (total <= 0) return 0;
-  const dim3 grid((unsigned)((total + 255) / 256));
-  if (esize == 2)
-    hipLaunchKernelGGL(part_nms_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)prob, pcp, pc0, NB, H, W, J,
-                       thr, radius, cap, cnt, cand);
-  else
-    hipLaunchKernelGGL(part_nms_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)prob, pcp, pc0, NB, H, W, J, thr,
-                       radius, cap, cnt, cand);
-  return (int)hipGetLastError();
-}
-
-int launch_part_emit(const void* loc, int lcp, int lc0, int esize, int NB, int H, int W, int J, double scale, int cap, int max_det,
-                     int* cnt, unsigned long long* cand, double* out, void* stream) {
+int launch_part_select(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H, int W, int J, float thr,
+                       int radius, double scale, int max_det, unsigned long long* spill, int* counts, double* out, void* stream) {
   if (NB * J <= 0) return 0;
   if (esize == 2)
-    hipLaunchKernelGGL(part_emit_kernel<_Float16>, dim3(NB * J), dim3(64), 0, (hipStream_t)stream, (const _Float16*)loc, lcp, lc0, H, W, J,
-                       scale, cap, max_det, cnt, cand, out);
+    hipLaunchKernelGGL(part_select_kernel<_Float16>, dim3(NB * J), dim3(256), 0, (hipStream_t)stream, (const _Float16*)prob, pcp, pc0,
+                       (const _Float16*)loc, lcp, lc0, H, W, J, thr, radius, scale, max_det, spill, counts, out);
   else
-    hipLaunchKernelGGL(part_emit_kernel<float>, dim3(NB * J), dim3(64), 0, (hipStream_t)stream, (const float*)loc, lcp, lc0, H, W, J, scale,
-                       cap, max_det, cnt, cand, out);
+    hipLaunchKernelGGL(part_select_kernel<float>, dim3(NB * J), dim3(256), 0, (hipStream_t)stream, (const float*)prob, pcp, pc0,
+                       (const float*)loc, lcp, lc0, H, W, J, thr, radius, scale, max_det, spill, counts, out);
   return (int)hipGetLastError();
 }
 

@@ -1678,11 +1678,19 @@ void Net::release_graph() {
   }
 }
 
-void Net::sync_to_device(Storage& s) {
+// SyncedMemory::to_gpu (syncedmem.cpp:49-77): UNINITIALIZED -> a zeroed device image that is authoritative
+// (HEAD_AT_GPU); HEAD_AT_CPU -> upload, SYNCED.  The device image of a 4-D blob is channels-last.
+void storage_to_device(Storage& s, void* stream) {
   if (s.head == HEAD_AT_GPU || s.head == SYNCED) return;
-  ensure_device();
+  if (device_count() <= 0) throw DcError(DC_EDEVICE, "no HIP device visible");
   size_t n = s.count();
   s.ensure_dev(s.dev_count());
+  if (s.head == UNINITIALIZED) {
+    HIPCHECK(hipMemsetAsync(s.dev, 0, std::max<size_t>(s.dev_count(), 8) * (size_t)s.esize, (hipStream_t)stream));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    s.head = HEAD_AT_GPU;
+    return;
+  }
   if (s.shape.size() == 4) {
     s.ensure_stage(n);
     HIPCHECK(hipMemcpyAsync(s.stage, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -1695,19 +1703,23 @@ void Net::sync_to_device(Storage& s) {
   s.head = SYNCED;
 }
 
-void Net::sync_to_host(Storage& s) {
+void storage_mutable_device(Storage& s, void* stream) {  // syncedmem.cpp:130-139
+  storage_to_device(s, stream);
+  s.head = HEAD_AT_GPU;
+}
+
+// SyncedMemory::to_cpu (syncedmem.cpp:25-47)
+void storage_to_host(Storage& s, void* stream, Storage* base) {
   if (s.head != HEAD_AT_GPU) {
     s.host_ptr();
     if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
     return;
   }
-  ensure_device();
   size_t n = s.count();
   float* h = s.host_ptr();
-  if (s.view_of >= 0) {  // channel slice of a concatenated tensor
-    Storage& base = *storages[s.view_of];
+  if (base) {  // channel slice of a concatenated tensor
     s.ensure_stage(n);
-    KCHECK(launch_nhwc_to_nchw(base.dev, s.stage, base.esize, s.dim(0), s.dim(1), s.dim(2), s.dim(3), base.cp(), s.view_c0, stream));
+    KCHECK(launch_nhwc_to_nchw(base->dev, s.stage, base->esize, s.dim(0), s.dim(1), s.dim(2), s.dim(3), base->cp(), s.view_c0, stream));
     HIPCHECK(hipMemcpyAsync(h, s.stage, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   } else if (s.shape.size() == 4) {
     s.ensure_stage(n);
@@ -1719,6 +1731,67 @@ void Net::sync_to_host(Storage& s) {
   }
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
   s.head = SYNCED;
+}
+
+void storage_copy(Storage& dst, Storage& src, Storage* src_base, void* stream) {
+  if (dst.count() != src.count()) throw DcError(DC_ESHAPE, "Trying to copy blobs of different sizes.");  // blob.cpp:437-443
+  if (&dst == &src) return;
+  const size_t n = src.count();
+  if (src.head == HEAD_AT_GPU) {  // device -> device; the two images may differ in channel pitch / element type
+    dst.ensure_dev(dst.dev_count());
+    if (src.shape.size() == 4 && dst.shape.size() == 4) {
+      if (dst.shape != src.shape) throw DcError(DC_ESHAPE, "device copy needs equal 4-D shapes");
+      dst.ensure_stage(n);
+      Storage& img = src_base ? *src_base : src;
+      KCHECK(launch_nhwc_to_nchw(img.dev, dst.stage, img.esize, src.dim(0), src.dim(1), src.dim(2), src.dim(3), img.cp(),
+                                 src_base ? src.view_c0 : 0, stream));
+      KCHECK(launch_nchw_to_nhwc(dst.stage, dst.dev, dst.esize, dst.dim(0), dst.dim(1), dst.dim(2), dst.dim(3), dst.cp(), stream));
+    } else if (src.shape.size() != 4 && dst.shape.size() != 4) {
+      HIPCHECK(hipMemcpyAsync(dst.dev, src.dev, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    } else {
+      throw DcError(DC_ESHAPE, "device copy between a 4-D and a non-4-D blob");
+    }
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    dst.head = HEAD_AT_GPU;
+    return;
+  }
+  std::memcpy(dst.host_ptr(), src.host_ptr(), n * sizeof(float));  // UNINITIALIZED source: zeros (first touch zero-fills)
+  dst.head = HEAD_AT_CPU;
+}
+
+void Net::sync_to_device(Storage& s) {
+  if (s.head == HEAD_AT_GPU || s.head == SYNCED) return;
+  ensure_device();
+  storage_to_device(s, stream);
+}
+
+void Net::sync_to_host(Storage& s) {
+  if (s.head == HEAD_AT_GPU) ensure_device();
+  storage_to_host(s, stream, s.view_of >= 0 ? storages[s.view_of].get() : nullptr);
+}
+
+// Layer<Dtype>::SetUp for one reference layer: the layer's bottoms become the inputs of a one-layer net (same names, the
+// given shapes), so that Layer::Reshape / Forward_gpu are Net::reshape / Net::forward of that net with no fusion.
+Net* Net::create_for_layer(const std::string& layer_text, int phase, const std::vector<std::vector<int>>& bottom_shapes) {
+  TextMsg m = parse_text_proto(layer_text);
+  const TextMsg* L = &m;
+  if (m.sub("layer") && !m.has("type")) L = m.sub("layer");  // given with the enclosing `layer { }`
+  std::vector<std::string> bottoms = L->strs("bottom");
+  if (bottoms.size() != bottom_shapes.size())
+    throw DcError(DC_EINVAL, "layer '" + L->str("name") + "' declares " + std::to_string(bottoms.size()) + " bottom(s), " +
+                                 std::to_string(bottom_shapes.size()) + " given");
+  std::string text = "name: \"" + L->str("name") + "\"\n";
+  std::set<std::string> seen;
+  for (size_t i = 0; i < bottoms.size(); ++i) {
+    if (!seen.insert(bottoms[i]).second) throw DcError(DC_EUNSUP, "layer '" + L->str("name") + "': the same bottom twice");
+    text += "input: \"" + bottoms[i] + "\"\ninput_shape {";
+    for (int d : bottom_shapes[i]) text += " dim: " + std::to_string(d);
+    text += " }\n";
+  }
+  text += L == &m ? "layer {\n" + layer_text + "\n}\n" : layer_text + "\n";
+  std::unique_ptr<Net> n(Net::create(text, phase));
+  n->fuse = 0;
+  return n.release();
 }
 
 void Net::run_launch(const Launch& l, void* s) {
@@ -2231,20 +2304,18 @@ void Net::detect_parts(double scale, float thr, int radius, int max_det, int* co
   if (L.C != 2 * P.C || L.H != P.H || L.W != P.W || L.NB != P.NB || L.es != P.es)
     throw DcError(DC_ESHAPE, "detect_parts: loc_pred must have 2 channels per joint and the score map's size");
   const int lists = P.NB * P.C;
-  const int cap = std::max(max_det, 1024);  // candidates kept per map before sorting
-  const size_t cnt_b = ((size_t)lists * sizeof(int) + 255) / 256 * 256, cand_b = (size_t)lists * cap * sizeof(unsigned long long);
+  const size_t cnt_b = ((size_t)lists * sizeof(int) + 255) / 256 * 256;
+  const size_t spill_b = (size_t)lists * P.H * P.W * sizeof(unsigned long long);  // every cell may be a local maximum
   const size_t out_b = (size_t)lists * max_det * 5 * sizeof(double);
-  unsigned char* base = (unsigned char*)scratch(cnt_b + cand_b + out_b);
+  unsigned char* base = (unsigned char*)scratch(cnt_b + spill_b + out_b);
   int* cnt = (int*)base;
-  unsigned long long* cand = (unsigned long long*)(base + cnt_b);
-  double* out = (double*)(base + cnt_b + cand_b);
-  HIPCHECK(hipMemsetAsync(cnt, 0, cnt_b, (hipStream_t)stream));
-  KCHECK(launch_part_nms(P.ptr, P.cp, P.c0, P.es, P.NB, P.H, P.W, P.C, thr, radius, cap, cnt, cand, stream));
-  KCHECK(launch_part_emit(L.ptr, L.cp, L.c0, L.es, P.NB, P.H, P.W, P.C, scale, cap, max_det, cnt, cand, out, stream));
+  unsigned long long* spill = (unsigned long long*)(base + cnt_b);
+  double* out = (double*)(base + cnt_b + spill_b);
+  KCHECK(launch_part_select(P.ptr, P.cp, P.c0, L.ptr, L.cp, L.c0, P.es, P.NB, P.H, P.W, P.C, thr, radius, scale, max_det, spill, cnt, out,
+                            stream));
   HIPCHECK(hipMemcpyAsync(counts, cnt, (size_t)lists * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHECK(hipMemcpyAsync(dets, out, out_b, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
-  for (int i = 0; i < lists; ++i) counts[i] = std::min(counts[i], max_det);  // (more than `cap` local maxima: the list was cut)
 }
 
 // Pairwise regression of the next joint from a set of detections (cells), on the device.

@@ -73,7 +73,16 @@ struct Storage {
 struct NetBlob {
   std::string name;
   std::shared_ptr<Storage> st;
+  bool standalone = false;  // dc_blob_create: owned by the caller, moved on the default stream of the thread's device
 };
+
+// SyncedMemory::to_gpu / to_cpu (syncedmem.cpp:25-101) for a blob that may or may not belong to a net: `stream` is the
+// owner's stream (null: the default stream), `base` the concatenated tensor a channel view lives in (else null)
+void storage_to_device(Storage& s, void* stream);
+void storage_to_host(Storage& s, void* stream, Storage* base);
+void storage_mutable_device(Storage& s, void* stream);  // SyncedMemory::mutable_gpu_data: device image authoritative
+// Blob::CopyFrom (blob.cpp:435-474): wherever the source is authoritative; device copies re-pitch through an NCHW stage
+void storage_copy(Storage& dst, Storage& src, Storage* src_base, void* stream);
 
 struct ConvSpec {
   int num_output = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1, group = 1;
@@ -232,6 +241,8 @@ struct Net {
   void invalidate_plans();  // drop every cached plan and graph (option / weight change)
   void mark_weights_changed();  // parameter content changed: every executor re-packs and re-lowers before its next run
   void reserve(int n, int h, int w);  // lower + allocate + tune for a shape without running it
+  // one reference layer stand-alone (Layer<Dtype>::SetUp on given bottoms): a net whose inputs are the layer's bottoms
+  static Net* create_for_layer(const std::string& layer_text, int phase, const std::vector<std::vector<int>>& bottom_shapes);
   void forward(int start, int end);
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
                      float* next, void* user_stream);

@@ -87,6 +87,11 @@ def _load():
         "dc_blob_mutable_cpu_data": (ci, [vp, C.POINTER(C.POINTER(C.c_float))]),
         "dc_blob_head": (ci, [vp]),
         "dc_blob_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
+        "dc_blob_create": (ci, [ci, C.POINTER(ci), C.POINTER(vp)]),
+        "dc_blob_destroy": (ci, [vp]),
+        "dc_blob_mutable_gpu_data": (ci, [vp, C.POINTER(vp), C.POINTER(ci)]),
+        "dc_blob_copy_from": (ci, [vp, vp, ci]),
+        "dc_net_create_for_layer": (ci, [cp, ci, ci, C.POINTER(vp), C.POINTER(vp)]),
         "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
         "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
         "dc_net_emit_maps": (ci, [vp, vp, vp, vp, ci, ci, vp]),

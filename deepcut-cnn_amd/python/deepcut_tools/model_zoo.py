@@ -6,7 +6,8 @@ compatibility) to the reference's models/deepercut/ResNet-152.prototxt: ResNet-1
 MSRA stride placement (stride 2 on branch1/branch2a), conv5 at stride 1 with dilation-2 3x3
 convolutions, and three deconvolution heads (part score maps, location refinement, pairwise
 regression) tied to res3's last block through 1x1 skip convolutions.
-tests/test_model_zoo.py checks the equivalence against the reference file when it is present.
+tests/test_formats.py (test_generated_model_is_equivalent_to_the_reference_prototxt) checks the equivalence against the
+reference file when it is present (the build container; the file does not travel to the GPU box).
 `depth=101` gives the ResNet-101 variant BASELINE.json names (res3b1..b3 / res4b1..b22).
 """
 

@@ -35,11 +35,23 @@ def draw_disc(image, cx, cy, radius, color):
 @click.option("--gpu", type=click.INT, default=0)
 @click.option("--tiling", type=click.Choice(["none", "exact", "reference"]), default="none",
               help="none: one forward per scale (default); exact / reference: see pose.estimate_pose")
-@click.option("--model_def", default=os.path.join(_HERE, "..", "..", "models", "deepercut", "ResNet-152.prototxt"))
-@click.option("--model_bin", default=os.path.join(_HERE, "..", "..", "models", "deepercut", "ResNet-152.caffemodel"))
+@click.option("--model_def", default=None,
+              help="model definition (.prototxt).  Default: the definition deepcut_tools.deepercut_prototxt(152) generates, which is "
+                   "layer-for-layer the reference's models/deepercut/ResNet-152.prototxt (that directory is not part of this repository)")
+@click.option("--model_bin", default=None, required=True,
+              help="trained weights (.caffemodel / .h5): the reference fetches them with models/deepercut/download_models.sh; not shipped here")
 def predict_pose_from(image_name, out_name, scales, visualize, folder_image_suffix, use_cpu, gpu, tiling, model_def, model_bin):
     import caffe
     from PIL import Image
+
+    if model_def is None:
+        import tempfile
+
+        from deepcut_tools import deepercut_prototxt
+
+        fd, model_def = tempfile.mkstemp(suffix=".prototxt")
+        with os.fdopen(fd, "w") as f:
+            f.write(deepercut_prototxt(152))
 
     scales = [float(v) for v in scales.split(",")]
     if os.path.isdir(image_name):

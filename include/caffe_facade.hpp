@@ -10,12 +10,20 @@
 //   Net::ForwardFromTo / ForwardPrefilled       dc_net_forward / dc_net_forward_all  (net.cpp:565-581)
 //   Net::Reshape, blob_by_name, has_blob        dc_net_reshape, dc_net_blob          (net.cpp:744-749,947-957)
 //   Net::blob_names / layer_names / input_blobs / output_blobs
-//   Blob<float>::Reshape / shape / count / offset / cpu_data / mutable_cpu_data / gpu_data
-//                                                                                    (blob.hpp:52-164, blob.cpp:82-139)
+//   Blob<float>::Reshape / shape / count / offset / cpu_data / mutable_cpu_data / gpu_data / mutable_gpu_data / CopyFrom
+//                                                                                    (blob.hpp:52-164, blob.cpp:82-139,435-474)
+//   Blob<float>() / Blob<float>(shape)          dc_blob_create (a blob of its own)   (blob.hpp:26-33)
+//   SyncedMemory(size) cpu_data / gpu_data / mutable_* / head / size                 (syncedmem.hpp:45-83, syncedmem.cpp:25-139)
+//   Layer<float>(LayerParameter) SetUp / Reshape / Forward / blobs, protected virtual Forward_cpu / Forward_gpu
+//                                               dc_net_create_for_layer              (layer.hpp:40-74,131-151,335-345,451-487)
+//   LayerRegistry<float>::CreateLayer(param)                                         (layer_factory.hpp:75-84)
+//   LayerParameter: the reference's is a protobuf message (caffe.proto:311-334); here it carries the TEXT form of that
+//   message (what TextFormat would parse) — libprotobuf is not a dependency of this path.
 // Errors: the reference LOG(FATAL)s; the facade throws std::runtime_error with the library's message.
 #ifndef CAFFE_FACADE_HPP_
 #define CAFFE_FACADE_HPP_
 
+#include <cctype>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -48,10 +56,60 @@ class Caffe {
 template <typename Dtype>
 class Blob;
 
+// SyncedMemory (syncedmem.hpp:45-83): the 4-state lazily synchronised host/device buffer.  Backed by a 1-axis blob of
+// ceil(size/4) floats; the device side of a non-4-D blob is a plain copy of the host bytes.  set_cpu_data/set_gpu_data
+// (adopting foreign pointers: data layers only) are not offered.
+class SyncedMemory {
+ public:
+  enum SyncedHead { UNINITIALIZED, HEAD_AT_CPU, HEAD_AT_GPU, SYNCED };
+  SyncedMemory() : SyncedMemory(0) {}
+  explicit SyncedMemory(size_t size) : size_(size) {
+    int n = (int)((size + 3) / 4);
+    dc_check_(dc_blob_create(1, &n, &h_));
+  }
+  ~SyncedMemory() { dc_blob_destroy(h_); }
+  SyncedMemory(const SyncedMemory&) = delete;
+  SyncedMemory& operator=(const SyncedMemory&) = delete;
+  const void* cpu_data() {
+    const float* p = nullptr;
+    dc_check_(dc_blob_cpu_data(h_, &p));
+    return p;
+  }
+  void* mutable_cpu_data() {
+    float* p = nullptr;
+    dc_check_(dc_blob_mutable_cpu_data(h_, &p));
+    return p;
+  }
+  const void* gpu_data() {
+    const void* p = nullptr;
+    dc_check_(dc_blob_gpu_data(h_, &p, nullptr));
+    return p;
+  }
+  void* mutable_gpu_data() {
+    void* p = nullptr;
+    dc_check_(dc_blob_mutable_gpu_data(h_, &p, nullptr));
+    return p;
+  }
+  SyncedHead head() { return static_cast<SyncedHead>(dc_blob_head(h_)); }
+  size_t size() { return size_; }
+
+ private:
+  dc_blob* h_ = nullptr;
+  size_t size_;
+};
+
 template <>
 class Blob<float> {
  public:
-  explicit Blob(dc_blob* h) : h_(h) {}
+  explicit Blob(dc_blob* h) : h_(h) {}  // a net's blob (owned by the net)
+  Blob() : Blob(vector<int>()) {}       // a blob of its own (blob.hpp:26-33)
+  explicit Blob(const vector<int>& shape) : own_(true) { dc_check_(dc_blob_create((int)shape.size(), shape.data(), &h_)); }
+  Blob(int num, int channels, int height, int width) : Blob(vector<int>{num, channels, height, width}) {}
+  ~Blob() {
+    if (own_) dc_blob_destroy(h_);
+  }
+  Blob(const Blob&) = delete;
+  Blob& operator=(const Blob&) = delete;
   void Reshape(const vector<int>& shape) { dc_check_(dc_blob_reshape(h_, (int)shape.size(), shape.data())); }
   void Reshape(int num, int channels, int height, int width) { Reshape(vector<int>{num, channels, height, width}); }
   vector<int> shape() const {
@@ -90,10 +148,164 @@ class Blob<float> {
     dc_check_(dc_blob_gpu_data(h_, &p, channel_pitch));
     return static_cast<const float*>(p);
   }
+  // Blob::mutable_gpu_data (blob.cpp:111-115): the device image becomes authoritative
+  float* mutable_gpu_data(int* channel_pitch = nullptr) {
+    void* p = nullptr;
+    dc_check_(dc_blob_mutable_gpu_data(h_, &p, channel_pitch));
+    return static_cast<float*>(p);
+  }
+  SyncedMemory::SyncedHead head() const { return static_cast<SyncedMemory::SyncedHead>(dc_blob_head(h_)); }
+  // Blob::CopyFrom (blob.cpp:435-474), data only
+  void CopyFrom(const Blob& source, bool copy_diff = false, bool reshape = false) {
+    if (copy_diff) throw std::runtime_error("no diff side on the inference path");
+    dc_check_(dc_blob_copy_from(h_, source.h_, reshape ? 1 : 0));
+  }
+  void ReshapeLike(const Blob& other) { Reshape(other.shape()); }
   dc_blob* handle() const { return h_; }
 
  private:
-  dc_blob* h_;
+  dc_blob* h_ = nullptr;
+  bool own_ = false;
+};
+
+// LayerParameter (caffe.proto:311-334) in text form: `name: "c" type: "Convolution" bottom: "x" top: "y" convolution_param { ... }`
+class LayerParameter {
+ public:
+  LayerParameter() {}
+  explicit LayerParameter(const string& text_format) : text_(text_format) {}
+  const string& text() const { return text_; }
+  string name() const { return field_("name"); }
+  string type() const { return field_("type"); }
+
+ private:
+  string field_(const char* key) const {  // first top-level `key: "value"`
+    int depth = 0;
+    const string k(key);
+    for (size_t i = 0; i < text_.size(); ++i) {
+      const char c = text_[i];
+      if (c == '{') ++depth;
+      else if (c == '}') --depth;
+      else if (c == '#') while (i < text_.size() && text_[i] != '\n') ++i;
+      else if (c == '"') { for (++i; i < text_.size() && text_[i] != '"'; ++i) {} }
+      else if (depth == 0 && text_.compare(i, k.size(), k) == 0 && (i == 0 || !(isalnum((unsigned char)text_[i - 1]) || text_[i - 1] == '_'))) {
+        size_t j = i + k.size();
+        while (j < text_.size() && (text_[j] == ' ' || text_[j] == ':')) ++j;
+        if (j < text_.size() && text_[j] == '"') {
+          size_t e = text_.find('"', j + 1);
+          return text_.substr(j + 1, e == string::npos ? string::npos : e - j - 1);
+        }
+      }
+    }
+    return string();
+  }
+  string text_;
+};
+
+// Layer<float> (layer.hpp): one reference layer on its own.  SetUp builds the layer for the given bottoms, Reshape follows
+// the bottoms' shapes, Forward reshapes then dispatches on Caffe::mode() to the protected virtual Forward_cpu / Forward_gpu
+// exactly like layer.hpp:451-487.  Forward_gpu runs the layer's CDNA4 kernels (the counterpart of
+// src/caffe/layers/*_layer.cu Forward_gpu); Forward_cpu refuses: this library has no CPU compute path.
+template <typename Dtype>
+class Layer;
+
+template <>
+class Layer<float> {
+ public:
+  explicit Layer(const LayerParameter& param) : layer_param_(param) {}
+  virtual ~Layer() {
+    if (net_) dc_net_destroy(net_);
+  }
+  Layer(const Layer&) = delete;
+  Layer& operator=(const Layer&) = delete;
+
+  void SetUp(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {  // layer.hpp:67-74
+    LayerSetUp(bottom, top);
+    Reshape(bottom, top);
+  }
+  virtual void LayerSetUp(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {
+    (void)top;
+    vector<dc_blob*> hs;
+    for (auto* b : bottom) hs.push_back(b->handle());
+    if (net_) dc_net_destroy(net_), net_ = nullptr;
+    dc_check_(dc_net_create_for_layer(layer_param_.text().c_str(), DC_PHASE_TEST, (int)hs.size(), hs.data(), &net_));
+    layer_index_ = dc_net_num_layers(net_) - 1;
+    for (int i = 0; i < dc_net_num_layers(net_); ++i)
+      if (layer_param_.name() == dc_net_layer_name(net_, i)) layer_index_ = i;
+    blobs_.clear();
+    const char* lname = dc_net_layer_name(net_, layer_index_);
+    for (int i = 0; i < dc_net_layer_num_params(net_, lname); ++i) {
+      dc_blob* pb = nullptr;
+      dc_check_(dc_net_param(net_, lname, i, &pb));
+      blobs_.push_back(std::make_shared<Blob<float> >(pb));
+    }
+  }
+  virtual void Reshape(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {
+    require_setup_();
+    if ((int)bottom.size() != dc_net_num_inputs(net_)) throw std::runtime_error("Layer::Reshape: bottom count changed since SetUp");
+    for (size_t i = 0; i < bottom.size(); ++i) {
+      const vector<int> s = bottom[i]->shape();
+      dc_check_(dc_blob_reshape(in_(i), (int)s.size(), s.data()));
+    }
+    dc_check_(dc_net_reshape(net_));
+    for (size_t i = 0; i < top.size(); ++i) {
+      int n = 0, d[8];
+      dc_check_(dc_blob_shape(out_(i), &n, d));
+      top[i]->Reshape(vector<int>(d, d + n));
+    }
+  }
+  inline float Forward(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {  // layer.hpp:451-487
+    Reshape(bottom, top);
+    switch (Caffe::mode()) {
+      case Caffe::CPU: Forward_cpu(bottom, top); break;
+      case Caffe::GPU: Forward_gpu(bottom, top); break;
+    }
+    return 0.f;  // no loss layers on the inference path
+  }
+  vector<shared_ptr<Blob<float> > >& blobs() { return blobs_; }
+  const LayerParameter& layer_param() const { return layer_param_; }
+  virtual inline const char* type() const { return net_ ? dc_net_layer_type(net_, layer_index_) : ""; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {
+    (void)bottom, (void)top;
+    throw std::runtime_error("Layer::Forward_cpu: libdeepcut_hip provides the MI355X path only (DC_ENOCPU); set Caffe::GPU");
+  }
+  virtual void Forward_gpu(const vector<Blob<float>*>& bottom, const vector<Blob<float>*>& top) {
+    require_setup_();
+    for (size_t i = 0; i < bottom.size(); ++i) dc_check_(dc_blob_copy_from(in_(i), bottom[i]->handle(), 0));  // device side if authoritative there
+    dc_check_(dc_net_forward_all(net_));
+    for (size_t i = 0; i < top.size(); ++i) dc_check_(dc_blob_copy_from(top[i]->handle(), out_(i), 1));  // stays on the device (HEAD_AT_GPU)
+  }
+  LayerParameter layer_param_;
+  vector<shared_ptr<Blob<float> > > blobs_;
+
+ private:
+  void require_setup_() const {
+    if (!net_) throw std::runtime_error("Layer used before SetUp");
+  }
+  dc_blob* in_(size_t i) const {
+    dc_blob* b = nullptr;
+    dc_check_(dc_net_blob(net_, dc_net_input_name(net_, (int)i), &b));
+    return b;
+  }
+  dc_blob* out_(size_t i) const {  // tops = the blobs the one-layer net leaves unconsumed (an in-place top is its bottom's blob)
+    const char* name = dc_net_output_name(net_, (int)i);
+    if (!name) throw std::runtime_error("Layer: top index out of range");
+    dc_blob* b = nullptr;
+    dc_check_(dc_net_blob(net_, name, &b));
+    return b;
+  }
+  dc_net* net_ = nullptr;
+  int layer_index_ = 0;
+};
+
+// LayerRegistry<float>::CreateLayer (layer_factory.hpp:75-84): every layer type of the path is served by the same class
+template <typename Dtype>
+class LayerRegistry;
+template <>
+class LayerRegistry<float> {
+ public:
+  static shared_ptr<Layer<float> > CreateLayer(const LayerParameter& param) { return std::make_shared<Layer<float> >(param); }
 };
 
 template <typename Dtype>

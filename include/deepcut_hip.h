@@ -143,6 +143,27 @@ int dc_blob_head(dc_blob* b);
  * blob, plus its channel pitch (>= channels; the 3-channel input is stored with pitch 4). */
 int dc_blob_gpu_data(dc_blob* b, const void** dev_ptr, int* channel_pitch);
 
+/* Blob<float>() / Blob<float>(shape) (blob.hpp:26-33): a blob of its own, owned by the caller — the bottoms and tops a
+ * stand-alone Layer is driven with, or the backing store of a caffe::SyncedMemory.  It moves between host and device on
+ * the default stream of the calling thread's device (Caffe::SetDevice).  dc_blob_destroy refuses a net's blob.       */
+int dc_blob_create(int ndim, const int* dims, dc_blob** out);
+int dc_blob_destroy(dc_blob* b);
+/* Blob::mutable_gpu_data (blob.cpp:111-115 -> SyncedMemory::mutable_gpu_data, syncedmem.cpp:130-139): the device image
+ * (channels-last for 4-D blobs, plain otherwise) becomes authoritative (HEAD_AT_GPU); an UNINITIALIZED blob gets a
+ * zeroed image, a host-side one is uploaded first.  Refused for blobs a fused plan never materialises.            */
+int dc_blob_mutable_gpu_data(dc_blob* b, void** dev_ptr, int* channel_pitch);
+/* Blob::CopyFrom(source, copy_diff=false, reshape) (blob.cpp:435-474): copies wherever the source is authoritative —
+ * host to host, or device image to device image (re-pitched) leaving dst HEAD_AT_GPU.  Shapes must agree unless
+ * `reshape`.                                                                                                      */
+int dc_blob_copy_from(dc_blob* dst, dc_blob* src, int reshape);
+
+/* ---- one reference layer stand-alone: Layer<Dtype>::SetUp(bottom, top) (layer.hpp:67-74) ---------------------------
+ * layer_param_text: the text-format LayerParameter (the body of a `layer { }` message, or the message itself).  The
+ * result is a net whose inputs are the layer's bottoms (named as in the text, shaped like `bottoms`), with DC_OPT_FUSE 0:
+ * Layer::Reshape = dc_blob_reshape on its inputs + dc_net_reshape, Layer::Forward_gpu = dc_net_forward_all, the layer's
+ * blobs() = dc_net_param(net, <layer name>, i).  include/caffe_facade.hpp wraps this as caffe::Layer<float>.        */
+int dc_net_create_for_layer(const char* layer_param_text, int phase, int nbottom, dc_blob* const* bottoms, dc_net** out);
+
 /* ---- batched / sharded extension (no reference counterpart: the reference forwards one
  * image at a time, conv_layer.cpp:31).  Runs `n` same-shape images as one batch:
  * inputs  : host or device NCHW float32 [n,3,H,W] (is_device selects)
@@ -200,11 +221,6 @@ int dc_net_detect_parts(dc_net* net, double scale, float threshold, int radius, 
 int dc_net_decode_pairwise(dc_net* net, double scale, int ndet, const int* detections, const double* mean,
                            const double* stdev, double* out);
 
-/* ---- Layer::Forward_gpu surface ---------------------------------------------------------
- * One reference layer stand-alone = a one-layer prototxt given to dc_net_create_from_text with
- * DC_OPT_FUSE 0, weights injected through dc_net_param + dc_blob_mutable_cpu_data: the CDNA4
- * counterpart of src/caffe/layers/{conv,deconv,batch_norm,scale,relu,pooling,eltwise,crop,
- * sigmoid}_layer Forward_gpu (tests/test_layers_gpu.py drives every layer type this way).   */
 
 /* ---- introspection used by bench.py / DESIGN.md ----------------------------------------- */
 /* algorithmic FLOPs (2*MAC of conv+deconv) of the current shape               */

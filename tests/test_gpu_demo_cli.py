@@ -27,7 +27,8 @@ def _run(args):
     return subprocess.run([sys.executable, DEMO] + args, env=env, capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("hw,extra", [((240, 320), ["--scales", "0.75,1.0"]), ((720, 960), ["--tiling", "exact"])])
+@pytest.mark.parametrize("hw,extra", [((240, 320), ["--scales", "0.75,1.0"]), ((720, 960), ["--tiling", "exact"]),
+                                      ((96, 128), ["--default-def"])])
 def test_demo_writes_a_pose(model, hw, extra):
     from PIL import Image
 
@@ -35,7 +36,9 @@ def test_demo_writes_a_pose(model, hw, extra):
     img = d / ("img_%dx%d.png" % hw)
     Image.fromarray(np.random.RandomState(hw[0]).randint(0, 256, hw + (3,)).astype(np.uint8)).save(str(img))
     out = str(d / ("pose_%d.npz" % hw[0]))
-    r = _run([str(img), "--model_def", proto, "--model_bin", weights, "--out_name", out, "--visualize", "False"] + extra)
+    use_default_def = "--default-def" in extra  # no --model_def: the generated ResNet-152 definition
+    extra = [e for e in extra if e != "--default-def"]
+    r = _run([str(img)] + ([] if use_default_def else ["--model_def", proto]) + ["--model_bin", weights, "--out_name", out, "--visualize", "False"] + extra)
     assert r.returncode == 0, r.stderr[-2000:]
     pose = np.load(out, allow_pickle=True)["pose"]
     assert pose.shape == (5, 14) and np.isfinite(pose.astype(np.float64)).all()

@@ -64,3 +64,29 @@ def test_bad_arguments(net, gpu_caffe):
     for args in [(0.0, 0.5, 1, 4), (1.0, -0.1, 1, 4), (1.0, 0.5, -1, 4), (1.0, 0.5, 1, 0)]:
         with pytest.raises(gpu_caffe.DeepcutError):
             net.detect_parts(*args)
+
+
+def test_more_local_maxima_than_fit_in_lds_is_still_deterministic(gpu_caffe, synth152):
+    """threshold 0 / radius 0 makes every one of the 68 x 92 = 6256 cells of a 544x736 forward a candidate — more than the
+    4096 keys the selection kernel sorts in LDS: the spill path must return the same (score desc, cell asc) prefix as the
+    oracle, run after run (the round-1 kernel kept whichever 1024 candidates arrived first)."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    n = gpu_caffe.Net(deepercut_prototxt(152, 544, 736), path, gpu_caffe.TEST, from_text=True)
+    n.forward_batch(rand_image(13, 544, 736), want=())
+    prob, loc = n.blobs["prob"].data, n.blobs["loc_pred"].data
+    runs = [n.detect_parts(1.0, 0.0, 0, 96) for _ in range(3)]
+    for counts, dets in runs[1:]:
+        assert np.array_equal(counts, runs[0][0]) and np.array_equal(dets, runs[0][1])
+    counts, dets = runs[0]
+    assert (counts == 96).all()
+    ref_counts, ref = M.nms_candidates(prob[0], loc[0], 1.0, 0.0, 0, 96)
+    assert np.array_equal(counts[0], ref_counts)
+    assert np.array_equal(dets[0][:, :, 2:], ref[:, :, 2:])
+    assert np.allclose(dets[0][:, :, :2], ref[:, :, :2], rtol=0, atol=1e-9)
+    # radius 1 at the same size: ~700 maxima per map, the LDS path, same contract
+    counts1, dets1 = n.detect_parts(1.0, 0.0, 1, 4096)
+    ref_counts1, ref1 = M.nms_candidates(prob[0], loc[0], 1.0, 0.0, 1, 4096)
+    assert np.array_equal(counts1[0], ref_counts1) and counts1.max() < 4096
+    assert np.array_equal(dets1[0][:, :, 2:], ref1[:, :, 2:])
