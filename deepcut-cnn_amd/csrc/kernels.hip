@@ -55,6 +55,9 @@ struct Elem;
 template <>
 struct Elem<float> {
   static constexpr int SPC = 4;  // MFMA steps per 32-byte operand chunk: 4 x v_mfma_f32_32x32x2_f32 (k = 8)
+  typedef unsigned raw_t;  // a loaded element before conversion (conversion = first use: the load stays in flight until then)
+  static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+  static __device__ __forceinline__ float cvt(raw_t v) { return __builtin_bit_cast(float, v); }
   static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
   }
@@ -65,6 +68,9 @@ struct Elem<float> {
 template <>
 struct Elem<_Float16> {
   static constexpr int SPC = 1;  // 1 x v_mfma_f32_32x32x16_f16 (k = 16) per 32-byte chunk
+  typedef unsigned short raw_t;
+  static __device__ __forceinline__ raw_t load_raw(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
+  static __device__ __forceinline__ float cvt(raw_t v) { return (float)__builtin_bit_cast(_Float16, v); }
   static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
   }
@@ -101,6 +107,14 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int RPW = 16 / WK;           // accumulator registers each split-K wave finalises
   static_assert((WK - 1) * BM * BN * 4 <= 2 * TILEB, "split-K partials must fit in the tile buffers");
   constexpr bool EARLY_RESID = FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
+  // Wide epilogue (float16): the C fragment gives a lane ONE channel of 16 different pixels, i.e. 2-byte accesses — 128 vector
+  // memory instructions per lane for a 64x64 wave tile with a shortcut, and the CU's address unit, not HBM, bounds the
+  // bandwidth-bound layers (K <= 512).  Instead the finished tile (fp32, after the affine) is transposed through the tile
+  // buffers in LDS and every thread adds the shortcut to, and stores, 8 consecutive channels of one pixel: 16-byte accesses,
+  // 8x fewer instructions; the shortcut vectors are requested before the transposition so that they are in flight meanwhile.
+  constexpr int WPS = BN + 4;                       // staging row pitch (floats)
+  constexpr int WVEC = BM * (BN / 8) / NT;           // 16-byte output vectors per thread
+  constexpr bool WIDE_OK = ES == 2 && BM * WPS * 4 <= 2 * TILEB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB + 16 * BM];
   i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILEB);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
@@ -166,8 +180,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   const int T_ = c_Ktot / BK;
   auto stamp = [&](int slot) {
     if (p.dbg && lane == 0) {
-      long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 8;
+      long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 10;
       d[slot] = (long long)__builtin_readcyclecounter();
+      if (slot == 0) d[8] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
+      if (slot == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
     }
   };
   stamp(0);
@@ -386,6 +402,21 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // branch) so that every accumulator index is a compile-time constant: no v_cndmask register selects.
   auto finish = [&](auto wk_tag) {
     constexpr int MYK = decltype(wk_tag)::value;
+    const bool wide = WIDE_OK && p.wide_epi;  // uniform
+    f32x4 wres[WIDE_OK ? WVEC : 1];             // shortcut vectors (8 halves each) of this thread's output vectors
+    unsigned woff[WIDE_OK ? WVEC : 1];
+    if constexpr (WIDE_OK) {
+      if (wide) {
+#pragma unroll
+        for (int i = 0; i < WVEC; ++i) {
+          const int v = t + i * NT, row = v / (BN / 8), cv = v - row * (BN / 8);
+          const int yo = rowinfo[row].w;
+          const int co = n0 + cv * 8;
+          woff[i] = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;  // Cout % 8 == 0: a vector is all in or all out
+          if (p.resid) wres[i] = dc_bload4(rr, woff[i], 0);
+        }
+      }
+    }
     if (WK > 1) {
       __syncthreads();  // tile buffers are free
       float* part = reinterpret_cast<float*>(smem);
@@ -415,6 +446,39 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       }
     }
     stamp(6);
+    if constexpr (WIDE_OK) {
+      if (wide) {
+        float* stg = reinterpret_cast<float*>(smem);
+        __syncthreads();  // every wave is past its reads of the tile buffers / the split-K partials
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int e = 0; e < RPW; ++e) {
+              const int r = MYK * RPW + e;
+              const int row = wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              stg[row * WPS + wc * TN + b * 32 + (lane & 31)] = acc[a][b][r] * sc[b] + sh[b];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WVEC; ++i) {
+          const int v = t + i * NT, row = v / (BN / 8), cv = v - row * (BN / 8);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * WPS + cv * 8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * WPS + cv * 8 + 4);
+          f16x8 rz = __builtin_bit_cast(f16x8, wres[i]);
+          f16x8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float x = (q < 4 ? lo[q] : hi[q - 4]) + (p.resid ? (float)rz[q] : 0.f);
+            if (p.relu) x = fmaxf(x, 0.f);
+            o[q] = (_Float16)x;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, woff[i], 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int b = 0; b < FN; ++b) {
       const int co = n0 + wc * TN + b * 32 + (lane & 31);
@@ -561,6 +625,9 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   const VariantEntry& e = kVariants[variant];
   ConvGemmParams p = p_in;
   if (p.esize != e.esize) return (int)hipErrorInvalidValue;
+  static const int wide_epi = getenv("DC_WIDE_EPI") ? atoi(getenv("DC_WIDE_EPI")) : 1;
+  p.wide_epi = wide_epi && p.esize == 2 && p.ncls <= 1 && p.Cout % 8 == 0 && p.y_pix_stride % 8 == 0 && p.y_row_stride % 8 == 0 &&
+               p.y_img_stride % 8 == 0 && p.sigmoid_ch == 0 && ((uintptr_t)p.y & 15) == 0 && (!p.resid || ((uintptr_t)p.resid & 15) == 0);
   // n / d magic: sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1, n/d = (n*mul) >> sh for 0 <= n < 2^31
   auto magic_of = [](unsigned d, unsigned (&mg)[2]) {
     if (d <= 1) {

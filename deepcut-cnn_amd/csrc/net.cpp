@@ -1822,7 +1822,7 @@ void Net::run_launch(const Launch& l, void* s) {
         // device-side phase timestamps of ONE launch (diagnostics only): wall clock (100 MHz) at
         // start / loop entry / loop exit / end, and the shader cycle counter at the same points
         const int nwv = conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
-        const long n = (l.grid * 2 + 64) * nwv * 8;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
+        const long n = (l.grid * 2 + 64) * nwv * 10;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
         HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
@@ -1839,12 +1839,26 @@ void Net::run_launch(const Launch& l, void* s) {
         // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
         double dsum[8] = {0};
         long cnt = 0;
+        // per XCD (workgroup b runs on XCD b % 8; the cycle counters of different XCDs need not agree): spread of the wave
+        // start times = dispatch ramp, last end - first start = the launch as the waves see it
+        long long t0min[8], t0max[8], t7max[8];
+        long seen[8] = {0};
         for (long i = 0; i < (l.grid * 2 + 64) * nwv; ++i) {
-          const long long* w = &h[i * 8];
-          if (w[7] == 0) continue;  // workgroup of the padded XCD grid that exited at once
+          const long long* w = &h[i * 10];
+          if (w[7] == 0 || w[0] == 0) continue;  // workgroup of the padded XCD grid that exited at once
           for (int k = 1; k < 8; ++k) dsum[k] += (double)(w[k] - w[k - 1]);
+          const int q = 0;  // the 100 MHz real-time counter (slots 8, 9) is the same on every CU
+          if (!seen[q] || w[8] < t0min[q]) t0min[q] = w[8];
+          if (!seen[q] || w[8] > t0max[q]) t0max[q] = w[8];
+          if (!seen[q] || w[9] > t7max[q]) t7max[q] = w[9];
+          ++seen[q];
           ++cnt;
         }
+        long long ramp = 0, span = 0;
+        for (int q = 0; q < 8; ++q)
+          if (seen[q]) ramp = std::max(ramp, t0max[q] - t0min[q]), span = std::max(span, t7max[q] - t0min[q]);
+        std::fprintf(stderr, "[dc timing] first wave start -> last wave start %.2f us | first start -> last end %.2f us | waves %ld\n",
+                     ramp / 100.0, span / 100.0, cnt);
         std::fprintf(stderr,
                      "[dc timing] launch %d %s %s\n  mean cycles per wave: filter-load issue %.0f | decode+barrier %.0f | "
                      "activation-load issue %.0f | wait+stage+barrier %.0f | K loop %.0f | split-K exchange %.0f | epilogue math+stores %.0f\n",
