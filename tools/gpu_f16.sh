@@ -1,0 +1,12 @@
+#!/bin/bash
+# ON THE GPU BOX: float16 batch-8 forward, tiles tuned from scratch; per-shape table + the tune cache it ends with
+OUT=gpurun_out/${1:-f16}; shift
+mkdir -p $OUT
+rm -f $OUT/tune_cache.txt
+DC_TUNE_CACHE=$OUT/tune_cache.txt timeout 400 python bench.py --no-cpu-baseline --no-f16-line --dtype f16 --batch 8 --streams 2 --steps 10 --warmup 2 --breakdown $OUT/per_launch.txt "$@" > $OUT/bench.json 2>$OUT/bench.err
+python - <<PY
+import json
+d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
+print("f16 batch 8: value %.1f img/s (%.0f TF/s)  one-at-a-time %.1f img/s (%.0f TF/s)" % (d["value"], d["tflops"], d["one_forward_at_a_time"]["value"], d["one_forward_at_a_time"]["tflops"]))
+PY
+python tools/breakdown.py $OUT/per_launch.txt | head -${LINES_OUT:-16}
