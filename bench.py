@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 3],
                     help="BASELINE.json configs index: 1 = batch 1 per GPU (the headline), 3 = 8 images of 736x544 per GPU "
                          "(batch 64 sharded 8-way) with the gather of the maps to rank 0")
+    ap.add_argument("--coalesce", type=int, default=2, help="also measure cross-request batching: k batch-1 requests per batch forward (0/1: skip)")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the configs[2] (fp16 pyramid) measurement printed beside the headline")
     ap.add_argument("--depth", type=int, default=152)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -390,6 +391,32 @@ def main():
             res["pcie_inclusive_image_entry"] = {"value": n_pcie * B / dt_img, "unit": "images/s",
                                                  "ms_per_forward": dt_img / n_pcie * 1e3,
                                                  "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
+        if world == 1 and args.config == 1 and args.coalesce > 1:
+            # cross-request batching (deepcut_tools.Pipeline(coalesce=k)): the same independent batch-1 requests, merged k at a
+            # time into batch-k forwards on the executors — reported beside `value`, which stays batch-1 forwards in flight
+            from deepcut_tools import Pipeline
+
+            pipe = Pipeline(net, depth=len(nets), coalesce=args.coalesce)
+            pipe.nets = nets  # reuse the executors (and their tuned plans)
+            nreq = args.steps * args.coalesce
+            bufs = [(xs[i % S], [torch.empty(B, c, H // 8, W // 8, device=dev) for c in (shp["prob"][1], shp["loc_pred"][1], shp["next_pred"][1])])
+                    for i in range(2 * args.coalesce * len(nets))]
+
+            def burst(count):
+                for i in range(count):
+                    x, o = bufs[i % len(bufs)]
+                    pipe.submit(x.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=i)
+                pipe.drain()
+
+            burst(4 * args.coalesce * len(nets))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            burst(nreq)
+            torch.cuda.synchronize(dev)
+            dtc = time.perf_counter() - t1
+            res["cross_request_batching"] = {"value": nreq / dtc, "unit": "images/s", "coalesce": args.coalesce, "executors": len(nets),
+                                             "requests": nreq, "note": "independent batch-1 requests merged into batch-%d forwards "
+                                             "(dc_net_forward_requests), %d executors" % (args.coalesce, len(nets))}
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
             # the other single-GPU configuration of BASELINE.json, timed by the same run (never `value`)
             res["config2_f16"] = config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights)

@@ -378,6 +378,16 @@ int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, i
   return guard([&] { N(net)->forward_batch(input, n, h, w, is_device != 0, prob, loc_pred, next_pred, stream); });
 }
 
+int dc_net_forward_requests(dc_net* net, int n, const float* const* inputs, int h, int w, float* const* prob,
+                            float* const* loc_pred, float* const* next_pred, void* stream) {
+  REQUIRE(net);
+  REQUIRE(inputs);
+  if (n <= 0 || h <= 0 || w <= 0) return fail(DC_EINVAL, "bad batch shape");
+  for (int i = 0; i < n; ++i)
+    if (!inputs[i]) return fail(DC_EINVAL, "null request input");
+  return guard([&] { N(net)->forward_requests(n, inputs, h, w, prob, loc_pred, next_pred, stream); });
+}
+
 int dc_net_decode_pose(dc_net* net, double scale, double* pose, int is_device, void* stream) {
   REQUIRE(net);
   REQUIRE(pose);

@@ -68,6 +68,7 @@ struct ConvGemmParams {
   long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
   // --- multi-class launches (the stride-2 deconvolution heads): ncls > 1 and cls[0..ncls) replace the single-problem
   //     fields nty..x_bias / Ktot / OH / OW / M above; sy, sx, klen, strides, Cout, epilogue are common to all classes
+  int mask_lce;  // tap validity depends on the element column inside a tap (taps spanning several pixels: the stem's row taps)
   int wide_epi;  // (filled by launch_conv_gemm) float16: 16-byte epilogue through LDS — Cout and the output strides are multiples of 8
   int ncls;
   int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)

@@ -225,16 +225,31 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // (3) one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
   if (t < BM) {
     const int m = m0 + t;
-    i32x4 ri = {(int)kOOB, -(1 << 28), 0, -1};
+    i32x4 ri = {(int)kOOB, 0, 0, -1};
     if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
       const int ox = rem - oy * c_OW;
       ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES);
-      ri.y = oy * p.sy;
       ri.z = ox * p.sx;
       ri.w = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * ES);
+      // tap validity of the row, decided HERE once per row (not by every loading thread): bit (ty*ntx + tx) = source row
+      // (ty) inside the image and source pixel (tx) inside the row.  Taps of whole pixels (klen = channel pitch) do not
+      // depend on the thread's element column; the stem's row taps (klen = several pixels) do: for those only the row part
+      // is stored and the column part is finished per thread below.
+      unsigned rowmask = 0, colmask = 0;
+#pragma nounroll
+      for (int ty = 0; ty < c_nty; ++ty) rowmask |= ((unsigned)(oy * p.sy + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows ? 1u : 0u) << ty;
+#pragma nounroll
+      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ri.z + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
+      unsigned full = 0;
+#pragma nounroll
+      for (int ty = 0; ty < c_nty; ++ty)
+        if ((rowmask >> ty) & 1u) full |= colmask << (ty * c_ntx);
+      ri.y = (int)(p.mask_lce ? rowmask : full);
+    } else {
+      ri.y = 0;
     }
     rowinfo[t] = ri;
   }
@@ -247,11 +262,17 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   for (int i = 0; i < NA; ++i) {
     const i32x4 ri = rowinfo[lrow + RPP * i];
     avoff[i] = (unsigned)ri.x + lcb;
-    unsigned colmask = 0, mk = 0;  // validity of a tap = (row tap valid) x (column tap valid)
-    for (int tx = 0; tx < c_ntx; ++tx)
-      colmask |= ((unsigned)(ri.z + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
-    for (int ty = 0; ty < c_nty; ++ty)
-      if ((unsigned)(ri.y + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows) mk |= colmask << (ty * c_ntx);
+    unsigned mk = (unsigned)ri.y;
+    if (p.mask_lce) {  // uniform; the stem only
+      unsigned colmask = 0;
+      const unsigned rowmask = mk;
+      mk = 0;
+#pragma nounroll
+      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ri.z + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
+#pragma nounroll
+      for (int ty = 0; ty < c_nty; ++ty)
+        if ((rowmask >> ty) & 1u) mk |= colmask << (ty * c_ntx);
+    }
     amask[i] = mk;
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a

@@ -246,6 +246,9 @@ struct Net {
   void forward(int start, int end);
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
                      float* next, void* user_stream);
+  // cross-request batching: n independent single-image requests (device buffers, one pointer set per request) as ONE batch-n forward
+  void forward_requests(int n, const float* const* inputs, int h, int w, float* const* prob, float* const* loc, float* const* next,
+                        void* user_stream);
   // image entry: pre-processing (estimate_pose.py:83-103) + forward + optional decode, all on the device
   void forward_images(const unsigned char* bgr, int n, int h, int w, double scale, bool is_device, float* prob, float* loc,
                       float* next, double* pose, void* user_stream);

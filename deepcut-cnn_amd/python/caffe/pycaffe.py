@@ -93,6 +93,7 @@ def _load():
         "dc_blob_copy_from": (ci, [vp, vp, ci]),
         "dc_net_create_for_layer": (ci, [cp, ci, ci, C.POINTER(vp), C.POINTER(vp)]),
         "dc_net_forward_batch": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]),
+        "dc_net_forward_requests": (ci, [vp, ci, C.POINTER(vp), ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "dc_net_decode_pose": (ci, [vp, C.c_double, vp, ci, vp]),
         "dc_net_emit_maps": (ci, [vp, vp, vp, vp, ci, ci, vp]),
         "dc_net_forward_images": (ci, [vp, vp, ci, ci, ci, C.c_double, ci, vp, vp, vp, vp, vp]),
@@ -381,6 +382,21 @@ class Net(object):
             stream = C.c_void_p(-1).value
         _check(_lib.dc_net_forward_batch(self._h, C.c_void_p(in_ptr), n, h, w, 1, C.c_void_p(prob_ptr or 0),
                                          C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(stream or 0)))
+
+    def forward_requests(self, in_ptrs, h, w, prob_ptrs=None, loc_ptrs=None, next_ptrs=None, stream=None):
+        """Cross-request batching: len(in_ptrs) independent single-image requests (raw device pointers, one output pointer
+        per request or None) run as ONE batch forward; asynchronous on `stream` ("own" = the net's)."""
+        if stream == "own":
+            stream = C.c_void_p(-1).value
+        n = len(in_ptrs)
+
+        def arr(ps):
+            if ps is None:
+                return None
+            return (C.c_void_p * n)(*[C.c_void_p(p or 0) for p in ps])
+
+        _check(_lib.dc_net_forward_requests(self._h, n, arr(in_ptrs), int(h), int(w), arr(prob_ptrs), arr(loc_ptrs), arr(next_ptrs),
+                                            C.c_void_p(stream or 0)))
 
     def decode_pose(self, scale=1.0):
         """-> float64 [n, 5, J]: `_pose_from_mats` of the last forward, computed on the device."""

@@ -176,6 +176,13 @@ int dc_net_create_for_layer(const char* layer_param_text, int phase, int nbottom
 int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
                          float* prob, float* loc_pred, float* next_pred, void* stream);
 
+/* Cross-request batching: `n` independent single-image requests — one DEVICE input pointer ([3,H,W] float32) and one
+ * set of DEVICE output pointers per request (the arrays, or single entries, may be NULL) — run as ONE batch-n forward;
+ * request i's maps land in its own buffers.  What a server does with concurrent batch-1 requests (the reference forwards
+ * one image at a time, conv_layer.cpp:31).  stream as dc_net_forward_batch.                                       */
+int dc_net_forward_requests(dc_net* net, int n, const float* const* inputs, int h, int w, float* const* prob,
+                            float* const* loc_pred, float* const* next_pred, void* stream);
+
 /* The maps of the LAST forward copied out as NCHW, host or device destination, any pointer NULL to skip: elem 0 =
  * float32; elem 1 = float16, offered by fp16 nets (DC_OPT_DTYPE 1) only — the values as they are in HBM, i.e. half the
  * bytes for the gather of the maps to rank 0 (no reference counterpart; Blob::cpu_data of the three outputs).

@@ -226,6 +226,18 @@ def test_pipeline_of_clones_matches_sequential(gpu_caffe, synth152):
     for i in range(len(imgs)):
         for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
             assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)
+    # cross-request batching: the same seven requests coalesced three at a time (3 + 3 + a partial batch of 1) into batch
+    # forwards on two executors; every request still gets ITS maps in ITS buffers
+    for o in outs:
+        for t in o:
+            t.zero_()
+    pipe2 = Pipeline(net, depth=2, coalesce=3)
+    for i, im in enumerate(imgs):
+        pipe2.submit(im.data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
+    assert sorted(pipe2.drain()) == list(range(7))
+    for i in range(len(imgs)):
+        for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
+            assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)
 
 
 @pytest.mark.parametrize("hw", [(16, 24), (24, 16), (40, 8)])

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cp profiles/r02_tune_cache.txt $OUT/tune_cache.txt
 export DC_TUNE_CACHE=$OUT/tune_cache.txt
-timeout 300 python bench.py --no-cpu-baseline --no-f16-line --breakdown $OUT/per_launch.txt > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --breakdown $OUT/per_launch.txt > $OUT/bench.json 2> $OUT/bench.err
 python - <<PY
 import json
 d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
@@ -16,7 +16,7 @@ print("value %.1f  one-at-a-time %.1f  frac %.3f" % (d["value"], d["one_forward_
 PY
 if [ "${2:-}" = "pmc" ]; then
 cd /tmp && export TMPDIR=/tmp
-PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --streams 1 --no-graph --steps 3 --warmup 1"
+PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $PMC_CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $PMC_CMD > /dev/null 2> $OUT/pmc_write.err
 cd $R

@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-f16}; shift
 mkdir -p $OUT
 rm -f $OUT/tune_cache.txt
-DC_TUNE_CACHE=$OUT/tune_cache.txt timeout 400 python bench.py --no-cpu-baseline --no-f16-line --dtype f16 --batch 8 --streams 2 --steps 10 --warmup 2 --breakdown $OUT/per_launch.txt "$@" > $OUT/bench.json 2>$OUT/bench.err
+DC_TUNE_CACHE=$OUT/tune_cache.txt timeout 400 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 2 --steps 10 --warmup 2 --breakdown $OUT/per_launch.txt "$@" > $OUT/bench.json 2>$OUT/bench.err
 python - <<PY
 import json
 d=json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cp profiles/r02_tune_cache.txt $OUT/tune_cache.txt
 export DC_TUNE_CACHE=$OUT/tune_cache.txt
 cd /tmp && export TMPDIR=/tmp
-PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1"
+PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $PMC_CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $PMC_CMD > /dev/null 2> $OUT/pmc_write.err
 cd $R

@@ -10,7 +10,7 @@ run() {  # label, env..., -- args
   local envs=()
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done
   shift
-  env "${envs[@]}" timeout 200 python bench.py --no-cpu-baseline --no-f16-line --steps 30 --warmup 3 "$@" > $OUT/$label.json 2> $OUT/$label.err
+  env "${envs[@]}" timeout 200 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --steps 30 --warmup 3 "$@" > $OUT/$label.json 2> $OUT/$label.err
   python - <<PY
 import json
 try:

@@ -13,15 +13,15 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export DC_TUNE_CACHE=$OUT/tune_cache.txt
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 python bench.py --no-cpu-baseline --no-f16-line --streams 1 --breakdown $OUT/per_launch.txt > $OUT/bench_s1.json 2>> $OUT/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --breakdown $OUT/per_launch.txt > $OUT/bench_s1.json 2>> $OUT/bench.err
 python tools/breakdown.py $OUT/per_launch.txt > $OUT/per_shape_summary.txt 2>> $OUT/bench.err
-timeout 300 python bench.py --no-cpu-baseline --no-f16-line --dtype f16 --batch 8 --streams 2 --steps 20 --warmup 3 --breakdown $OUT/per_launch_f16_b8.txt > $OUT/bench_f16_batch8.json 2>> $OUT/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 2 --steps 20 --warmup 3 --breakdown $OUT/per_launch_f16_b8.txt > $OUT/bench_f16_batch8.json 2>> $OUT/bench.err
 python tools/breakdown.py $OUT/per_launch_f16_b8.txt > $OUT/per_shape_summary_f16_b8.txt 2>> $OUT/bench.err
-timeout 300 python bench.py --no-cpu-baseline --no-f16-line --config 3 --steps 10 --warmup 2 > $OUT/bench_config3_f32.json 2>> $OUT/bench.err
-timeout 300 python bench.py --no-cpu-baseline --no-f16-line --config 3 --dtype f16 --steps 10 --warmup 2 > $OUT/bench_config3_f16.json 2>> $OUT/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --config 3 --steps 10 --warmup 2 > $OUT/bench_config3_f32.json 2>> $OUT/bench.err
+timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --config 3 --dtype f16 --steps 10 --warmup 2 > $OUT/bench_config3_f16.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python $R/bench.py --no-cpu-baseline --no-f16-line --streams 1 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
-PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --streams 1 --no-graph --steps 3 --warmup 1"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1"
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o m -- $PMC_CMD > /dev/null 2> $OUT/pmc_mfma.err
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $PMC_CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $PMC_CMD > /dev/null 2> $OUT/pmc_write.err
@@ -29,8 +29,8 @@ cd $R
 db() { find $OUT/$1 -name "*.db" | head -1; }
 python tools/rocprof_summary.py $(db stats) > $OUT/kernel_stats.txt 2> $OUT/post.err
 python tools/rocprof_gaps.py $(db stats) > $OUT/kernel_gaps.txt 2>> $OUT/post.err
-python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
-python tools/pmc_hbm_traffic.py $(db pmc_fetch) $(db pmc_write) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --streams 1 --no-graph --steps 3 --warmup 1\`, $TAG" > $OUT/pmc_hbm_traffic.json 2>> $OUT/post.err
+python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
+python tools/pmc_hbm_traffic.py $(db pmc_fetch) $(db pmc_write) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\`, $TAG" > $OUT/pmc_hbm_traffic.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch) $(db pmc_write) > $OUT/pmc_hbm_traffic_per_shape.txt 2>> $OUT/post.err
 timeout 600 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err
 rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write
