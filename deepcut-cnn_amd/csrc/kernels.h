@@ -68,6 +68,9 @@ struct ConvGemmParams {
   long long* dbg;  // optional [grid][4 waves][6] device timestamps (DC_DEBUG_TIMING), else null
   // --- multi-class launches (the stride-2 deconvolution heads): ncls > 1 and cls[0..ncls) replace the single-problem
   //     fields nty..x_bias / Ktot / OH / OW / M above; sy, sx, klen, strides, Cout, epilogue are common to all classes
+  // --- Winograd launches (filled by launch_wino_conv): tile-grid geometry and the magic numbers of its divisions
+  int w_TY, w_TX, w_NBY, w_NBX, w_nblk;
+  unsigned w_div_nblk[2], w_div_nbyx[2], w_div_dd[2], w_div_d[2], w_div_nbx[2];
   int mask_lce;  // tap validity depends on the element column inside a tap (taps spanning several pixels: the stem's row taps)
   int wide_epi;  // (filled by launch_conv_gemm) float16: 16-byte epilogue through LDS — Cout and the output strides are multiples of 8
   int ncls;

@@ -82,6 +82,7 @@ struct Elem<_Float16> {
 // MC: multi-class launch (ConvGemmParams::ncls > 1): the class-dependent scalars come from p.cls[class of this block].
 template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false>
 __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
+  const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();  // before the first kernel-argument load (DC_DEBUG_TIMING)
   constexpr int ES = sizeof(T);          // bytes per element
   constexpr int VEC = 16 / ES;           // elements per 16-byte vector
   constexpr int SPC = Elem<T>::SPC;
@@ -180,9 +181,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   const int T_ = c_Ktot / BK;
   auto stamp = [&](int slot) {
     if (p.dbg && lane == 0) {
-      long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 10;
+      long long* d = p.dbg + ((long)blockIdx.x * NW + wave) * 12;
       d[slot] = (long long)__builtin_readcyclecounter();
-      if (slot == 0) d[8] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
+      if (slot == 0) d[8] = t_entry, d[10] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, the same clock on every CU
       if (slot == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
     }
   };
@@ -559,6 +560,21 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   stamp(7);
 }
 
+// magic {multiplier, shift word} for n / d, 0 <= n < 2^31 (see dc_fastdiv): sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1
+static void dc_magic(unsigned d, unsigned (&mg)[2]) {
+  if (d <= 1) {
+    mg[0] = 0;
+    mg[1] = 0x80000000u;
+    return;
+  }
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  const int sh = 31 + l;
+  const unsigned long long q = (((unsigned __int128)1) << sh) / d;
+  mg[0] = (unsigned)(q + 1);
+  mg[1] = (unsigned)(sh - 32);
+}
+
 namespace {
 struct VariantEntry {
   ConvVariant v;
@@ -619,6 +635,10 @@ const VariantEntry kVariants[] = {
     DC_VARIANT_H_MC(32, 64, 256, 1, 2, 4, 2), // 24: 8 waves, split-K 4
     DC_VARIANT_H(128, 128, 128, 2, 2, 2, 2),  // 25: 8 waves
     DC_VARIANT_H_MC(32, 32, 256, 1, 1, 4, 2), // 26
+    // deeper rings for the short-K (bandwidth-class) layers: three of the four K tiles of a K = 256 layer are in flight at once
+    DC_VARIANT_H(128, 128, 64, 2, 2, 1, 3),   // 27
+    DC_VARIANT_H(128, 64, 64, 2, 2, 1, 3),    // 28
+    DC_VARIANT_H(64, 128, 64, 2, 2, 1, 3),    // 29
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -809,6 +829,7 @@ __device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v
 }  // namespace
 
 __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams p) {
+  const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
   __shared__ __attribute__((aligned(16))) float stage[3][WRH * WRW * WPSTR + 8];
   // [i][b][tf][r][lane] partial inverse transforms: reuses the staging ring once the K loop is over (78 KB per
   // workgroup instead of 94: two workgroups fit the 160 KB of a CU)
@@ -817,13 +838,23 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
   const float* __restrict__ x = reinterpret_cast<const float*>(p.x);
   const float* __restrict__ up = reinterpret_cast<const float*>(p.w);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  auto stamp = [&](int slot) {  // DC_DEBUG_TIMING: per-wave phase stamps (see conv_gemm_kernel)
+    if (p.dbg && lane == 0) {
+      long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 12;
+      d[slot] = (long long)__builtin_readcyclecounter();
+      if (slot == 0) d[8] = t_entry, d[10] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (slot == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+  };
+  stamp(0);
   const int C = p.klen, H = p.x_rows, W = p.x_rowlen / p.klen;
   // dilation d: the image is d*d interleaved phase images, each an ordinary pad-1 3x3 problem on the pixels
   // (phy + d*u, phx + d*v); tiles, blocks and staged coordinates below live on the phase grid (u, v)
+  // (the tile grid and the magic numbers of the block-index divisions come from the host: seven runtime integer
+  // divisions were 2.8 k cycles of every workgroup's life)
   const int d = p.ddy;
-  const int TY = ((p.OH + d - 1) / d + 1) >> 1, TX = ((p.OW + d - 1) / d + 1) >> 1;
-  const int NBY = (TY + WBTY - 1) / WBTY, NBX = (TX + WBTX - 1) / WBTX;
-  const int nblk = p.NB * d * d * NBY * NBX;
+  const int NBY = p.w_NBY, NBX = p.w_NBX;
+  const int nblk = p.w_nblk;
   // Workgroup b runs on XCD (b % 8), each XCD with its own L2.  The transformed filters are the big stream (16/9 of the
   // filter bytes), shared by the nblk workgroups of a 16-channel slice: hand every XCD a CONTIGUOUS range of the
   // (slice-major) logical grid, so that a slice is fetched from HBM by one L2 (two at a range boundary) instead of by
@@ -833,11 +864,11 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
     const int g8 = gridDim.x >> 3, r8 = gridDim.x & 7, q = blockIdx.x & 7;
     lb = q * g8 + min(q, r8) + (blockIdx.x >> 3);
   }
-  const int nt = lb / nblk, blk = lb - nt * nblk;  // same-filter workgroups are adjacent in the logical grid
-  const int nph = blk / (NBY * NBX), brem = blk - nph * (NBY * NBX);
-  const int n = nph / (d * d), ph = nph - n * (d * d);
-  const int phy = ph / d, phx = ph - phy * d;
-  const int by = brem / NBX, bx = brem - by * NBX;
+  const int nt = dc_fastdiv(lb, p.w_div_nblk), blk = lb - nt * nblk;  // same-filter workgroups are adjacent in the logical grid
+  const int nph = dc_fastdiv(blk, p.w_div_nbyx), brem = blk - nph * (NBY * NBX);
+  const int n = dc_fastdiv(nph, p.w_div_dd), ph = nph - n * (d * d);
+  const int phy = dc_fastdiv(ph, p.w_div_d), phx = ph - phy * d;
+  const int by = dc_fastdiv(brem, p.w_div_nbx), bx = brem - by * NBX;
   const int oy0 = 2 * WBTY * by - 1, ox0 = 2 * WBTX * bx - 1;  // phase-grid coordinates of staged pixel (0, 0): pad 1
   const int kg = lane >> 4;
   const int i = wave & 3, tf = wave >> 2;
@@ -911,15 +942,26 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vh[j][1], b[bslot][j][3], acc[j], 0, 0, 0);
   };
   const int NS = C / WKC;
+  stamp(1);
   // pipeline: global -> registers (3 steps ahead) -> LDS ring of 3 (2 steps ahead) -> MFMA; filters one sub-step ahead
+  // the first two stages are requested together (a second register set, dead after the prologue) so that their
+  // latencies overlap instead of adding up
+  f32x4 g1[WNLD];
   gload(0);
   bload(0, 0);
-  sstore(0);
   if (NS > 1) {
-    gload(1);
-    sstore(1);
+#pragma unroll
+    for (int q = 0; q < WNLD; ++q) g1[q] = gofs[q] >= 0 ? *reinterpret_cast<const f32x4*>(xn + gofs[q] + WKC) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  stamp(2);
+  sstore(0);
   if (NS > 2) gload(2);
+  if (NS > 1) {
+#pragma unroll
+    for (int q = 0; q < WNLD; ++q)
+      if (sofs[q] >= 0) *reinterpret_cast<f32x4*>(&stage[1][sofs[q]]) = g1[q];
+  }
+  stamp(3);
   // one staged step: U = K % 3 is a compile-time constant so that the ring buffer offsets fold into the instructions
   auto step = [&](int K, auto u_tag) {
     constexpr int U = decltype(u_tag)::value;
@@ -938,6 +980,7 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
     if (K0 + 1 < NS) step(K0 + 1, std::integral_constant<int, 1>{});
     if (K0 + 2 < NS) step(K0 + 2, std::integral_constant<int, 2>{});
   }
+  stamp(4);
   // inverse transform: over j in registers (P[b] = sum_j M[i][j] A[j][b]), over i through LDS
   __syncthreads();  // every wave is done reading the staging ring, which the partials now overwrite
 #pragma unroll
@@ -946,11 +989,13 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
     part[i][1][tf][r4][lane] = acc[1][r4] - acc[2][r4] - acc[3][r4];
   }
   __syncthreads();
+  stamp(5);
   const int a = (wave >> 1) & 1, bq = wave & 1;  // this wave finalises output pixel (a, bq) of the tiles of fragment tf
   const int co = nt * WBN + (lane & 15);
   const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
   float* yb = reinterpret_cast<float*>(p.y);
   const float* rbp = reinterpret_cast<const float*>(p.resid);
+  stamp(6);
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
     const float p0 = part[0][bq][tf][r4][lane], p1 = part[1][bq][tf][r4][lane], p2 = part[2][bq][tf][r4][lane], p3 = part[3][bq][tf][r4][lane];
@@ -966,6 +1011,7 @@ __global__ __launch_bounds__(WNTH, 4) void wino_f23_kernel(const ConvGemmParams 
       yb[off] = v;
     }
   }
+  stamp(7);
 }
 
 bool wino_eligible(const ConvGemmParams& p) {
@@ -1013,6 +1059,17 @@ int launch_wino_conv(const ConvGemmParams& p, void* stream) {
   ConvGemmParams q = p;
   static const int xcd_map = getenv("DC_XCD_MAP") ? atoi(getenv("DC_XCD_MAP")) : 1;
   q.xcd_on = xcd_map && grid >= 16;
+  {
+    const int d = p.ddy;
+    q.w_TY = ((p.OH + d - 1) / d + 1) / 2, q.w_TX = ((p.OW + d - 1) / d + 1) / 2;
+    q.w_NBY = (q.w_TY + WBTY - 1) / WBTY, q.w_NBX = (q.w_TX + WBTX - 1) / WBTX;
+    q.w_nblk = p.NB * d * d * q.w_NBY * q.w_NBX;
+    dc_magic((unsigned)q.w_nblk, q.w_div_nblk);
+    dc_magic((unsigned)(q.w_NBY * q.w_NBX), q.w_div_nbyx);
+    dc_magic((unsigned)(d * d), q.w_div_dd);
+    dc_magic((unsigned)d, q.w_div_d);
+    dc_magic((unsigned)q.w_NBX, q.w_div_nbx);
+  }
   hipLaunchKernelGGL(wino_f23_kernel, dim3((unsigned)grid), dim3(WNTH), 0, (hipStream_t)stream, q);
   return (int)hipGetLastError();
 }

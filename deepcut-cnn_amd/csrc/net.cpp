@@ -1808,11 +1808,10 @@ void Net::run_launch(const Launch& l, void* s) {
       g.w = l.w->dev;
       g.scale = l.scale ? l.scale->dev : nullptr;
       g.shift = l.shift ? l.shift->dev : nullptr;
-      if (l.variant == kWinoVariant) {  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
+      const bool wino = l.variant == kWinoVariant;  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
+      if (wino) {
         if (!l.wino_w) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
         g.w = l.wino_w->dev;
-        KCHECK(launch_wino_conv(g, s));
-        break;
       }
       static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
       // index of this launch in the plan (autotuning passes copies, which have none)
@@ -1820,52 +1819,57 @@ void Net::run_launch(const Launch& l, void* s) {
                            std::less<const Launch*>()(&l, plan.data() + plan.size());
       const int my_idx = in_plan ? (int)(&l - plan.data()) : -1;
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
-        // device-side phase timestamps of ONE launch (diagnostics only): wall clock (100 MHz) at
-        // start / loop entry / loop exit / end, and the shader cycle counter at the same points
-        const int nwv = conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
-        const long n = (l.grid * 2 + 64) * nwv * 10;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
+        // device-side phase timestamps of ONE launch (diagnostics only): per wave the shader cycle counter at up to 8 phase
+        // boundaries (slots 0..7) and the chip-wide 100 MHz clock at start / end (slots 8, 9)
+        const int nwv = wino ? 8 : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
+        const long n = (l.grid * 2 + 64) * nwv * 12;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
         HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
         for (int rep = 0; rep < 3; ++rep) {
           g.dbg = d;
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
-          KCHECK(launch_conv_gemm(g, l.variant, s));
+          if (wino) KCHECK(launch_wino_conv(g, s));
+          else KCHECK(launch_conv_gemm(g, l.variant, s));
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
         }
         std::vector<long long> h(n);
         HIPCHECK(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
         (void)hipFree(d);
-        // slots: 0 start, 1 filter loads + epilogue constants issued, 2 pixel decode + barrier, 3 activation loads
-        // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
-        double dsum[8] = {0};
+        double dsum[8] = {0}, karg = 0;
         long cnt = 0;
-        // per XCD (workgroup b runs on XCD b % 8; the cycle counters of different XCDs need not agree): spread of the wave
-        // start times = dispatch ramp, last end - first start = the launch as the waves see it
-        long long t0min[8], t0max[8], t7max[8];
-        long seen[8] = {0};
+        long long t0min = 0, t0max = 0, t7max = 0;
         for (long i = 0; i < (l.grid * 2 + 64) * nwv; ++i) {
-          const long long* w = &h[i * 10];
+          const long long* w = &h[i * 12];
           if (w[7] == 0 || w[0] == 0) continue;  // workgroup of the padded XCD grid that exited at once
           for (int k = 1; k < 8; ++k) dsum[k] += (double)(w[k] - w[k - 1]);
-          const int q = 0;  // the 100 MHz real-time counter (slots 8, 9) is the same on every CU
-          if (!seen[q] || w[8] < t0min[q]) t0min[q] = w[8];
-          if (!seen[q] || w[8] > t0max[q]) t0max[q] = w[8];
-          if (!seen[q] || w[9] > t7max[q]) t7max[q] = w[9];
-          ++seen[q];
+          karg += (double)(w[10] - w[8]);
+          if (!cnt || w[8] < t0min) t0min = w[8];
+          if (!cnt || w[8] > t0max) t0max = w[8];
+          if (!cnt || w[9] > t7max) t7max = w[9];
           ++cnt;
         }
-        long long ramp = 0, span = 0;
-        for (int q = 0; q < 8; ++q)
-          if (seen[q]) ramp = std::max(ramp, t0max[q] - t0min[q]), span = std::max(span, t7max[q] - t0min[q]);
-        std::fprintf(stderr, "[dc timing] first wave start -> last wave start %.2f us | first start -> last end %.2f us | waves %ld\n",
-                     ramp / 100.0, span / 100.0, cnt);
-        std::fprintf(stderr,
-                     "[dc timing] launch %d %s %s\n  mean cycles per wave: filter-load issue %.0f | decode+barrier %.0f | "
-                     "activation-load issue %.0f | wait+stage+barrier %.0f | K loop %.0f | split-K exchange %.0f | epilogue math+stores %.0f\n",
-                     my_idx, l.kernel.c_str(), l.label.c_str(), dsum[1] / cnt, dsum[2] / cnt, dsum[3] / cnt, dsum[4] / cnt,
-                     dsum[5] / cnt, dsum[6] / cnt, dsum[7] / cnt);
+        std::fprintf(stderr, "[dc timing] first wave start -> last wave start %.2f us | first start -> last end %.2f us | wave entry -> kernel "
+                     "arguments there %.2f us | waves %ld\n",
+                     (t0max - t0min) / 100.0, (t7max - t0min) / 100.0, karg / std::max(cnt, 1L) / 100.0, cnt);
+        // conv_gemm slots: 0 start, 1 filter loads + epilogue constants issued, 2 pixel decode + barrier, 3 activation loads
+        // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
+        static const char* kGemm[7] = {"filter-load issue", "decode+barrier", "activation-load issue", "wait+stage+barrier", "K loop",
+                                       "split-K exchange", "epilogue math+stores"};
+        static const char* kWino[7] = {"index setup", "first loads issued", "two stages in LDS", "K loop", "partials to LDS + barrier",
+                                       "inverse transform + epilogue constants", "shortcut + stores"};
+        std::string line;
+        for (int k = 1; k < 8; ++k) {
+          char buf[96];
+          std::snprintf(buf, sizeof buf, "%s%s %.0f", k > 1 ? " | " : "", (wino ? kWino : kGemm)[k - 1], dsum[k] / std::max(cnt, 1L));
+          line += buf;
+        }
+        std::fprintf(stderr, "[dc timing] launch %d %s %s\n  mean cycles per wave: %s\n", my_idx, l.kernel.c_str(), l.label.c_str(), line.c_str());
         g.dbg = nullptr;
+      }
+      if (wino) {
+        KCHECK(launch_wino_conv(g, s));
+        break;
       }
       {
         const int rc = launch_conv_gemm(g, l.variant, s);
