@@ -60,7 +60,12 @@ struct ConvGemmParams {
   int sigmoid_ch;  // channels [0, sigmoid_ch) get the logistic
   // --- filled by launch_conv_gemm (host-side precomputation keeps integer divisions out of the prologue) ---
   int xcd_on;              // XCD-aware tile map in use
-  int xcd_rect[8][4];      // per XCD q: {first n tile, n tiles, first m tile, m tiles} of its rectangle
+  int xcd_lgx;             // the 8 XCDs form a (1 << xcd_lgx) x (8 >> xcd_lgx) arrangement over (n tiles) x (m tiles): XCD (qx, qy)
+                           // owns n tiles [tn*qx/gx, tn*(qx+1)/gx) and m tiles [tm*qy/gy, tm*(qy+1)/gy) — computed with shifts in
+                           // the kernel (a per-XCD table in the argument block cost every workgroup a second, dependent
+                           // kernel-argument fetch: ~0.5 us before its first useful instruction)
+  int tiles_m;
+  unsigned div_rw[2][2];   // magic numbers for a division by the rectangle width: floor(tn/gx) and that + 1
   unsigned div_ohw[2];     // magic {multiplier, shift} for m / (OH*OW)
   unsigned div_ow[2];      // ... for m / OW
   unsigned div_tn[2];      // ... for block / tiles_n (linear map)

@@ -167,9 +167,11 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     tile_n = n_lo + (slot - sr * n_cnt);
   } else if (p.xcd_on) {
     const int q = blockIdx.x & 7, slot = blockIdx.x >> 3;  // XCD, position inside its rectangle
-    const int n_lo = p.xcd_rect[q][0], rw = p.xcd_rect[q][1], m_lo = p.xcd_rect[q][2], rh = p.xcd_rect[q][3];
+    const int lgx = p.xcd_lgx, lgy = 3 - lgx, qx = q & ((1 << lgx) - 1), qy = q >> lgx;
+    const int n_lo = (p.tiles_n * qx) >> lgx, rw = ((p.tiles_n * (qx + 1)) >> lgx) - n_lo;
+    const int m_lo = (p.tiles_m * qy) >> lgy, rh = ((p.tiles_m * (qy + 1)) >> lgy) - m_lo;
     if (slot >= rw * rh) return;  // grid is padded to 8 x the largest rectangle
-    const int sr = slot / rw;     // uniform (SALU) division
+    const int sr = rw == (p.tiles_n >> lgx) ? dc_fastdiv(slot, p.div_rw[0]) : dc_fastdiv(slot, p.div_rw[1]);  // slot / rw, all scalar
     tile_n = n_lo + (slot - sr * rw);
     tile_m = m_lo + sr;
   } else {
@@ -760,35 +762,32 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   magic((unsigned)p.OW, p.div_ow);
   static const int xcd_map = getenv("DC_XCD_MAP") ? atoi(getenv("DC_XCD_MAP")) : 1;
   p.xcd_on = 0;
+  p.tiles_m = (int)tm;
   if (xcd_map && grid >= 16) {
     // Blocks are observed to land on XCD (blockIdx % 8), each with its own 4 MB L2.  Cut the tile grid into 8
     // rectangles (gx along n, 8/gx along m) minimising the bytes an L2 must fetch for its rectangle
     // (filters of its n-range + pixels of its m-range); XCD q walks rectangle q.  A locality hint only.
     double best = 1e300;
-    int best_gx = 0;
+    int best_lgx = -1;
     long best_grid = 0;
-    for (int gx : {1, 2, 4, 8}) {
-      const int gy = 8 / gx;
+    for (int lgx = 0; lgx <= 3; ++lgx) {
+      const int gx = 1 << lgx, gy = 8 >> lgx;
       if (gx > tn || gy > tm) continue;
       long maxrect = 0;
       for (int q = 0; q < 8; ++q) {
-        const int qx = q % gx, qy = q / gx;
-        const long rw = (tn * (qx + 1)) / gx - (tn * qx) / gx, rh = (tm * (qy + 1)) / gy - (tm * qy) / gy;
+        const int qx = q & (gx - 1), qy = q >> lgx;
+        const long rw = ((tn * (qx + 1)) >> lgx) - ((tn * qx) >> lgx), rh = ((tm * (qy + 1)) >> (3 - lgx)) - ((tm * qy) >> (3 - lgx));
         maxrect = std::max(maxrect, rw * rh);
       }
       const double w_bytes = (double)p.Cout * p.Ktot / gx, a_bytes = (double)p.M * p.klen * p.nty / gy;
       const double cost = (w_bytes + a_bytes) * (1.0 + 0.02 * (maxrect * 8 - grid) / (double)grid);
-      if (cost < best) best = cost, best_gx = gx, best_grid = maxrect * 8;
+      if (cost < best) best = cost, best_lgx = lgx, best_grid = maxrect * 8;
     }
-    if (best_gx) {
-      const int gx = best_gx, gy = 8 / gx;
-      for (int q = 0; q < 8; ++q) {
-        const int qx = q % gx, qy = q / gx;
-        p.xcd_rect[q][0] = (int)((tn * qx) / gx);
-        p.xcd_rect[q][1] = (int)((tn * (qx + 1)) / gx - (tn * qx) / gx);
-        p.xcd_rect[q][2] = (int)((tm * qy) / gy);
-        p.xcd_rect[q][3] = (int)((tm * (qy + 1)) / gy - (tm * qy) / gy);
-      }
+    if (best_lgx >= 0) {
+      p.xcd_lgx = best_lgx;
+      const unsigned w0 = (unsigned)(tn >> best_lgx);
+      magic(std::max(w0, 1u), p.div_rw[0]);
+      magic(w0 + 1, p.div_rw[1]);
       p.xcd_on = 1;
       grid = best_grid;
     }
