@@ -641,6 +641,9 @@ const VariantEntry kVariants[] = {
     DC_VARIANT_H(128, 128, 64, 2, 2, 1, 3),   // 27
     DC_VARIANT_H(128, 64, 64, 2, 2, 1, 3),    // 28
     DC_VARIANT_H(64, 128, 64, 2, 2, 1, 3),    // 29
+    // 256-row / 256-column tiles (one workgroup per CU): half the operand traffic per flop for the long-K matrix-class layers
+    DC_VARIANT_H(256, 128, 64, 4, 2, 1, 2),   // 30
+    DC_VARIANT_H(128, 256, 64, 2, 4, 1, 2),   // 31
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
