@@ -286,3 +286,36 @@ def test_bench_two_ranks_gloo_smoke(gpu_caffe, extra):
     assert res["config"]["global_batch"] == 2 * res["config"]["per_gpu_batch"]
     if extra:
         assert res["config"]["per_gpu_batch"] == 8 and res["dtype"] == "f16"
+
+
+def test_float16_net_ships_float16_maps_and_coalesces_requests(gpu_caffe, synth152):
+    """A float16 net hands its maps over as float16 (half the gather payload): the runner's device pipeline returns exactly
+    the values the host copy-out of the same forwards gives; and cross-request batching on a float16 net."""
+    import torch
+    from deepcut_tools import Pipeline, ShardedPoseRunner, deepercut_prototxt
+
+    path, _ = synth152
+    rs = np.random.RandomState(6)
+    imgs = [rs.randint(0, 256, (96, 128, 3)).astype(np.uint8) for _ in range(5)]
+    net = gpu_caffe.Net(deepercut_prototxt(152, 96, 128), path, gpu_caffe.TEST, from_text=True, dtype="f16", hipgraph=1)
+    assert net.dtype == "f16"
+    res = ShardedPoseRunner(net, max_batch=4, depth=2).run(imgs, [1.0, 0.75], want_maps=True)
+    for k, (i, s, hw) in enumerate(res["items"]):
+        out = net.forward_images(imgs[i][None], s, want=("prob", "loc_pred", "next_pred"), pose=True)
+        for name in ("prob", "loc_pred", "next_pred"):
+            # batch composition differs (runner batches same-shape items), so fp16 rounding of a different tile schedule
+            assert np.abs(res["maps"][k][name] - out[name][0]).max() <= 4e-3 * max(1.0, float(np.abs(out[name]).max())), (k, name)
+            assert res["maps"][k][name].dtype == np.float32
+    # cross-request batching on the float16 net: each request's maps equal its own single forward up to that rounding
+    dev = torch.device("cuda", 0)
+    h, w = 96, 128
+    xs = [torch.from_numpy((rs.randn(1, 3, h, w) * 50).astype(np.float32)).to(dev) for _ in range(4)]
+    outs = [[torch.empty(1, c, h // 8, w // 8, device=dev) for c in (14, 28, 364)] for _ in xs]
+    pipe = Pipeline(net, depth=2, coalesce=2)
+    for i, x in enumerate(xs):
+        pipe.submit(x.data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
+    assert sorted(pipe.drain()) == [0, 1, 2, 3]
+    for i, x in enumerate(xs):
+        ref = net.forward_batch(x.cpu().numpy())
+        for name, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
+            assert np.abs(t.cpu().numpy() - ref[name]).max() <= 4e-3 * max(1.0, float(np.abs(ref[name]).max())), (i, name)
