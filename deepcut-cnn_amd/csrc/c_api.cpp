@@ -249,7 +249,7 @@ static int blob_host(dc_blob* b, float** out, bool mut) {
       s.head = HEAD_AT_CPU;
       if (s.is_param && s.shared) {  // a writable view was handed out: its content is re-checked before the next run
         std::lock_guard<std::mutex> lk(s.shared->mu);
-        s.shared->touched.push_back(B(b)->st);
+        if (!s.touch_listed) s.shared->touched.push_back(B(b)->st), s.touch_listed = true;
       }
     }
   });
@@ -351,7 +351,7 @@ int dc_blob_copy_from(dc_blob* dst, dc_blob* src, int reshape) {
     storage_copy(d, s, s.view_of >= 0 && s.owner ? s.owner->storages[s.view_of].get() : nullptr, stream);
     if (d.is_param && d.shared) {
       std::lock_guard<std::mutex> lk(d.shared->mu);
-      d.shared->touched.push_back(B(dst)->st);
+      if (!d.touch_listed) d.shared->touched.push_back(B(dst)->st), d.touch_listed = true;
     }
   });
 }

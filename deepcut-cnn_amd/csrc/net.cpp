@@ -1431,8 +1431,10 @@ void Net::check_weights() {
     if (!shared->touched.empty()) {
       bool changed = shared->packed_gen != shared->weights_gen;  // nothing packed yet: hashes are not meaningful
       for (auto& w : shared->touched)
-        if (auto st = w.lock())
+        if (auto st = w.lock()) {
+          st->touch_listed = false;
           if (!changed && content_hash(st->host_ptr(), st->count()) != st->packed_hash) changed = true;
+        }
       shared->touched.clear();
       if (changed && shared->packed_gen == shared->weights_gen) ++shared->weights_gen;
     }

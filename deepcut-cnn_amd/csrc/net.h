@@ -56,6 +56,7 @@ struct Storage {
   Net* owner = nullptr;  // activations: the net whose stream moves this blob between host and device (null: stand-alone blob)
   std::shared_ptr<ModelShared> shared;  // params: the model state a net and its clones own jointly (outlives any one of them)
   uint64_t packed_hash = 0;  // params: content hash when the filter images were last packed (see ModelShared::touched)
+  bool touch_listed = false; // params: already on ModelShared::touched (an access loop must not grow the list)
   int id = -1;
 
   ~Storage();
