@@ -340,6 +340,7 @@ int dc_blob_copy_from(dc_blob* dst, dc_blob* src, int reshape) {
     Net* own = d.owner ? d.owner : s.owner;
     void* stream = nullptr;
     if (s.head == HEAD_AT_GPU) {
+      if (s.owner && s.owner != own) s.owner->synchronize();  // the source may still be being written on its own net's stream
       if (own) {
         own->synchronize();
         stream = own->stream;
