@@ -76,7 +76,6 @@ struct ConvGemmParams {
   // --- Winograd launches (filled by launch_wino_conv): tile-grid geometry and the magic numbers of its divisions
   int w_TY, w_TX, w_NBY, w_NBX, w_nblk;
   unsigned w_div_nblk[2], w_div_nbyx[2], w_div_dd[2], w_div_d[2], w_div_nbx[2];
-  int mask_lce;  // tap validity depends on the element column inside a tap (taps spanning several pixels: the stem's row taps)
   int wide_epi;  // (filled by launch_conv_gemm) float16: 16-byte epilogue through LDS — Cout and the output strides are multiples of 8
   int ncls;
   int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)

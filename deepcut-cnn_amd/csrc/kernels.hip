@@ -136,8 +136,8 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int WVEC = BM * (BN / 8) / NT;           // 16-byte output vectors per thread
   constexpr bool WIDE_OK = ES == 2 && BM * WPS * 4 <= 2 * TILEB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB + 16 * BM];
-  i32x4* rowinfo = reinterpret_cast<i32x4*>(smem + 2 * TILEB);  // per tile row: {x byte offset, iy0, xe0, y byte offset | -1}
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB + 4 * BM];
+  int* rowinfo = reinterpret_cast<int*>(smem + 2 * TILEB);  // per tile row: byte offset of its output pixel, or -1
   const T* px = reinterpret_cast<const T*>(p.x);
 
   const int t = threadIdx.x;
@@ -245,58 +245,34 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   }
 
   stamp(1);
-  // (3) one pixel decode per tile row (integer divisions are VALU-expensive), shared through LDS
-  if (t < BM) {
-    const int m = m0 + t;
-    i32x4 ri = {(int)kOOB, 0, 0, -1};
+  // (3) activation rows: every loading thread decodes ITS rows itself (two magic-number divisions and a handful of
+  //     multiply-adds each) and requests their first tiles at once.  An earlier form decoded each row once, in one thread,
+  //     and shared it through LDS: that put a barrier and an LDS round trip between the kernel arguments and the first
+  //     activation load — ~2 k cycles of every workgroup's life.  Loop-invariant voffset + validity bit per tap (zero padding
+  //     = out-of-range voffset); bit (ty*ntx + tx) = source row ty inside the image and source element inside its row (the
+  //     thread's element column is added: it matters only for the stem's row taps, which span several pixels).
+  unsigned avoff[NA], amask[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + lrow + RPP * i;
+    avoff[i] = kOOB;
+    amask[i] = 0;
     if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
       const int ox = rem - oy * c_OW;
-      ri.x = (int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES);
-      ri.z = ox * p.sx;
-      ri.w = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * ES);
-      // tap validity of the row, decided HERE once per row (not by every loading thread): bit (ty*ntx + tx) = source row
-      // (ty) inside the image and source pixel (tx) inside the row.  Taps of whole pixels (klen = channel pitch) do not
-      // depend on the thread's element column; the stem's row taps (klen = several pixels) do: for those only the row part
-      // is stored and the column part is finished per thread below.
-      unsigned rowmask = 0, colmask = 0;
+      avoff[i] = (unsigned)(int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES) + lcb;
+      unsigned rowmask = 0, colmask = 0, full = 0;
 #pragma nounroll
       for (int ty = 0; ty < c_nty; ++ty) rowmask |= ((unsigned)(oy * p.sy + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows ? 1u : 0u) << ty;
 #pragma nounroll
-      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ri.z + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
-      unsigned full = 0;
+      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ox * p.sx + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
 #pragma nounroll
       for (int ty = 0; ty < c_nty; ++ty)
         if ((rowmask >> ty) & 1u) full |= colmask << (ty * c_ntx);
-      ri.y = (int)(p.mask_lce ? rowmask : full);
-    } else {
-      ri.y = 0;
+      amask[i] = full;
     }
-    rowinfo[t] = ri;
-  }
-  __syncthreads();
-  stamp(2);
-
-  // (4) activation rows: loop-invariant voffset + validity bit per tap (zero padding = OOB voffset)
-  unsigned avoff[NA], amask[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const i32x4 ri = rowinfo[lrow + RPP * i];
-    avoff[i] = (unsigned)ri.x + lcb;
-    unsigned mk = (unsigned)ri.y;
-    if (p.mask_lce) {  // uniform; the stem only
-      unsigned colmask = 0;
-      const unsigned rowmask = mk;
-      mk = 0;
-#pragma nounroll
-      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ri.z + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
-#pragma nounroll
-      for (int ty = 0; ty < c_nty; ++ty)
-        if ((rowmask >> ty) & 1u) mk |= colmask << (ty * c_ntx);
-    }
-    amask[i] = mk;
   }
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
   // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
@@ -326,28 +302,23 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
   for (int k = 0; k < PF; ++k)
     if (k < T_) gload_a(k);
+  stamp(2);
+  // (4) output byte offset of every tile row, for the epilogue (off the critical path: the loads are in flight)
+  if (t < BM) {
+    const int m = m0 + t;
+    int yo = -1;
+    if (m < c_M) {
+      const int n = dc_fastdiv(m, c_dohw);
+      const int rem = m - n * (c_OH * c_OW);
+      const int oy = dc_fastdiv(rem, c_dow);
+      const int ox = rem - oy * c_OW;
+      yo = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * ES);
+    }
+    rowinfo[t] = yo;
+  }
   stamp(3);
-
-  // (5) output addressing of the rows this wave will finalise, and (small tiles) the shortcut itself.
-  //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
-  //     With in-workgroup split-K every one of the WK waves finalises RPW of the 16 accumulator registers.
   const __amdgpu_buffer_rsrc_t yr = dc_rsrc(reinterpret_cast<T*>(p.y) + c_yoff, 0x7fffffffu);
   const __amdgpu_buffer_rsrc_t rr = dc_rsrc(reinterpret_cast<const T*>(p.resid ? p.resid : p.y) + c_yoff, 0x7fffffffu);
-  float rs[EARLY_RESID ? FM * FN * RPW : 1];
-  if (EARLY_RESID && p.resid) {
-#pragma unroll
-    for (int a = 0; a < FM; ++a)
-#pragma unroll
-      for (int b = 0; b < FN; ++b)
-#pragma unroll
-        for (int e = 0; e < RPW; ++e) {
-          const int r = wk * RPW + e;
-          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
-          const int co = n0 + wc * TN + b * 32 + (lane & 31);
-          const unsigned off = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;
-          rs[(a * FN + b) * RPW + e] = Elem<T>::load(rr, off);
-        }
-  }
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -400,8 +371,26 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     gload_a(0);
     gload_b(0);
   }
-  __syncthreads();
+  __syncthreads();  // tile 0 staged; the rows' output offsets are visible
   frag_load(0, 0, 0);
+  // (5) small wave tiles: the shortcut itself is requested now, before the K loop.
+  //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
+  //     With in-workgroup split-K every one of the WK waves finalises RPW of the 16 accumulator registers.
+  float rs[EARLY_RESID ? FM * FN * RPW : 1];
+  if (EARLY_RESID && p.resid) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int e = 0; e < RPW; ++e) {
+          const int r = wk * RPW + e;
+          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+          const int co = n0 + wc * TN + b * 32 + (lane & 31);
+          const unsigned off = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;
+          rs[(a * FN + b) * RPW + e] = Elem<T>::load(rr, off);
+        }
+  }
   stamp(4);
   for (int it0 = 0; it0 < T_; it0 += PF) {
 #pragma unroll
@@ -454,7 +443,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
         for (int i = 0; i < WVEC; ++i) {
           const int v = t + i * NT, row = v / (BN / 8), cv = v - row * (BN / 8);
-          const int yo = rowinfo[row].w;
+          const int yo = rowinfo[row];
           const int co = n0 + cv * 8;
           woff[i] = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;  // Cout % 8 == 0: a vector is all in or all out
           if (p.resid) wres[i] = dc_bload4(rr, woff[i], 0);
@@ -535,7 +524,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 #pragma unroll
         for (int e = 0; e < RPW; ++e) {
           const int r = MYK * RPW + e;
-          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)].w;
+          const int yo = rowinfo[wr * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
           off[e] = (yo >= 0 && cok) ? (unsigned)yo + co * ES : kOOB;  // masked lanes: load 0 / store dropped
         }
         if (EARLY_RESID) {

@@ -103,7 +103,11 @@ void Storage::ensure_dev(size_t n) {
   if (dev) HIPCHECK(hipFree(dev));
   dev = nullptr;
   HIPCHECK(hipMalloc((void**)&dev, bytes));
-  HIPCHECK(hipMemset(dev, 0, bytes));  // pitch-padding channels stay 0
+  // pitch-padding channels stay 0.  The fill runs on the NULL stream and may return before it has executed, while the
+  // executors' streams are non-blocking (they do not wait for the NULL stream): without the wait below the fill could land
+  // AFTER the first kernels of a forward had written the buffer (seen once as garbage in a clone's first request).
+  HIPCHECK(hipMemset(dev, 0, bytes));
+  HIPCHECK(hipStreamSynchronize(nullptr));
   dev_cap = bytes;
   if (owner) {  // captured graphs carry the old address: they are re-captured lazily (PlanState::graph_buf_gen)
     ++owner->buf_gen_;
@@ -1152,7 +1156,6 @@ void Net::build_plan() {
         g.ddx = 0;
         g.klen = klen;
         g.Ktot = c.kh * klen;
-        g.mask_lce = 1;  // a tap covers kw pixels: column validity varies inside it
         kgcd = klen;
         l.w = get_vec(dkey + "w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
           h.assign((size_t)c.num_output * g.Ktot, 0.f);
@@ -1828,6 +1831,7 @@ void Net::run_launch(const Launch& l, void* s) {
         long long* d = nullptr;
         HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
         HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
+        HIPCHECK(hipStreamSynchronize(nullptr));
         for (int rep = 0; rep < 3; ++rep) {
           g.dbg = d;
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
@@ -1854,10 +1858,10 @@ void Net::run_launch(const Launch& l, void* s) {
         std::fprintf(stderr, "[dc timing] first wave start -> last wave start %.2f us | first start -> last end %.2f us | wave entry -> kernel "
                      "arguments there %.2f us | waves %ld\n",
                      (t0max - t0min) / 100.0, (t7max - t0min) / 100.0, karg / std::max(cnt, 1L) / 100.0, cnt);
-        // conv_gemm slots: 0 start, 1 filter loads + epilogue constants issued, 2 pixel decode + barrier, 3 activation loads
-        // issued, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
-        static const char* kGemm[7] = {"filter-load issue", "decode+barrier", "activation-load issue", "wait+stage+barrier", "K loop",
-                                       "split-K exchange", "epilogue math+stores"};
+        // conv_gemm slots: 0 start, 1 filter loads + epilogue constants issued, 2 rows decoded + activation loads issued,
+        // 3 output offsets in LDS, 4 first tile staged (K-loop entry), 5 K-loop exit, 6 split-K exchange done, 7 stores issued
+        static const char* kGemm[7] = {"filter-load issue", "row decode + activation-load issue", "output offsets to LDS", "wait+stage+barrier",
+                                       "K loop", "split-K exchange", "epilogue math+stores"};
         static const char* kWino[7] = {"index setup", "first loads issued", "two stages in LDS", "K loop", "partials to LDS + barrier",
                                        "inverse transform + epilogue constants", "shortcut + stores"};
         std::string line;

@@ -9,7 +9,7 @@ import pytest
 from conftest import rand_image
 
 pytestmark = pytest.mark.gpu
-H, W = 72, 104
+H, W = [int(v) for v in os.environ.get("DC_TEST_VARIANT_HW", "72,104").split(",")]  # override to sweep another input size
 NUM_VARIANTS = 32  # csrc/kernels.hip kVariants; the last test fails if the table grows without this number
 
 
