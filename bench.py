@@ -367,33 +367,42 @@ def main():
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
             },
         }
-        if world == 1:
+        # --- measurements reported BESIDE the headline (never as `value`).  Each one is guarded: whatever happens in them,
+        #     the line with `value`, `roofline` (and, if it ran, `cpu_baseline`) is printed.
+        def beside(key, fn):
+            try:
+                res[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("bench.py: %s failed: %s" % (key, e), file=sys.stderr)
+
+        def pcie_inclusive():
             # the boundary as pycaffe uses it: host NCHW buffers in, host maps out (4.8 MB up + 10.2 MB down per
-            # 544x736 image over PCIe, pageable numpy memory) — reported beside `value`, never as `value`
+            # 544x736 image over PCIe, pageable numpy memory)
             xh = x.cpu().numpy()
             net.forward_batch(xh)
             t1 = time.perf_counter()
-            n_pcie = max(3, min(20, args.steps))
             for _ in range(n_pcie):
                 net.forward_batch(xh)
             dt_pcie = time.perf_counter() - t1
-            res["pcie_inclusive"] = {"value": n_pcie * B / dt_pcie, "unit": "images/s",
-                                     "ms_per_forward": dt_pcie / n_pcie * 1e3,
-                                     "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
-            # the image entry: uint8 pixels up (1.2 MB), pre-processing + forward + pose decode on the device,
-            # 5x14 doubles down — what the demo needs per image
+            return {"value": n_pcie * B / dt_pcie, "unit": "images/s", "ms_per_forward": dt_pcie / n_pcie * 1e3,
+                    "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
+
+        def image_entry():
+            # uint8 pixels up (1.2 MB), pre-processing + forward + pose decode on the device, 5x14 doubles down — what the
+            # demo needs per image
             img8 = np.random.RandomState(2).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
             net.forward_images(img8, 1.0, want=(), pose=True)
             t1 = time.perf_counter()
             for _ in range(n_pcie):
                 net.forward_images(img8, 1.0, want=(), pose=True)
             dt_img = time.perf_counter() - t1
-            res["pcie_inclusive_image_entry"] = {"value": n_pcie * B / dt_img, "unit": "images/s",
-                                                 "ms_per_forward": dt_img / n_pcie * 1e3,
-                                                 "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
-        if world == 1 and args.config == 1 and args.coalesce > 1:
-            # cross-request batching (deepcut_tools.Pipeline(coalesce=k)): the same independent batch-1 requests, merged k at a
-            # time into batch-k forwards on the executors — reported beside `value`, which stays batch-1 forwards in flight
+            return {"value": n_pcie * B / dt_img, "unit": "images/s", "ms_per_forward": dt_img / n_pcie * 1e3,
+                    "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
+
+        def cross_request_batching():
+            # deepcut_tools.Pipeline(coalesce=k): the same independent batch-1 requests, merged k at a time into batch-k
+            # forwards on the executors; `value` stays batch-1 forwards in flight
             from deepcut_tools import Pipeline
 
             pipe = Pipeline(net, depth=len(nets), coalesce=args.coalesce)
@@ -404,8 +413,8 @@ def main():
 
             def burst(count):
                 for i in range(count):
-                    x, o = bufs[i % len(bufs)]
-                    pipe.submit(x.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=i)
+                    xi, o = bufs[i % len(bufs)]
+                    pipe.submit(xi.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=i)
                 pipe.drain()
 
             burst(4 * args.coalesce * len(nets))
@@ -414,12 +423,19 @@ def main():
             burst(nreq)
             torch.cuda.synchronize(dev)
             dtc = time.perf_counter() - t1
-            res["cross_request_batching"] = {"value": nreq / dtc, "unit": "images/s", "coalesce": args.coalesce, "executors": len(nets),
-                                             "requests": nreq, "note": "independent batch-1 requests merged into batch-%d forwards "
-                                             "(dc_net_forward_requests), %d executors" % (args.coalesce, len(nets))}
+            return {"value": nreq / dtc, "unit": "images/s", "coalesce": args.coalesce, "executors": len(nets), "requests": nreq,
+                    "note": "independent batch-1 requests merged into batch-%d forwards (dc_net_forward_requests), %d executors"
+                            % (args.coalesce, len(nets))}
+
+        n_pcie = max(3, min(20, args.steps))
+        if world == 1:
+            beside("pcie_inclusive", pcie_inclusive)
+            beside("pcie_inclusive_image_entry", image_entry)
+        if world == 1 and args.config == 1 and args.coalesce > 1 and B == 1:
+            beside("cross_request_batching", cross_request_batching)
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
-            # the other single-GPU configuration of BASELINE.json, timed by the same run (never `value`)
-            res["config2_f16"] = config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights)
+            # the other single-GPU configuration of BASELINE.json, timed by the same run
+            beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights))
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()
@@ -427,9 +443,9 @@ def main():
                 f.write(net.plan_text())
                 f.write(net.profile_text(20))
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(lambda h, w: deepercut_prototxt(args.depth, h, w), layers,
-                                               flops_img, (H, W))
-            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            beside("cpu_baseline", lambda: cpu_baseline(lambda h, w: deepercut_prototxt(args.depth, h, w), layers, flops_img, (H, W)))
+            if "value" in res["cpu_baseline"]:
+                res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
