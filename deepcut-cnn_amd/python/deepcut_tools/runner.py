@@ -130,7 +130,7 @@ class ShardedPoseRunner(object):
         mdtype = torch.float16 if half else torch.float32
         mine = batches_of[rank]
         busy = [None] * self.depth
-        poses, payload, recv = {}, {}, {}
+        poses, payload, recv, uploaded = {}, {}, {}, {}
         reqs = []
 
         def msize(b):
@@ -180,8 +180,16 @@ class ShardedPoseRunner(object):
                     finish(q)
                 self._seen.add(key)
             st = self._streams[e]
+            ids = tuple(items[k][0] for k in chunk)
             with torch.cuda.device(dev), torch.cuda.stream(st):
-                img_t = torch.from_numpy(np.stack([images[items[k][0]] for k in chunk])).to(dev, non_blocking=True)
+                # the scales of a pyramid forward the SAME images: their uint8 pixels are stacked and uploaded once
+                if ids not in uploaded:
+                    up = torch.from_numpy(np.stack([images[i] for i in ids])).to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    uploaded[ids] = (up, ev)
+                img_t, up_ev = uploaded[ids]
+                st.wait_event(up_ev)  # the upload may have been enqueued on another executor's stream
                 pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device=dev)
                 mbuf = torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None
             assert img_t.device == dev and pose_t.device == dev

@@ -56,7 +56,11 @@ def main():
                                           "tflops": 8 * 823.8e9 / dt / 1e12}
     dt = timed(lambda: r.run(imgs8, [1.0]), 10)
     out["config4_share_8_images_fp16"] = {"seconds": dt, "images_per_s": 8 / dt}
-    del r, half
+    r2 = ShardedPoseRunner(half, max_batch=8, depth=2)
+    dt = timed(lambda: r2.run(imgs8, scales), 5)
+    out["config3_pyramid_fp16_batch8_2_batches_in_flight"] = {"seconds_per_batch_of_8_pyramids": dt, "images_per_s": 8 / dt,
+                                                              "forwards_per_s": 32 / dt, "tflops": 8 * 823.8e9 / dt / 1e12}
+    del r, r2, half
 
     full = make_net("f32")
     r = ShardedPoseRunner(full, max_batch=8)
