@@ -23,6 +23,12 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1"
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o m -- $PMC_CMD > /dev/null 2> $OUT/pmc_mfma.err
+MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+# the same counters on the batched forwards: batch 2 (what cross-request batching runs) and batch 8 (configs[3]'s share)
+for B in 2 8; do
+  timeout 300 python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --steps 5 --warmup 2 --breakdown $OUT/per_launch_b$B.txt > $OUT/bench_s1_b$B.json 2>> $OUT/bench.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $MF -d $OUT/pmc_mfma_b$B -o m -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --no-graph --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_mfma_b$B.err
+done
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $PMC_CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $PMC_CMD > /dev/null 2> $OUT/pmc_write.err
 cd $R
@@ -30,9 +36,12 @@ db() { find $OUT/$1 -name "*.db" | head -1; }
 python tools/rocprof_summary.py $(db stats) > $OUT/kernel_stats.txt 2> $OUT/post.err
 python tools/rocprof_gaps.py $(db stats) > $OUT/kernel_gaps.txt 2>> $OUT/post.err
 python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
+for B in 2 8; do
+  python tools/pmc_mfma_util.py $(db pmc_mfma_b$B) "the same counters over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --no-graph --steps 2 --warmup 1\` (float32, batch $B, one forward at a time)" $OUT/per_launch_b$B.txt > $OUT/pmc_mfma_util_batch$B.txt 2>> $OUT/post.err
+done
 python tools/pmc_hbm_traffic.py $(db pmc_fetch) $(db pmc_write) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\`, $TAG" > $OUT/pmc_hbm_traffic.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch) $(db pmc_write) > $OUT/pmc_hbm_traffic_per_shape.txt 2>> $OUT/post.err
 timeout 600 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err
-rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT | head -40
 tail -c 400 $OUT/bench.json; tail -5 $OUT/post.err
