@@ -20,6 +20,7 @@ class Pipeline(object):
         self._next = 0
         self._pending = collections.deque()  # (executor, [tags])
         self._held = []                      # requests waiting for their batch to fill: (in, h, w, prob, loc, next, tag)
+        self._done = collections.deque()     # tags of finished requests not yet handed back
 
     @property
     def depth(self):
@@ -65,23 +66,19 @@ class Pipeline(object):
     def _wait_group(self):
         k, tags = self._pending.popleft()
         self.nets[k].synchronize()
-        self._done = getattr(self, "_done", collections.deque())
         self._done.extend(tags)
 
     def wait_one(self):
         """Block until the oldest in-flight request has finished; returns its tag."""
-        done = getattr(self, "_done", None)
-        if not done:
+        if not self._done:
             self.flush()
             self._wait_group()
-            done = self._done
-        return done.popleft()
+        return self._done.popleft()
 
     def drain(self):
         self.flush()
         while self._pending:
             self._wait_group()
-        tags = list(getattr(self, "_done", []))
-        if hasattr(self, "_done"):
-            self._done.clear()
+        tags = list(self._done)
+        self._done.clear()
         return tags

@@ -110,6 +110,10 @@ class ShardedPoseRunner(object):
         if self.device is not None:
             return self.device
         if dist is not None and dist.get_backend(self.group) == "nccl":
+            if dev is None:  # host pipeline under RCCL: the tables still have to travel in device memory
+                import torch
+
+                dev = torch.device("cuda", torch.cuda.current_device())
             return dev  # RCCL moves device buffers
         return "cpu"
 
@@ -305,7 +309,7 @@ class ShardedPoseRunner(object):
         elif hasattr(self.net, "blobs"):
             nj = self.net.blobs["prob"].shape[1]  # a rank without work items still sizes the table from the model
         else:
-            nj = 14
+            nj = 0  # a rank without work items and without a model to ask: its table has no rows, the width is moot
         ncol = 2 + 5 * nj  # item index, channels of next_pred (0 when maps are not kept), the pose
         local = np.zeros((len(mine), ncol), np.float64)
         for row, k in enumerate(mine):
@@ -314,8 +318,6 @@ class ShardedPoseRunner(object):
             local[row, 2:] = poses[k].reshape(-1)
         if world > 1:
             dev = self._comm_device(dist, self._torch_device() if on_device else None)
-            if dev is None:
-                dev = "cpu"
             sizes = [len(shards[r]) * ncol for r in range(world)]  # known from the schedule: no header exchange
             got = gather_maps_known(torch.from_numpy(local).reshape(-1).to(dev), sizes, 0, self.group)
             map_bufs = None

@@ -50,7 +50,8 @@ def gather_maps_known(flat, sizes, dst=0, group=None, out=None, async_op=False):
         return [flat]
     if rank == dst:
         bufs = out if out is not None else [torch.empty(s, dtype=flat.dtype, device=flat.device) for s in sizes]
-        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst]
+        # a rank with nothing to send posts no send (sizes are known on both sides), so no receive is posted for it
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and sizes[r] > 0]
         reqs = dist.batch_isend_irecv(ops) if ops else []
         bufs[dst] = flat
         if async_op:
@@ -58,7 +59,7 @@ def gather_maps_known(flat, sizes, dst=0, group=None, out=None, async_op=False):
         for q in reqs:
             q.wait()
         return bufs
-    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst, group)])
+    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst, group)]) if sizes[rank] > 0 else []
     if async_op:
         return None, reqs
     for q in reqs:

@@ -74,7 +74,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_images=5, scales=(0.75, 1.0, 1.25)):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(here, "..", "deepcut-cnn_amd", "python"))
     sys.path.insert(0, here)
@@ -85,7 +85,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = ShardedPoseRunner(FakeNet()).run(_images(), [0.75, 1.0, 1.25], want_maps=True)
+        res = ShardedPoseRunner(FakeNet()).run(_images()[:n_images], list(scales), want_maps=True)
         if rank == 0:
             q.put((res["item_poses"], [p is not None for p in res["poses"]], sorted(res["maps"].keys()),
                    {k: v["prob"].shape for k, v in res["maps"].items()}))
@@ -112,3 +112,19 @@ def test_world2_gloo_equals_single_process():
     assert map_keys == list(range(15)) and all(have)
     for k, shp in map_shapes.items():
         assert shp == single["maps"][k]["prob"].shape
+
+
+def test_world2_gloo_with_a_rank_that_has_no_work():
+    """One image at one scale on two ranks: rank 1's shard is empty — it posts no send, rank 0 no receive for it."""
+    single = ShardedPoseRunner(FakeNet()).run(_images()[:1], [1.0], want_maps=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 1, (1.0,))) for r in range(2)]
+    for p in procs:
+        p.start()
+    item_poses, have, map_keys, _shapes = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.allclose(item_poses, single["item_poses"], atol=1e-12) and map_keys == [0] and have == [True]
