@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel MFMA utilisation table from a rocprofv3 --pmc pass (rocpd sqlite):
-   python tools/pmc_mfma_util.py <results.db> "<description line>" [plan.txt] > profiles/<name>.txt
+   python tools/pmc_mfma_util.py <results.db> "<description line>" [plan.txt [bench.json]] > profiles/<name>.txt
 With a plan file (bench.py --breakdown output, or Net.plan_text()) a second table groups the launches by network
 stage (conv1 / res2 / res3 / res4 / res5 / heads): dispatches are matched to plan lines by their order in a forward.
 Counters needed: SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE."""
@@ -49,7 +49,7 @@ def per_stage(c, plan_path):
                                                           100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * 2.4 * 1024)))
 
 
-def main(path, desc, plan_path=None):
+def main(path, desc, plan_path=None, bench_path=None):
     c = sqlite3.connect(path)
     rows = c.execute("select kernel_name, grid_size, workgroup_size, counter_name, sum(value), count(*), sum(duration) "
                      "from counters_collection group by kernel_name, grid_size, workgroup_size, counter_name").fetchall()
@@ -81,7 +81,38 @@ def main(path, desc, plan_path=None):
     print("# all convolution / deconvolution dispatches (conv1..conv5 + heads): MfmaUtil = %.1f%% of the 1024 matrix pipes over the kernels' own run time" % (100 * tm / (tg * 1024)))
     if plan_path:
         per_stage(c, plan_path)
+        in_flight(c, plan_path, bench_path)
+
+
+def in_flight(c, plan_path, bench_path):
+    """Counter collection serialises dispatches, so the regime `value` is measured in (several forwards in flight) cannot
+    be profiled per dispatch.  But a forward issues the same MFMA instructions however it is scheduled: its busy cycles,
+    counted here, times the forwards per second of the unprofiled bench line, is the share of the wall time the 1024
+    matrix pipes are busy in that regime (at the 2.4 GHz the profiled clock is NOT: an upper bound on the clock, so a
+    lower bound on the share)."""
+    n = sum(1 for ln in open(plan_path) if len(ln.split("\t")) == 4 and ln.split("\t")[0].isdigit()
+            and ("conv_gemm<" in ln or "wino_f23<" in ln))
+    busy, disp = c.execute("select sum(value), count(*) from counters_collection where counter_name = 'SQ_VALU_MFMA_BUSY_CYCLES' "
+                           "and (kernel_name like '%conv_gemm%' or kernel_name like '%wino_f23%')").fetchone()
+    if not n or not disp or disp % n:
+        return
+    per_fwd = busy / (disp // n)
+    print("# MFMA busy cycles per forward (all %d convolution launches, summed over the 1024 SIMDs): %.3e" % (n, per_fwd))
+    if not bench_path:
+        return
+    import json
+
+    b = json.loads(open(bench_path).read().strip().splitlines()[-1])
+    batch = b["config"].get("per_gpu_batch", 1)
+    rows = [("one forward at a time", b.get("one_forward_at_a_time", {}).get("value")),
+            ("%s forwards in flight (`value`)" % b["config"].get("forwards_in_flight", "?"), b.get("value")),
+            ("cross-request batching", b.get("cross_request_batching", {}).get("value"))]
+    print("# share of the wall time the matrix pipes are busy = busy cycles per forward x forwards/s / (2.4e9 x 1024):")
+    for name, v in rows:
+        if v:
+            print("#   %-36s %7.1f images/s -> %.1f%%" % (name, v, 100 * per_fwd * (v / batch) / (2.4e9 * 1024)))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", sys.argv[3] if len(sys.argv) > 3 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", sys.argv[3] if len(sys.argv) > 3 else None,
+         sys.argv[4] if len(sys.argv) > 4 else None)

@@ -35,9 +35,9 @@ cd $R
 db() { find $OUT/$1 -name "*.db" | head -1; }
 python tools/rocprof_summary.py $(db stats) > $OUT/kernel_stats.txt 2> $OUT/post.err
 python tools/rocprof_gaps.py $(db stats) > $OUT/kernel_gaps.txt 2>> $OUT/post.err
-python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
+python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt $OUT/bench.json > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
 for B in 2 8; do
-  python tools/pmc_mfma_util.py $(db pmc_mfma_b$B) "the same counters over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --no-graph --steps 2 --warmup 1\` (float32, batch $B, one forward at a time)" $OUT/per_launch_b$B.txt > $OUT/pmc_mfma_util_batch$B.txt 2>> $OUT/post.err
+  python tools/pmc_mfma_util.py $(db pmc_mfma_b$B) "the same counters over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --no-graph --steps 2 --warmup 1\` (float32, batch $B, one forward at a time)" $OUT/per_launch_b$B.txt $OUT/bench_s1_b$B.json > $OUT/pmc_mfma_util_batch$B.txt 2>> $OUT/post.err
 done
 python tools/pmc_hbm_traffic.py $(db pmc_fetch) $(db pmc_write) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\`, $TAG" > $OUT/pmc_hbm_traffic.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch) $(db pmc_write) > $OUT/pmc_hbm_traffic_per_shape.txt 2>> $OUT/post.err
