@@ -105,8 +105,7 @@ def in_flight(c, plan_path, bench_path):
     b = json.loads(open(bench_path).read().strip().splitlines()[-1])
     batch = b["config"].get("per_gpu_batch", 1)
     rows = [("one forward at a time", b.get("one_forward_at_a_time", {}).get("value")),
-            ("%s forwards in flight (`value`)" % b["config"].get("forwards_in_flight", "?"), b.get("value")),
-            ("cross-request batching", b.get("cross_request_batching", {}).get("value"))]
+            ("%s forwards in flight (`value`)" % b["config"].get("forwards_in_flight", "?"), b.get("value"))]
     print("# share of the wall time the matrix pipes are busy = busy cycles per forward x forwards/s / (2.4e9 x 1024):")
     for name, v in rows:
         if v:
