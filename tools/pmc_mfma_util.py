@@ -18,11 +18,13 @@ def stage_of(label):
 
 
 def per_stage(c, plan_path):
-    labels = []
+    labels, unprof = [], []
     for ln in open(plan_path):
         f = ln.rstrip("\n").split("\t")
         if len(f) == 4 and f[0].isdigit() and ("conv_gemm<" in f[1] or "wino_f23<" in f[1]):
             labels.append(f[3])
+        if len(f) == 7 and f[0].isdigit() and ("conv_gemm<" in f[1] or "wino_f23<" in f[1]):
+            unprof.append(float(f[2]))  # bench.py --breakdown: hipEvent microseconds of this launch, nothing profiled
     n = len(labels)
     rows = c.execute("select dispatch_id, counter_name, value, duration from counters_collection where (kernel_name like '%conv_gemm%' or kernel_name like '%wino_f23%') "
                      "and counter_name in ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES') order by dispatch_id").fetchall()
@@ -31,22 +33,30 @@ def per_stage(c, plan_path):
         print("# per-stage table skipped: %d conv_gemm dispatches is not a multiple of the plan's %d" % (len(ids), n))
         return
     pos = {d: i % n for i, d in enumerate(ids)}
+    have_u = len(unprof) == n
     agg = collections.OrderedDict()
     for d, cn, v, dur in rows:
-        a = agg.setdefault(stage_of(labels[pos[d]]), {"GRBM_GUI_ACTIVE": 0.0, "SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "n": 0, "ns": 0.0})
+        a = agg.setdefault(stage_of(labels[pos[d]]), {"GRBM_GUI_ACTIVE": 0.0, "SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "n": 0, "ns": 0.0, "uns": 0.0})
         a[cn] += v
         if cn == "GRBM_GUI_ACTIVE":
             a["n"] += 1
             a["ns"] += dur
+            if have_u:
+                a["uns"] += unprof[pos[d]] * 1e3
     print("# by network stage (%d forwards of %d conv_gemm launches):" % (len(ids) // n, n))
-    print("%-18s %9s %12s %9s %12s" % ("stage", "launches", "busy share", "MfmaUtil", "MfmaUtil(t)"))
+    if have_u:
+        print("# MfmaUtil(u) = the same busy cycles / (the launch's UNPROFILED duration x 2.4 GHz x 1024 SIMDs): hipEvents around each launch of")
+        print("#            a plain run (bench.py --breakdown, same tiles) - a counter-collecting dispatch takes 15-25 % longer than it does in")
+        print("#            production, the MFMA instructions it issues are the same")
+    print("%-18s %9s %12s %9s %12s %12s" % ("stage", "launches", "busy share", "MfmaUtil", "MfmaUtil(t)", "MfmaUtil(u)"))
     tot = sum(a["GRBM_GUI_ACTIVE"] for a in agg.values())
     for st in ("conv1", "res2 (conv2_x)", "res3 (conv3_x)", "res4 (conv4_x)", "res5 (conv5_x)", "heads"):
         if st in agg:
             a = agg[st]
-            print("%-18s %9d %11.1f%% %8.1f%% %11.1f%%" % (st, a["n"] * n // len(ids), 100 * a["GRBM_GUI_ACTIVE"] / tot,
-                                                          100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024),
-                                                          100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * 2.4 * 1024)))
+            print("%-18s %9d %11.1f%% %8.1f%% %11.1f%% %11s" % (st, a["n"] * n // len(ids), 100 * a["GRBM_GUI_ACTIVE"] / tot,
+                                                               100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024),
+                                                               100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["ns"] * 2.4 * 1024),
+                                                               "%.1f%%" % (100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["uns"] * 2.4 * 1024)) if have_u else "-"))
 
 
 def main(path, desc, plan_path=None, bench_path=None):
