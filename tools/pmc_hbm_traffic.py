@@ -2,7 +2,8 @@
 """HBM traffic per conv_gemm launch from two rocprofv3 --pmc passes (rocpd sqlite), as MI355X_MICROARCH.md's HBM
 section prescribes: FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, both in KB, FETCH_SIZE x2 on gfx950 for
 wide (16 B/lane) coalesced reads, WRITE_SIZE taken as is.
-   python tools/pmc_hbm_traffic.py fetch.db write.db "<description>" > profiles/<name>.json"""
+   python tools/pmc_hbm_traffic.py fetch.db write.db "<description>" [minimum bytes per forward] > profiles/<name>.json
+The minimum defaults to the float32 batch-1 forward at 544x736 (2.07 GB of activations + 0.263 GB of filters)."""
 import json
 import sqlite3
 import sys
@@ -22,7 +23,7 @@ def family(path, counter, like):
     return (v or 0.0) / max(n, 1), n
 
 
-def main(fetch_db, write_db, desc):
+def main(fetch_db, write_db, desc, min_bytes_per_forward=2.07e9 + 0.263e9):
     f, nf = per_launch(fetch_db, "FETCH_SIZE")
     w, nw = per_launch(write_db, "WRITE_SIZE")
     fam = {}
@@ -40,9 +41,9 @@ def main(fetch_db, write_db, desc):
         "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced "
                       "(16 B/lane) streaming reads -> x2; WRITE_SIZE uncalibrated, taken as is; both counters are KB",
         "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
-        "algorithmic_min_bytes_per_launch": (2.07e9 + 0.263e9) / launches_per_forward,
+        "algorithmic_min_bytes_per_launch": min_bytes_per_forward / launches_per_forward,
     }, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "", float(sys.argv[4]) if len(sys.argv) > 4 else 2.07e9 + 0.263e9)

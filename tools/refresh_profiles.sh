@@ -31,6 +31,11 @@ for B in 2 8; do
 done
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- $PMC_CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- $PMC_CMD > /dev/null 2> $OUT/pmc_write.err
+timeout 400 rocprofv3 --kernel-trace --pmc $MF -d $OUT/pmc_mfma16 -o m -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_mfma16.err
+# HBM traffic of the float16 batch-8 forward (configs[2]'s unit): minimum = 8 x 2.07 GB / 2 of activations + 0.263 GB / 2 of filters
+PMC16="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch16 -o f -- $PMC16 > /dev/null 2> $OUT/pmc_fetch16.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write16 -o w -- $PMC16 > /dev/null 2> $OUT/pmc_write16.err
 cd $R
 db() { find $OUT/$1 -name "*.db" | head -1; }
 python tools/rocprof_summary.py $(db stats) > $OUT/kernel_stats.txt 2> $OUT/post.err
@@ -41,7 +46,10 @@ for B in 2 8; do
 done
 python tools/pmc_hbm_traffic.py $(db pmc_fetch) $(db pmc_write) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\`, $TAG" > $OUT/pmc_hbm_traffic.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch) $(db pmc_write) > $OUT/pmc_hbm_traffic_per_shape.txt 2>> $OUT/post.err
+python tools/pmc_mfma_util.py $(db pmc_mfma16) "the same counters over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1\` (float16 operands, batch 8, one forward at a time; v_mfma_f32_32x32x16_f16 = 32 busy cycles)" $OUT/per_launch_f16_b8.txt $OUT/bench_f16_batch8.json > $OUT/pmc_mfma_util_f16_b8.txt 2>> $OUT/post.err
+python tools/pmc_hbm_traffic.py $(db pmc_fetch16) $(db pmc_write16) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1\`, $TAG" 8.4115e9 > $OUT/pmc_hbm_traffic_f16_b8.json 2>> $OUT/post.err
+python tools/pmc_per_shape.py $(db pmc_fetch16) $(db pmc_write16) > $OUT/pmc_hbm_traffic_per_shape_f16_b8.txt 2>> $OUT/post.err
 timeout 600 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err
-rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_mfma16
 ls -la $OUT | head -40
 tail -c 400 $OUT/bench.json; tail -5 $OUT/post.err
