@@ -400,6 +400,22 @@ def main():
             return {"value": n_pcie * B / dt_pcie, "unit": "images/s", "ms_per_forward": dt_pcie / n_pcie * 1e3,
                     "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
 
+        def pycaffe_forward():
+            # the reference's own call sequence (python/pose/estimate_pose.py:104-112): write blobs['data'].data, net.forward(),
+            # read the three output blobs — host blobs are pinned memory owned by the library
+            xh = x.cpu().numpy()
+            net.blobs["data"].data[...] = xh
+            net.forward()
+            t1 = time.perf_counter()
+            for _ in range(n_pcie):
+                net.blobs["data"].data[...] = xh
+                net.forward()
+                outs_h = [net.blobs[k].data for k in ("prob", "loc_pred", "next_pred")]
+            dt_py = time.perf_counter() - t1
+            assert all(o.size for o in outs_h)
+            return {"value": n_pcie * B / dt_py, "unit": "images/s", "ms_per_forward": dt_py / n_pcie * 1e3,
+                    "note": "pycaffe drop-in path: blobs['data'].data[...] = image; net.forward(); read prob / loc_pred / next_pred"}
+
         def image_entry():
             # uint8 pixels up (1.2 MB), pre-processing + forward + pose decode on the device, 5x14 doubles down — what the
             # demo needs per image
@@ -443,6 +459,7 @@ def main():
         if world == 1:
             beside("pcie_inclusive", pcie_inclusive)
             beside("pcie_inclusive_image_entry", image_entry)
+            beside("pycaffe_forward", pycaffe_forward)
         if world == 1 and args.config == 1 and args.coalesce > 1 and B == 1:
             beside("cross_request_batching", cross_request_batching)
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
