@@ -3,7 +3,7 @@
 # one) with the SAME tile choices (profiles/r02_tune_cache.txt).   gpu_libs.sh <tag> name...
 OUT=gpurun_out/${1:-libs}; shift
 mkdir -p $OUT
-for rep in 1 2 3; do for which in base "$@"; do
+for rep in 1 2; do for which in base "$@"; do
   if [ $which = base ]; then unset DEEPCUT_HIP_LIB; else export DEEPCUT_HIP_LIB=$PWD/tools/probes/bin/lib_$which.so; fi
   cp profiles/r02_tune_cache.txt $OUT/tune_cache.txt
   DC_TUNE_CACHE=$OUT/tune_cache.txt timeout 200 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --steps 100 --warmup 10 > $OUT/$which.json 2> $OUT/$which.err
