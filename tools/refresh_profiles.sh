@@ -21,8 +21,6 @@ timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --confi
 timeout 300 python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --config 3 --dtype f16 --steps 10 --warmup 2 > $OUT/bench_config3_f16.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
-# the regime `value` is measured in: three forwards in flight (kernel trace of the default command's streams; rocprof_overlap.py)
-timeout 300 rocprofv3 --kernel-trace -d $OUT/ovl -o o -- python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --steps 60 --warmup 5 > $OUT/bench_in_flight_under_rocprof.json 2> $OUT/rocprof_ovl.err
 PMC_CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1"
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o m -- $PMC_CMD > /dev/null 2> $OUT/pmc_mfma.err
 MF="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
@@ -42,7 +40,6 @@ cd $R
 db() { find $OUT/$1 -name "*.db" | head -1; }
 python tools/rocprof_summary.py $(db stats) > $OUT/kernel_stats.txt 2> $OUT/post.err
 python tools/rocprof_gaps.py $(db stats) > $OUT/kernel_gaps.txt 2>> $OUT/post.err
-{ echo "# rocprofv3 --kernel-trace over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --steps 60 --warmup 5\` (the span in which the extra streams carry kernels = 3 forwards in flight)"; python tools/rocprof_overlap.py $(db ovl); } > $OUT/kernel_overlap_in_flight.txt 2>> $OUT/post.err
 python tools/pmc_mfma_util.py $(db pmc_mfma) "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 3 --warmup 1\` with a warm DC_TUNE_CACHE (tools/refresh_profiles.sh): one forward at a time" $OUT/per_launch.txt $OUT/bench.json > $OUT/pmc_mfma_util.txt 2>> $OUT/post.err
 for B in 2 8; do
   python tools/pmc_mfma_util.py $(db pmc_mfma_b$B) "the same counters over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --batch $B --no-graph --steps 2 --warmup 1\` (float32, batch $B, one forward at a time)" $OUT/per_launch_b$B.txt $OUT/bench_s1_b$B.json > $OUT/pmc_mfma_util_batch$B.txt 2>> $OUT/post.err
@@ -53,6 +50,6 @@ python tools/pmc_mfma_util.py $(db pmc_mfma16) "the same counters over \`bench.p
 python tools/pmc_hbm_traffic.py $(db pmc_fetch16) $(db pmc_write16) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1\`, $TAG" 8.4115e9 > $OUT/pmc_hbm_traffic_f16_b8.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch16) $(db pmc_write16) > $OUT/pmc_hbm_traffic_per_shape_f16_b8.txt 2>> $OUT/post.err
 timeout 600 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err
-rm -rf $OUT/stats $OUT/ovl $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_mfma16
+rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_mfma16
 ls -la $OUT | head -40
 tail -c 400 $OUT/bench.json; tail -5 $OUT/post.err

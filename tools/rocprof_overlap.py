@@ -18,13 +18,19 @@ def main(path):
     main_q = max(per_q, key=per_q.get)
     extra = [(s, e) for s, e, q in rows if q != main_q]
     if extra:
-        # the last contiguous burst on the extra queues (warm-up and timed region run back to back; tuning launches, if
-        # any, are long before): walk back from the end until a gap of more than 5 ms
+        # the longest contiguous burst on the extra queues (warm-up and timed region run back to back; gaps of more than 5 ms
+        # separate bursts)
         extra.sort()
-        lo = len(extra) - 1
-        while lo > 0 and extra[lo][0] - extra[lo - 1][1] < 5e6:
-            lo -= 1
-        t0, t1 = extra[lo][0], max(e for _, e in extra[lo:])
+        bursts, cur = [], [extra[0]]
+        for se in extra[1:]:
+            if se[0] - max(e for _, e in cur[-8:]) < 5e6:
+                cur.append(se)
+            else:
+                bursts.append(cur)
+                cur = [se]
+        bursts.append(cur)
+        best = max(bursts, key=len)  # the bursts of a few kernels are stray copies / fills on other queues
+        t0, t1 = best[0][0], max(e for _, e in best)
         rows = [(max(s, t0), min(e, t1), q) for s, e, q in rows if e > t0 and s < t1]
     ev = []
     for s, e, q in rows:
