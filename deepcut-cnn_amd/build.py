@@ -34,7 +34,7 @@ def build_lib(force=False, verbose=True):
     objs = []
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
                "-c", os.path.join(CSRC, src), "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")

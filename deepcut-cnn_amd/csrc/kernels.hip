@@ -48,6 +48,29 @@ __device__ __forceinline__ int dc_fastdiv(int n, const unsigned (&mg)[2]) {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// LDS-DMA (`buffer_load_dwordx4 ... lds`): 64 lanes x 16 bytes travel from global memory straight into LDS, no VGPRs and
+// no ds_write.  The LDS destination is M0 + 16*lane (lane-linear, 1 KiB per wave instruction); the SOURCE address is per
+// lane (V# base + voffset + soffset), so a swizzled LDS image is made by permuting which 16-byte chunk each lane
+// fetches.  An out-of-range voffset stores zeros (the zero padding of the gather keeps working unchanged).
+// Written as inline asm on purpose: through the builtin the compiler knows that LDS is written behind its back and
+// makes every later ds_read wait for vmcnt(0) — the pipeline below keeps 1-2 tiles in flight across its barriers and
+// counts vmcnt itself.  (M0 is written in the same statement that reads it; the compiler does not use M0 on this path.)
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ i32x4 dc_rsrc_words(const void* p) {
+  const unsigned long long a = (unsigned long long)p;
+  return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+}
+__device__ __forceinline__ void dc_dma16(i32x4 rs, unsigned lds, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff)
+               : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void dc_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// own LDS traffic retired, then the workgroup barrier (a raw s_barrier: __syncthreads() would drain vmcnt too)
+__device__ __forceinline__ void dc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Kernel arguments are fetched lazily, cache line by cache line, wherever the compiler first needs a field: the gather-GEMM
 // touched four lines of its 632-byte block at four different points of its prologue, each first touch a scalar-cache miss
 // on the critical path.  DC_KARG_TOUCH requests one dword of each of the first five lines (every field but the multi-class table) at kernel entry (results unused), so
@@ -98,7 +121,10 @@ struct Elem<_Float16> {
 };
 
 // MC: multi-class launch (ConvGemmParams::ncls > 1): the class-dependent scalars come from p.cls[class of this block].
-template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false>
+// DMA: 0 = operands staged through a register ring (PF tiles) and ds_write_b128 into two padded LDS stages;
+//      D >= 2 = operands fetched by LDS-DMA into a ring of D unpadded, XOR-swizzled LDS stages (tile rows of 128 bytes),
+//      D - 1 tiles requested ahead, one raw barrier per tile, vmcnt counted by hand (PF unused).
+template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0>
 __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();  // before the first kernel-argument load (DC_DEBUG_TIMING)
   DC_KARG_TOUCH(ka0, ka1, ka2, ka3, ka4);
@@ -108,7 +134,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int NW = WR * WC * WK;       // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  constexpr int LDB = BK * ES + 16;      // padded LDS row, bytes (16-B aligned, bank-spread)
+  constexpr int LDB = DMA ? BK * ES : BK * ES + 16;  // LDS row, bytes: padded (16-B aligned, bank-spread), or 128 swizzled (DMA)
+  static_assert(!DMA || BK * ES == 128, "the LDS-DMA image has 128-byte rows (8 chunks of 16 bytes, XOR-swizzled)");
+  static_assert(DMA == 0 || (DMA >= 2 && DMA <= 4), "ring of 2..4 LDS stages");
+  constexpr int NSTG = DMA ? DMA : 2;
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1 && TM % 32 == 0 && TN % 32 == 0, "wave tile = multiples of 32x32");
@@ -121,23 +150,27 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int NCH = KCH / WK;          // chunks this wave owns per tile
   static_assert(NCH >= 2 && NCH % 2 == 0, "the software pipeline needs an even number (>=2) of chunks per wave");
   constexpr int NST = NCH * SPC;         // MFMA steps per tile per wave
-  static_assert(NST >= 4, "the pipeline places its work in 4 distinct MFMA steps");
+  static_assert(DMA || NST >= 4, "the register-ring pipeline places its work in 4 distinct MFMA steps");
   constexpr int GBAR = SPC > 1 ? NST - 3 : NST - 1;  // step before which the tile's barrier is taken
   constexpr int TILEB = (BM + BN) * LDB;  // bytes per LDS stage
   constexpr int RPW = 16 / WK;           // accumulator registers each split-K wave finalises
-  static_assert((WK - 1) * BM * BN * 4 <= 2 * TILEB, "split-K partials must fit in the tile buffers");
+  constexpr int WPS = BN + 4;                       // wide-epilogue staging row pitch (floats)
+  // DMA: the buffer is sized for the ring, the split-K exchange and the wide epilogue's staging, whichever is largest
+  constexpr int EPIB = ES == 2 ? BM * WPS * 4 : 0;
+  constexpr int SPKB = (WK - 1) * BM * BN * 4;
+  constexpr int MAINB = DMA ? (NSTG * TILEB > EPIB ? (NSTG * TILEB > SPKB ? NSTG * TILEB : SPKB) : (EPIB > SPKB ? EPIB : SPKB)) : 2 * TILEB;
+  static_assert(SPKB <= MAINB, "split-K partials must fit in the tile buffers");
   constexpr bool EARLY_RESID = FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
   // Wide epilogue (float16): the C fragment gives a lane ONE channel of 16 different pixels, i.e. 2-byte accesses — 128 vector
   // memory instructions per lane for a 64x64 wave tile with a shortcut, and the CU's address unit, not HBM, bounds the
   // bandwidth-bound layers (K <= 512).  Instead the finished tile (fp32, after the affine) is transposed through the tile
   // buffers in LDS and every thread adds the shortcut to, and stores, 8 consecutive channels of one pixel: 16-byte accesses,
   // 8x fewer instructions; the shortcut vectors are requested before the transposition so that they are in flight meanwhile.
-  constexpr int WPS = BN + 4;                       // staging row pitch (floats)
   constexpr int WVEC = BM * (BN / 8) / NT;           // 16-byte output vectors per thread
-  constexpr bool WIDE_OK = ES == 2 && BM * WPS * 4 <= 2 * TILEB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
+  constexpr bool WIDE_OK = ES == 2 && BM * WPS * 4 <= MAINB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILEB + 4 * BM];
-  int* rowinfo = reinterpret_cast<int*>(smem + 2 * TILEB);  // per tile row: byte offset of its output pixel, or -1
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[MAINB + 4 * BM];
+  int* rowinfo = reinterpret_cast<int*>(smem + MAINB);  // per tile row: byte offset of its output pixel, or -1
   const T* px = reinterpret_cast<const T*>(p.x);
 
   const int t = threadIdx.x;
@@ -214,8 +247,14 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // ---- prologue, ordered so that every exposed memory round trip overlaps another -------------------
   // (1) filter rows need no pixel decode: their first PF tiles go out immediately
   const int lrow = t / C4;
-  const int lcb = (t % C4) * 16;  // byte column of this thread's 16-byte vector
+  // byte column of this thread's 16-byte vector.  DMA: lane l of a wave lands at LDS byte 16*l of its 1 KiB piece (8 rows of
+  // 128 bytes: row l/8, position l%8), and position p of row r holds source chunk p ^ ((r >> 1) & 7) — the swizzle that makes
+  // the ds_read_b128 fragment fetches bank-conflict-free without padding (rows of one piece set differ by multiples of 32).
+  const int lcb = DMA ? ((t % C4) ^ ((lrow >> 1) & 7)) * 16 : (t % C4) * 16;
   const int lce = lcb / ES;       // same, in elements
+  static_assert(!DMA || (C4 == 8 && RPP % 32 == 0), "DMA loader: 8 lanes per row, piece sets 32 rows apart");
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned ldsw = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;  // this wave's piece of every 8*NW-row set
   unsigned bvoff[NBV];
 #pragma unroll
   for (int j = 0; j < NBV; ++j) {
@@ -223,16 +262,29 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     bvoff[j] = n < p.Cout ? (unsigned)(n * c_Ktot + lce) * ES : kOOB;  // rows past Cout read as zeros
   }
   const __amdgpu_buffer_rsrc_t wr_ = dc_rsrc(reinterpret_cast<const T*>(p.w) + c_woff, 0x7fffffffu);
-  f32x4 ra[PF][NA], rb[PF][NBV];  // 16-byte containers (4 floats or 8 halves)
+  const i32x4 wrs = dc_rsrc_words(reinterpret_cast<const T*>(p.w) + c_woff);
+  f32x4 ra[DMA ? 1 : PF][DMA ? 1 : NA], rb[DMA ? 1 : PF][DMA ? 1 : NBV];  // 16-byte containers (4 floats or 8 halves)
   int kg = 0;
   auto gload_b = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < NBV; ++j) rb[slot][j] = dc_bload4(wr_, bvoff[j], (unsigned)kg * ES);
     kg += BK;
   };
+  // DMA: the filter rows of one K tile into LDS stage `stg` (piece j = rows j*RPP + 8*wave .. +7 of the B block)
+  auto dma_b = [&](int stg) {
 #pragma unroll
-  for (int k = 0; k < PF; ++k)
-    if (k < T_) gload_b(k);
+    for (int j = 0; j < NBV; ++j) dc_dma16(wrs, ldsw + stg * TILEB + BM * LDB + j * RPP * LDB, bvoff[j], (unsigned)kg * ES);  // prologue: stage index
+    kg += BK;
+  };
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < DMA - 1; ++k)
+      if (k < T_) dma_b(k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < T_) gload_b(k);
+  }
 
   // (2) epilogue constants (folded BatchNorm/Scale/bias) also travel now
   float sc[FN], sh[FN];
@@ -277,6 +329,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // the source descriptor starts `x_bias` elements BEFORE the tensor so that every tap displacement is a
   // non-negative soffset; masked lanes never touch memory, valid lanes land inside the tensor
   const __amdgpu_buffer_rsrc_t xr = dc_rsrc(px + c_xbias, 0x7fffffffu);
+  const i32x4 xrs = dc_rsrc_words(px + c_xbias);
   // tap cursor, all uniform (SALU): (tx, c0, running bit) and the element displacement of the current tap
   int tx = 0, c0 = 0, tbit = 0;
   int row_soff = c_dy0 * p.x_row_stride + c_x0 - c_xbias;  // displacement of tap (ty, 0)
@@ -299,9 +352,49 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       }
     }
   };
+  // DMA: the tap cursor hands out (soffset, validity bit) of the next K tile ...
+  unsigned d_soff = 0, d_bit = 0, d_kg = 0;
+  auto dma_next = [&]() {
+    d_soff = (unsigned)(tap_soff + c0) * ES;
+    d_bit = 1u << tbit;
+    d_kg = (unsigned)kg * ES;
+    kg += BK;
+    c0 += BK;
+    if (c0 >= p.klen) {
+      c0 = 0;
+      ++tbit;
+      ++tx;
+      tap_soff += c_ddx;
+      if (tx >= c_ntx) {
+        tx = 0;
+        row_soff += c_ddy * p.x_row_stride;
+        tap_soff = row_soff;
+      }
+    }
+  };
+  // ... and piece pc of that tile (0..NA-1: activation rows, NA..NA+NBV-1: filter rows) goes to stage `stg`
+  auto dma_piece = [&](unsigned so, int pc) {  // so: byte offset of the stage
+    if (pc < NA)
+      dc_dma16(xrs, ldsw + so + pc * RPP * LDB, (amask[pc < NA ? pc : 0] & d_bit) ? avoff[pc < NA ? pc : 0] : kOOB, d_soff);
+    else
+      dc_dma16(wrs, ldsw + so + BM * LDB + (pc - NA) * RPP * LDB, bvoff[pc >= NA ? pc - NA : 0], d_kg);
+  };
+  if constexpr (DMA) {
+    // the filter pieces of the first DMA-1 tiles are on their way already (dma_b advanced kg): only the activation pieces here
+    const int kg_keep = kg;
 #pragma unroll
-  for (int k = 0; k < PF; ++k)
-    if (k < T_) gload_a(k);
+    for (int k = 0; k < DMA - 1; ++k)
+      if (k < T_) {
+        dma_next();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dma_piece(k * TILEB, i);
+      }
+    kg = kg_keep;
+  } else {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (k < T_) gload_a(k);
+  }
   stamp(2);
   // (4) output byte offset of every tile row, for the epilogue (off the critical path: the loads are in flight)
   if (t < BM) {
@@ -341,11 +434,14 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // MFMA operand fragments, two register sets (chunk parity); lane holds 16 bytes of row (lane&31):
   // fp32: k = 4*(lane>>5) .. +3 of the 8-deep chunk; fp16: k = 8*(lane>>5) .. +7 of the 16-deep chunk
   f32x4 av[2][FM], bv[2][FN];
-  const int frag_a = (wr * TM + (lane & 31)) * LDB + (lane >> 5) * 16 + wk * 32;
-  const int frag_b = BM * LDB + (wc * TN + (lane & 31)) * LDB + (lane >> 5) * 16 + wk * 32;
+  // DMA image: 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7); the wave's q-th operand chunk pair is chunk
+  // 2*(q*WK + wk) + (lane >> 5), and since q*WK*32 only touches address bits 5..6 it is applied as an XOR on the offset
+  const int frag_k = DMA ? (((2 * wk + (lane >> 5)) ^ ((lane >> 1) & 7)) * 16) : ((lane >> 5) * 16 + wk * 32);
+  const int frag_a = (wr * TM + (lane & 31)) * LDB + frag_k;
+  const int frag_b = BM * LDB + (wc * TN + (lane & 31)) * LDB + frag_k;
   auto frag_load = [&](int buf, int q, int set) {
-    const unsigned char* As = smem + buf * TILEB + frag_a + q * WK * 32;
-    const unsigned char* Bs = smem + buf * TILEB + frag_b + q * WK * 32;
+    const unsigned char* As = smem + buf * TILEB + (DMA ? (frag_a ^ (q * WK * 32)) : frag_a + q * WK * 32);
+    const unsigned char* Bs = smem + buf * TILEB + (DMA ? (frag_b ^ (q * WK * 32)) : frag_b + q * WK * 32);
 #pragma unroll
     for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDB);
 #pragma unroll
@@ -366,12 +462,21 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   //            stage are issued before the barrier, so the next tile may overwrite it).
   // Tile k lives in ring slot k % PF: filters are streamed from HBM once per forward (263 MB per image
   // sweep the 256 MB Infinity Cache), so a single tile of lookahead does not cover their latency.
-  lstore(0, 0);
-  if (PF < T_) {
-    gload_a(0);
-    gload_b(0);
+  if constexpr (DMA) {
+    // tile 0 has landed when at most the later prologue tiles' activation pieces (requested after it) are outstanding
+    const int pt = T_ < DMA - 1 ? T_ : DMA - 1;  // tiles requested so far
+    if (pt >= 3) dc_wait_vm<2 * NA>();
+    else if (pt == 2) dc_wait_vm<NA>();
+    else dc_wait_vm<0>();
+    dc_lds_barrier();  // every wave's pieces of tile 0 are in LDS; the rows' output offsets are visible
+  } else {
+    lstore(0, 0);
+    if (PF < T_) {
+      gload_a(0);
+      gload_b(0);
+    }
+    __syncthreads();  // tile 0 staged; the rows' output offsets are visible
   }
-  __syncthreads();  // tile 0 staged; the rows' output offsets are visible
   frag_load(0, 0, 0);
   // (5) small wave tiles: the shortcut itself is requested now, before the K loop.
   //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
@@ -392,6 +497,78 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
         }
   }
   stamp(4);
+  if constexpr (DMA) {
+    // ---- K loop, LDS-DMA form.  Tile `it` is computed from stage it % DMA while the pieces of tile it+DMA-1 are requested
+    // into the stage tile it-1 was read from (free since the barrier taken inside tile it-1).  Before the last MFMA step of a
+    // tile (fp32: the third last) every wave (a) waits until ITS pieces of tile it+1 have landed — vmcnt counts requests, the
+    // younger tiles stay in flight —, (b) waits for its own fragment reads, (c) takes the one barrier of the tile: after it
+    // tile it+1 is complete in LDS for every reader and stage it % DMA may be overwritten.  The first fragments of tile it+1
+    // are fetched right there, under the remaining MFMA step(s).
+    constexpr int PPW = NA + NBV;  // pieces (1 KiB wave requests) per wave and tile
+    static_assert(2 * PPW <= 60, "vmcnt is a 6-bit counter");
+    // The stage offsets are run-time scalars and the loop is NOT unrolled over the ring (one body for the steady state, one
+    // for the last DMA-1 tiles, one for the last tile): with an unrolled ring and an early exit in the middle the
+    // register allocator parked the 64 accumulators in different register classes on the two sides of the loop header
+    // and copied all of them (v_accvgpr_read/write) once per round.
+    unsigned sb = 0;                    // byte offset of the stage tile `it` is read from
+    unsigned sbp = (DMA - 1) * TILEB;   // ... of the stage tile it+DMA-1 goes to (tile it-1 was read from it)
+    auto frag_load_d = [&](unsigned so, int q, int set) {
+      const unsigned char* As = smem + so + (frag_a ^ (q * WK * 32));
+      const unsigned char* Bs = smem + so + (frag_b ^ (q * WK * 32));
+#pragma unroll
+      for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDB);
+#pragma unroll
+      for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDB);
+    };
+    auto tile = [&](auto more1_tag, auto moreD_tag, int it) {
+      constexpr bool more1 = decltype(more1_tag)::value, moreD = decltype(moreD_tag)::value;
+      const unsigned sbn = sb + TILEB == DMA * TILEB ? 0u : sb + TILEB;  // stage of tile it+1
+      if (moreD) dma_next();
+#pragma unroll
+      for (int g = 0; g < NST; ++g) {
+        const int q = g / SPC, st = g % SPC, cur = q & 1;
+        if (st == 0 && q + 1 < NCH) frag_load_d(sb, q + 1, cur ^ 1);
+        if (g == GBAR && more1) {
+          // tiles that may stay in flight: those after it+1 that exist, but never a prologue tile (the prologue requested
+          // all filter pieces before all activation pieces, so "the youngest n tiles" only means something for loop tiles)
+          if constexpr (moreD) {
+            if (DMA >= 4 && it == 0) dc_wait_vm<PPW>();
+            else dc_wait_vm<(DMA - 2) * PPW>();
+          } else {
+            int left = T_ - 2 - it;
+            if (left > it + 1) left = it + 1;
+            if (DMA >= 4 && left >= 2) dc_wait_vm<2 * PPW>();
+            else if (DMA >= 3 && left == 1) dc_wait_vm<PPW>();
+            else dc_wait_vm<0>();
+          }
+          dc_lds_barrier();
+          frag_load_d(sbn, 0, 0);
+        }
+        if (g < GBAR && moreD) {
+#pragma unroll
+          for (int pc = g * PPW / GBAR; pc < (g + 1) * PPW / GBAR; ++pc) dma_piece(sbp, pc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b) {
+            if constexpr (SPC == 4)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
+            else
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[cur][a]),
+                                                                 __builtin_bit_cast(f16x8, bv[cur][b]), acc[a][b], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      sbp = sb;
+      sb = sbn;
+    };
+    int it = 0;
+    for (; it < T_ - (DMA - 1); ++it) tile(std::true_type{}, std::true_type{}, it);
+    for (; it < T_ - 1; ++it) tile(std::true_type{}, std::false_type{}, it);
+    tile(std::false_type{}, std::false_type{}, it);
+  } else
   for (int it0 = 0; it0 < T_; it0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -616,6 +793,18 @@ struct VariantEntry {
         conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2,             \
         conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF, true>               \
   }
+// LDS-DMA variants: "d" prefix, BK fixed by the 128-byte row (64 halves), S = LDS stages of the ring
+#define DC_VARIANT_HD(BM, BN, WR, WC, WK, S)                                        \
+  {                                                                                \
+    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S>, 64, 2, nullptr \
+  }
+#define DC_VARIANT_HD_MC(BM, BN, WR, WC, WK, S)                                     \
+  {                                                                                \
+    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S>, 64, 2,     \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, true, S>              \
+  }
 const VariantEntry kVariants[] = {
     DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
     DC_VARIANT(128, 64, 32, 2, 2, 1, 2),   // 1
@@ -653,6 +842,16 @@ const VariantEntry kVariants[] = {
     // 256-row / 256-column tiles (one workgroup per CU): half the operand traffic per flop for the long-K matrix-class layers
     DC_VARIANT_H(256, 128, 64, 4, 2, 1, 2),   // 30
     DC_VARIANT_H(128, 256, 64, 2, 4, 1, 2),   // 31
+    // float16 through LDS-DMA (round 3): no register ring, no ds_write, unpadded swizzled stages
+    DC_VARIANT_HD(128, 128, 2, 2, 1, 2),      // 32: 66 KB -> two workgroups per CU
+    DC_VARIANT_HD(128, 128, 2, 2, 1, 3),      // 33: 96 KB, one workgroup per CU, two tiles ahead
+    DC_VARIANT_HD(128, 128, 2, 2, 2, 3),      // 34: 8 waves
+    DC_VARIANT_HD(128, 128, 2, 2, 2, 4),      // 35: 8 waves, 128 KB, three tiles ahead
+    DC_VARIANT_HD(128, 64, 2, 2, 1, 3),       // 36: 72 KB -> two per CU
+    DC_VARIANT_HD(64, 128, 2, 2, 1, 3),       // 37
+    DC_VARIANT_HD(64, 64, 2, 2, 1, 4),        // 38: 64 KB
+    DC_VARIANT_HD(256, 128, 4, 2, 1, 3),      // 39: 144 KB
+    DC_VARIANT_HD(128, 256, 2, 4, 1, 3),      // 40
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
