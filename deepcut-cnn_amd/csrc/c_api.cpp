@@ -485,4 +485,10 @@ const char* dc_net_profile_text(dc_net* net, int iters) {
   return rc == DC_OK ? n->text_buf.c_str() : nullptr;
 }
 
+
+// tile variants of the gather-GEMM (diagnostics / tests: DC_CONV_VARIANT takes an index into this table)
+int dc_conv_variant_count(void) { return dc::conv_num_variants(); }
+const char* dc_conv_variant_name(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant(i).name : nullptr; }
+int dc_conv_variant_esize(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant_esize(i) : 0; }
+
 }  // extern "C"

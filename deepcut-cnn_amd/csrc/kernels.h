@@ -77,6 +77,9 @@ struct ConvGemmParams {
   int w_TY, w_TX, w_NBY, w_NBX, w_nblk;
   unsigned w_div_nblk[2], w_div_nbyx[2], w_div_dd[2], w_div_d[2], w_div_nbx[2];
   int wide_epi;  // (filled by launch_conv_gemm) float16: 16-byte epilogue through LDS — Cout and the output strides are multiples of 8
+  int vec_epi;   // (filled) 16-byte output vectors are legal: Cout, the output strides and the bases are multiples of 16 bytes, no sigmoid
+  int dense_x;   // (filled) 1x1 / stride-1 layer over a dense NHWC tensor: output pixel m reads the klen elements at m * sx (no decode)
+  int dense_y;   // (filled) the output pixels are dense: pixel m is written at m * y_pix_stride
   int ncls;
   int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)
   ConvClass cls[kMaxClasses];

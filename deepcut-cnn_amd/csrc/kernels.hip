@@ -64,6 +64,16 @@ __device__ __forceinline__ void dc_dma16(i32x4 rs, unsigned lds, unsigned voff, 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff)
                : "memory", "m0");
 }
+// a 4-byte buffer load the compiler does not track (no s_waitcnt of its own): the caller's counted vmcnt covers it
+__device__ __forceinline__ float dc_load_f32_untracked(i32x4 rs, unsigned voff) {
+  float v;
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+  return v;
+}
+__device__ __forceinline__ void dc_permlane32_swap(float& lo, float& hi) {
+  // lanes 32..63 of `lo` <-> lanes 0..31 of `hi` (inline asm: this compiler's builtin returns the first result twice)
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
 template <int N>
 __device__ __forceinline__ void dc_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -124,7 +134,10 @@ struct Elem<_Float16> {
 // DMA: 0 = operands staged through a register ring (PF tiles) and ds_write_b128 into two padded LDS stages;
 //      D >= 2 = operands fetched by LDS-DMA into a ring of D unpadded, XOR-swizzled LDS stages (tile rows of 128 bytes),
 //      D - 1 tiles requested ahead, one raw barrier per tile, vmcnt counted by hand (PF unused).
-template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0>
+// SWP: the MFMA operands are swapped (filters as the row operand), so that a lane's accumulators are 16 CHANNELS of one
+//      pixel (4 runs of 4 consecutive channels) instead of 16 pixels of one channel: the epilogue then forms 16-byte output
+//      vectors in registers (float16: one v_permlane32_swap per register pair) — no LDS transposition, no barriers.
+template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0, bool SWP = false>
 __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();  // before the first kernel-argument load (DC_DEBUG_TIMING)
   DC_KARG_TOUCH(ka0, ka1, ka2, ka3, ka4);
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int NT = NW * 64;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int LDB = DMA ? BK * ES : BK * ES + 16;  // LDS row, bytes: padded (16-B aligned, bank-spread), or 128 swizzled (DMA)
-  static_assert(!DMA || BK * ES == 128, "the LDS-DMA image has 128-byte rows (8 chunks of 16 bytes, XOR-swizzled)");
+  static_assert(!DMA || BK * ES == 128 || BK * ES == 256, "the LDS-DMA image has 128- or 256-byte rows (8 / 16 chunks of 16 bytes, XOR-swizzled)");
   static_assert(DMA == 0 || (DMA >= 2 && DMA <= 4), "ring of 2..4 LDS stages");
   constexpr int NSTG = DMA ? DMA : 2;
   constexpr int TM = BM / WR, TN = BN / WC;
@@ -156,21 +169,24 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   constexpr int RPW = 16 / WK;           // accumulator registers each split-K wave finalises
   constexpr int WPS = BN + 4;                       // wide-epilogue staging row pitch (floats)
   // DMA: the buffer is sized for the ring, the split-K exchange and the wide epilogue's staging, whichever is largest
-  constexpr int EPIB = ES == 2 ? BM * WPS * 4 : 0;
+  constexpr int EPIB = ES == 2 && !SWP ? BM * WPS * 4 : 0;
   constexpr int SPKB = (WK - 1) * BM * BN * 4;
   constexpr int MAINB = DMA ? (NSTG * TILEB > EPIB ? (NSTG * TILEB > SPKB ? NSTG * TILEB : SPKB) : (EPIB > SPKB ? EPIB : SPKB)) : 2 * TILEB;
   static_assert(SPKB <= MAINB, "split-K partials must fit in the tile buffers");
-  constexpr bool EARLY_RESID = FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
+  constexpr bool EARLY_RESID = !SWP && FM * FN * RPW <= 16;  // shortcut tile prefetched before the K loop
   // Wide epilogue (float16): the C fragment gives a lane ONE channel of 16 different pixels, i.e. 2-byte accesses — 128 vector
   // memory instructions per lane for a 64x64 wave tile with a shortcut, and the CU's address unit, not HBM, bounds the
   // bandwidth-bound layers (K <= 512).  Instead the finished tile (fp32, after the affine) is transposed through the tile
   // buffers in LDS and every thread adds the shortcut to, and stores, 8 consecutive channels of one pixel: 16-byte accesses,
   // 8x fewer instructions; the shortcut vectors are requested before the transposition so that they are in flight meanwhile.
   constexpr int WVEC = BM * (BN / 8) / NT;           // 16-byte output vectors per thread
-  constexpr bool WIDE_OK = ES == 2 && BM * WPS * 4 <= MAINB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
+  constexpr bool WIDE_OK = !SWP && ES == 2 && BM * WPS * 4 <= MAINB && (BM * (BN / 8)) % NT == 0 && WVEC <= 16;
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[MAINB + 4 * BM];
-  int* rowinfo = reinterpret_cast<int*>(smem + MAINB);  // per tile row: byte offset of its output pixel, or -1
+  static_assert(!SWP || (DMA && (16 / WK) % 4 == 0), "SWP: LDS-DMA kernels, every split-K wave finalises whole 4-channel runs");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[MAINB + 4 * BM + (SWP ? 8 * BN : 0)];
+  int* rowinfo = reinterpret_cast<int*>(smem + MAINB);
+  float* epi_sc = reinterpret_cast<float*>(smem + MAINB + 4 * BM);  // SWP: scale[BN], shift[BN] of the tile's channels
+  // per tile row: byte offset of its output pixel, or -1
   const T* px = reinterpret_cast<const T*>(p.x);
 
   const int t = threadIdx.x;
@@ -248,11 +264,13 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   // (1) filter rows need no pixel decode: their first PF tiles go out immediately
   const int lrow = t / C4;
   // byte column of this thread's 16-byte vector.  DMA: lane l of a wave lands at LDS byte 16*l of its 1 KiB piece (8 rows of
-  // 128 bytes: row l/8, position l%8), and position p of row r holds source chunk p ^ ((r >> 1) & 7) — the swizzle that makes
-  // the ds_read_b128 fragment fetches bank-conflict-free without padding (rows of one piece set differ by multiples of 32).
-  const int lcb = DMA ? ((t % C4) ^ ((lrow >> 1) & 7)) * 16 : (t % C4) * 16;
+  // 128 bytes: row l/8, position l%8 — or 4 rows of 256 bytes), and position p of row r holds source chunk p ^ swz(r),
+  // swz(r) = (r >> 1) & 7 for 128-byte rows, r & 15 for 256-byte rows: the 16 lanes a ds_read_b128 serves together (rows
+  // {0-3,12-15,20-27} / {4-11,16-19,28-31} of a fragment, same chunk) then hit 16 different 16-byte bank groups, without padding.
+  constexpr bool ROW256 = BK * ES == 256;
+  const int lcb = DMA ? ((t % C4) ^ (ROW256 ? (lrow & 15) : ((lrow >> 1) & 7))) * 16 : (t % C4) * 16;
   const int lce = lcb / ES;       // same, in elements
-  static_assert(!DMA || (C4 == 8 && RPP % 32 == 0), "DMA loader: 8 lanes per row, piece sets 32 rows apart");
+  static_assert(!DMA || (C4 == (ROW256 ? 16 : 8) && RPP % (ROW256 ? 16 : 32) == 0), "DMA loader: the swizzle of a row must not depend on the piece set");
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned ldsw = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;  // this wave's piece of every 8*NW-row set
   unsigned bvoff[NBV];
@@ -288,12 +306,26 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
 
   // (2) epilogue constants (folded BatchNorm/Scale/bias) also travel now
   float sc[FN], sh[FN];
+  float epi_c = 0.f;  // SWP: thread t < BN holds scale[n0 + t], BN <= t < 2*BN holds shift[n0 + t - BN]; to LDS before the first barrier
+  if constexpr (SWP) {
+    static_assert(2 * BN <= NT, "one epilogue constant per thread");
+    const bool is_sh = t >= BN;
+    const int co = n0 + (is_sh ? t - BN : t);
+    epi_c = is_sh ? 0.f : 1.f;
+    const i32x4 scr = dc_rsrc_words(p.scale), shr = dc_rsrc_words(p.shift);  // uniform descriptors (SGPRs)
+    if (!is_sh) {
+      if (p.scale && co < p.Cout) epi_c = dc_load_f32_untracked(scr, (unsigned)co * 4u);
+    } else if (t < 2 * BN) {
+      if (p.shift && co < p.Cout) epi_c = dc_load_f32_untracked(shr, (unsigned)co * 4u);
+    }
+  } else {
 #pragma unroll
-  for (int b = 0; b < FN; ++b) {
-    const int co = n0 + wc * TN + b * 32 + (lane & 31);
-    const bool cok = co < p.Cout;
-    sc[b] = (cok && p.scale) ? p.scale[co] : 1.f;
-    sh[b] = (cok && p.shift) ? p.shift[co] : 0.f;
+    for (int b = 0; b < FN; ++b) {
+      const int co = n0 + wc * TN + b * 32 + (lane & 31);
+      const bool cok = co < p.Cout;
+      sc[b] = (cok && p.scale) ? p.scale[co] : 1.f;
+      sh[b] = (cok && p.shift) ? p.shift[co] : 0.f;
+    }
   }
 
   stamp(1);
@@ -309,7 +341,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     const int m = m0 + lrow + RPP * i;
     avoff[i] = kOOB;
     amask[i] = 0;
-    if (m < c_M) {
+    if (!MC && p.dense_x) {  // 1x1 over a dense tensor: pixel m starts at element m * sx, its one tap is always inside
+      if (m < c_M) avoff[i] = (unsigned)(m * p.sx) * ES + lcb, amask[i] = 1u;
+    } else if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
@@ -400,7 +434,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   if (t < BM) {
     const int m = m0 + t;
     int yo = -1;
-    if (m < c_M) {
+    if (!MC && p.dense_y) {
+      if (m < c_M) yo = m * p.y_pix_stride * ES;
+    } else if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
   f32x4 av[2][FM], bv[2][FN];
   // DMA image: 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7); the wave's q-th operand chunk pair is chunk
   // 2*(q*WK + wk) + (lane >> 5), and since q*WK*32 only touches address bits 5..6 it is applied as an XOR on the offset
-  const int frag_k = DMA ? (((2 * wk + (lane >> 5)) ^ ((lane >> 1) & 7)) * 16) : ((lane >> 5) * 16 + wk * 32);
+  const int frag_k = DMA ? (((2 * wk + (lane >> 5)) ^ (ROW256 ? (lane & 15) : ((lane >> 1) & 7))) * 16) : ((lane >> 5) * 16 + wk * 32);
   const int frag_a = (wr * TM + (lane & 31)) * LDB + frag_k;
   const int frag_b = BM * LDB + (wc * TN + (lane & 31)) * LDB + frag_k;
   auto frag_load = [&](int buf, int q, int set) {
@@ -468,7 +504,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     if (pt >= 3) dc_wait_vm<2 * NA>();
     else if (pt == 2) dc_wait_vm<NA>();
     else dc_wait_vm<0>();
-    dc_lds_barrier();  // every wave's pieces of tile 0 are in LDS; the rows' output offsets are visible
+    if constexpr (SWP) {  // the constants were requested before every DMA piece: the wait above covers them
+      if (t < 2 * BN) epi_sc[t] = epi_c;
+    }
+    dc_lds_barrier();  // every wave's pieces of tile 0 are in LDS; the rows' output offsets (and constants) are visible
   } else {
     lstore(0, 0);
     if (PF < T_) {
@@ -497,6 +536,11 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
         }
   }
   stamp(4);
+  // shortcut tile through LDS-DMA (swapped-operand epilogue, float16, one wave per output fragment set, a stage holds the tile)
+  constexpr bool RD_OK = SWP && ES == 2 && WK == 1 && (BN * ES == 128 || BN * ES == 256) && BM * BN * ES <= TILEB && (BM * BN * ES / 1024) % NW == 0;
+  constexpr int RD_PCS = RD_OK ? BM * BN * ES / 1024 / NW : 1;
+  bool rd_on = false;
+  unsigned rd_off = 0;
   if constexpr (DMA) {
     // ---- K loop, LDS-DMA form.  Tile `it` is computed from stage it % DMA while the pieces of tile it+DMA-1 are requested
     // into the stage tile it-1 was read from (free since the barrier taken inside tile it-1).  Before the last MFMA step of a
@@ -510,56 +554,73 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     // for the last DMA-1 tiles, one for the last tile): with an unrolled ring and an early exit in the middle the
     // register allocator parked the 64 accumulators in different register classes on the two sides of the loop header
     // and copied all of them (v_accvgpr_read/write) once per round.
+    rd_on = RD_OK && p.resid && p.vec_epi && !MC;
     unsigned sb = 0;                    // byte offset of the stage tile `it` is read from
     unsigned sbp = (DMA - 1) * TILEB;   // ... of the stage tile it+DMA-1 goes to (tile it-1 was read from it)
-    auto frag_load_d = [&](unsigned so, int q, int set) {
-      const unsigned char* As = smem + so + (frag_a ^ (q * WK * 32));
-      const unsigned char* Bs = smem + so + (frag_b ^ (q * WK * 32));
-#pragma unroll
-      for (int a = 0; a < FM; ++a) av[set][a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDB);
-#pragma unroll
-      for (int b = 0; b < FN; ++b) bv[set][b] = *reinterpret_cast<const f32x4*>(Bs + b * 32 * LDB);
-    };
     auto tile = [&](auto more1_tag, auto moreD_tag, int it) {
       constexpr bool more1 = decltype(more1_tag)::value, moreD = decltype(moreD_tag)::value;
       const unsigned sbn = sb + TILEB == DMA * TILEB ? 0u : sb + TILEB;  // stage of tile it+1
       if (moreD) dma_next();
+      // One MFMA step = FM*FN matrix instructions; its other work — the FM+FN fragment reads of the next chunk, the wait +
+      // barrier + first reads of the next tile (step GBAR), this step's share of the DMA requests — is cut into FM*FN slices
+      // and slice m is issued right AFTER matrix instruction m (pinned by sched_barrier): a wave issues in order and a
+      // v_mfma_f32_32x32x16_f16 occupies the pipe for 32 cycles, so ~5 other instructions fit into each MFMA's shadow; issued
+      // as one block before the step's MFMAs they left the matrix pipe idle for a third of a one-wave-per-SIMD K loop.
+      constexpr int NM = FM * FN, NFR = FM + FN;
+      auto frag_one = [&](unsigned so, int q, int set, int i) {  // i-th of the FM+FN 16-byte fragment reads of chunk q
+        if (i < FM) av[set][i < FM ? i : 0] = *reinterpret_cast<const f32x4*>(smem + so + (frag_a ^ (q * WK * 32)) + (i < FM ? i : 0) * 32 * LDB);
+        else bv[set][i >= FM ? i - FM : 0] = *reinterpret_cast<const f32x4*>(smem + so + (frag_b ^ (q * WK * 32)) + (i >= FM ? i - FM : 0) * 32 * LDB);
+      };
 #pragma unroll
       for (int g = 0; g < NST; ++g) {
         const int q = g / SPC, st = g % SPC, cur = q & 1;
-        if (st == 0 && q + 1 < NCH) frag_load_d(sb, q + 1, cur ^ 1);
-        if (g == GBAR && more1) {
-          // tiles that may stay in flight: those after it+1 that exist, but never a prologue tile (the prologue requested
-          // all filter pieces before all activation pieces, so "the youngest n tiles" only means something for loop tiles)
-          if constexpr (moreD) {
-            if (DMA >= 4 && it == 0) dc_wait_vm<PPW>();
-            else dc_wait_vm<(DMA - 2) * PPW>();
+        const bool rd_next = st == 0 && q + 1 < NCH;   // fragment reads of chunk q+1
+        const bool sync = g == GBAR && more1;          // wait + barrier + first reads of tile it+1
+        const int pc_lo = (g < GBAR && moreD) ? g * PPW / GBAR : 0, pc_hi = (g < GBAR && moreD) ? (g + 1) * PPW / GBAR : 0;
+        const int n_sync = sync ? 1 + NFR : 0, n_rd = rd_next ? NFR : 0, n_items = n_sync + n_rd + (pc_hi - pc_lo);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int a = m / FN, b = m % FN;
+          if constexpr (SPC == 4) {
+            if constexpr (SWP) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][b][st], av[cur][a][st], acc[a][b], 0, 0, 0);
+            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
           } else {
-            int left = T_ - 2 - it;
-            if (left > it + 1) left = it + 1;
-            if (DMA >= 4 && left >= 2) dc_wait_vm<2 * PPW>();
-            else if (DMA >= 3 && left == 1) dc_wait_vm<PPW>();
-            else dc_wait_vm<0>();
-          }
-          dc_lds_barrier();
-          frag_load_d(sbn, 0, 0);
-        }
-        if (g < GBAR && moreD) {
-#pragma unroll
-          for (int pc = g * PPW / GBAR; pc < (g + 1) * PPW / GBAR; ++pc) dma_piece(sbp, pc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b) {
-            if constexpr (SPC == 4)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][a][st], bv[cur][b][st], acc[a][b], 0, 0, 0);
+            if constexpr (SWP)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv[cur][b]),
+                                                                 __builtin_bit_cast(f16x8, av[cur][a]), acc[a][b], 0, 0, 0);
             else
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[cur][a]),
                                                                  __builtin_bit_cast(f16x8, bv[cur][b]), acc[a][b], 0, 0, 0);
           }
-        __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = m * n_items / NM; i < (m + 1) * n_items / NM; ++i) {
+            if (i < n_sync) {
+              if (i == 0) {
+                // tiles that may stay in flight: those after it+1 that exist, but never a prologue tile (the prologue requested
+                // all filter pieces before all activation pieces, so "the youngest n tiles" only means something for loop tiles)
+                if constexpr (moreD) {
+                  if (DMA >= 4 && it == 0) dc_wait_vm<PPW>();
+                  else dc_wait_vm<(DMA - 2) * PPW>();
+                } else {
+                  int left = T_ - 2 - it;
+                  if (left > it + 1) left = it + 1;
+                  if (DMA >= 4 && left >= 2) dc_wait_vm<2 * PPW>();
+                  else if (DMA >= 3 && left == 1) dc_wait_vm<PPW>();
+                  else dc_wait_vm<0>();
+                }
+                dc_lds_barrier();
+              } else {
+                frag_one(sbn, 0, 0, i - 1);
+              }
+            } else if (i < n_sync + n_rd) {
+              frag_one(sb, q + 1, cur ^ 1, i - n_sync);
+            } else {
+              dma_piece(sbp, pc_lo + (i - n_sync - n_rd));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       sbp = sb;
       sb = sbn;
@@ -567,6 +628,26 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
     int it = 0;
     for (; it < T_ - (DMA - 1); ++it) tile(std::true_type{}, std::true_type{}, it);
     for (; it < T_ - 1; ++it) tile(std::true_type{}, std::false_type{}, it);
+    if constexpr (RD_OK) {
+      // Shortcut tile by LDS-DMA: while the last K tile computes, the BM x BN shortcut values travel into the stage the
+      // previous tile was read from (free since that tile's barrier) — whole 128- / 256-byte pixel rows per request (the
+      // swapped-operand epilogue would otherwise fetch them as 32-byte fragments of 32 different lines per instruction),
+      // no VGPRs, and a tile's time earlier than the epilogue could ask for them.  Same swizzle as the operand tiles.
+      if (rd_on) {
+        rd_off = sbp;
+        constexpr int RB = BN * ES, LPR = RB / 16, PPP = 1024 / RB;  // row bytes, lanes per row, pixels per 1 KiB piece
+        const i32x4 rrs = dc_rsrc_words(reinterpret_cast<const T*>(p.resid) + c_yoff);
+#pragma unroll
+        for (int j = 0; j < RD_PCS; ++j) {
+          const int px_ = (j * NW + wave) * PPP + lane / LPR;        // tile row
+          const int c = (lane % LPR) ^ (RB == 256 ? (px_ & 15) : ((px_ >> 1) & 7));
+          const int yo = rowinfo[px_];
+          const int co = n0 + c * VEC;
+          const unsigned vo = (yo >= 0 && co < p.Cout) ? (unsigned)yo + (unsigned)co * ES : kOOB;
+          dc_dma16(rrs, ldsw + sbp + j * NW * 1024, vo, 0);
+        }
+      }
+    }
     tile(std::false_type{}, std::false_type{}, it);
   } else
   for (int it0 = 0; it0 < T_; it0 += PF) {
@@ -656,6 +737,126 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
       }
     }
     stamp(6);
+    if constexpr (SWP) {
+      // Swapped-operand accumulators: register r of fragment (a, b) is pixel wr*TM + a*32 + (lane & 31), channel
+      // wc*TN + b*32 + 8*(r >> 2) + 4*(lane >> 5) + (r & 3): four runs of 4 consecutive channels.  float32: a run IS a 16-byte
+      // vector.  float16: after the affine, v_permlane32_swap between the registers of runs g and g+1 leaves lanes 0..31 with
+      // channels 8g..8g+7 and lanes 32..63 with 8g+8..8g+15 of their pixel: 16-byte vectors again, formed in registers.
+      constexpr int NG = RPW / 4;  // runs per fragment this wave finalises
+      const int h = lane >> 5;
+      const float* scl = epi_sc;
+      const float* shl = epi_sc + BN;
+      int yo[FM];
+#pragma unroll
+      for (int a = 0; a < FM; ++a) yo[a] = rowinfo[wr * TM + a * 32 + (lane & 31)];
+      if (p.vec_epi && (ES == 4 || NG >= 2)) {
+        constexpr int NV = ES == 4 ? NG : (NG >= 2 ? NG / 2 : 1);  // 16-byte vectors per fragment
+        f32x4 rv[FM][FN][NV];
+        unsigned off[FM][FN][NV];
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+              const int g0 = MYK * NG + (ES == 4 ? j : 2 * j);
+              const int co = n0 + wc * TN + b * 32 + (ES == 4 ? 8 * g0 + 4 * h : 8 * (g0 + h));
+              off[a][b][j] = (yo[a] >= 0 && co < p.Cout) ? (unsigned)yo[a] + (unsigned)co * ES : kOOB;
+              if (p.resid && !rd_on) rv[a][b][j] = dc_bload4(rr, off[a][b][j], 0);
+            }
+        if constexpr (RD_OK) {
+          if (rd_on) {
+            dc_wait_vm<0>();
+            dc_lds_barrier();  // every wave's pieces of the shortcut tile have landed
+            constexpr int RB = BN * ES;
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+              const int px_ = wr * TM + a * 32 + (lane & 31);
+              const int sw = RB == 256 ? (px_ & 15) : ((px_ >> 1) & 7);
+#pragma unroll
+              for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                  const int c = (wc * TN + b * 32 + 8 * (2 * j + h)) / 8;  // 16-byte chunk of the row (WK == 1: g0 = 2j)
+                  rv[a][b][j] = *reinterpret_cast<const f32x4*>(smem + rd_off + px_ * RB + ((c ^ sw) * 16));
+                }
+            }
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const int g0 = MYK * NG + (ES == 4 ? j : 2 * j);
+            if constexpr (ES == 4) {
+              const int cb = wc * TN + b * 32 + 8 * g0 + 4 * h;
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + cb), h4 = *reinterpret_cast<const f32x4*>(shl + cb);
+#pragma unroll
+              for (int a = 0; a < FM; ++a) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float x = acc[a][b][4 * g0 + e] * s4[e] + h4[e] + (p.resid ? rv[a][b][j][e] : 0.f);
+                  if (p.relu) x = fmaxf(x, 0.f);
+                  o[e] = x;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
+              }
+            } else {
+              const int cb0 = wc * TN + b * 32 + 8 * g0 + 4 * h, cb1 = cb0 + 8;
+              const f32x4 s0 = *reinterpret_cast<const f32x4*>(scl + cb0), h0 = *reinterpret_cast<const f32x4*>(shl + cb0);
+              const f32x4 s1 = *reinterpret_cast<const f32x4*>(scl + cb1), h1 = *reinterpret_cast<const f32x4*>(shl + cb1);
+#pragma unroll
+              for (int a = 0; a < FM; ++a) {
+                float lo[4], hi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  lo[e] = acc[a][b][4 * g0 + e] * s0[e] + h0[e];
+                  hi[e] = acc[a][b][4 * g0 + 4 + e] * s1[e] + h1[e];
+                  dc_permlane32_swap(lo[e], hi[e]);
+                }
+                const f16x8 rz = __builtin_bit_cast(f16x8, rv[a][b][j]);
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  float x = (e < 4 ? lo[e] : hi[e - 4]) + (p.resid ? (float)rz[e] : 0.f);
+                  if (p.relu) x = fmaxf(x, 0.f);
+                  o[e] = (_Float16)x;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
+              }
+            }
+          }
+      } else {
+        // element-wise form (odd channel counts, sigmoid heads, unaligned views, split-K 4 in float16)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+              const int g = MYK * NG + gg;
+              const int cb = wc * TN + b * 32 + 8 * g + 4 * h;
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + cb), h4 = *reinterpret_cast<const f32x4*>(shl + cb);
+              unsigned eo[4];
+              float rvv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int co = n0 + cb + e;
+                eo[e] = (yo[a] >= 0 && co < p.Cout) ? (unsigned)yo[a] + (unsigned)co * ES : kOOB;
+                rvv[e] = p.resid ? Elem<T>::load(rr, eo[e]) : 0.f;
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v = acc[a][b][4 * g + e] * s4[e] + h4[e] + rvv[e];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (n0 + cb + e < p.sigmoid_ch) v = 1.f / (1.f + expf(-v));
+                Elem<T>::store(v, yr, eo[e]);
+              }
+            }
+      }
+      return;
+    }
     if constexpr (WIDE_OK) {
       if (wide) {
         float* stg = reinterpret_cast<float*>(smem);
@@ -797,13 +998,28 @@ struct VariantEntry {
 #define DC_VARIANT_HD(BM, BN, WR, WC, WK, S)                                        \
   {                                                                                \
     {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S>, 64, 2, nullptr \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, true>, 64, 2, nullptr \
+  }
+#define DC_VARIANT_HD_T(BM, BN, WR, WC, WK, S)  /* LDS-transposed epilogue instead of the swapped-operand one (A/B) */ \
+  {                                                                                \
+    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S "_t", BM, BN, WR, WC, WK},         \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, false>, 64, 2, nullptr \
   }
 #define DC_VARIANT_HD_MC(BM, BN, WR, WC, WK, S)                                     \
   {                                                                                \
     {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S>, 64, 2,     \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, true, S>              \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, true>, 64, 2, \
+        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, true, S, true>        \
+  }
+#define DC_VARIANT_HD2(BM, BN, WR, WC, WK, S)  /* 256-byte rows: BK = 128 halves */  \
+  {                                                                                \
+    {"d" #BM "x" #BN "x128_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},             \
+        conv_gemm_kernel<_Float16, BM, BN, 128, WR, WC, WK, 1, false, S, true>, 128, 2, nullptr \
+  }
+#define DC_VARIANT_FD(BM, BN, BK, WR, WC, WK, S)  /* float32: BK = 32 (128-byte rows) or 64 (256-byte rows) */ \
+  {                                                                                \
+    {"e" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},          \
+        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, 1, false, S, true>, BK, 4, nullptr \
   }
 const VariantEntry kVariants[] = {
     DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
@@ -843,15 +1059,35 @@ const VariantEntry kVariants[] = {
     DC_VARIANT_H(256, 128, 64, 4, 2, 1, 2),   // 30
     DC_VARIANT_H(128, 256, 64, 2, 4, 1, 2),   // 31
     // float16 through LDS-DMA (round 3): no register ring, no ds_write, unpadded swizzled stages
-    DC_VARIANT_HD(128, 128, 2, 2, 1, 2),      // 32: 66 KB -> two workgroups per CU
+    DC_VARIANT_HD_MC(128, 128, 2, 2, 1, 2),   // 32: 66 KB -> two workgroups per CU
     DC_VARIANT_HD(128, 128, 2, 2, 1, 3),      // 33: 96 KB, one workgroup per CU, two tiles ahead
-    DC_VARIANT_HD(128, 128, 2, 2, 2, 3),      // 34: 8 waves
+    DC_VARIANT_HD_MC(128, 128, 2, 2, 2, 3),   // 34: 8 waves
     DC_VARIANT_HD(128, 128, 2, 2, 2, 4),      // 35: 8 waves, 128 KB, three tiles ahead
     DC_VARIANT_HD(128, 64, 2, 2, 1, 3),       // 36: 72 KB -> two per CU
     DC_VARIANT_HD(64, 128, 2, 2, 1, 3),       // 37
     DC_VARIANT_HD(64, 64, 2, 2, 1, 4),        // 38: 64 KB
-    DC_VARIANT_HD(256, 128, 4, 2, 1, 3),      // 39: 144 KB
-    DC_VARIANT_HD(128, 256, 2, 4, 1, 3),      // 40
+    DC_VARIANT_HD_MC(256, 128, 4, 2, 1, 3),   // 39: 144 KB
+    DC_VARIANT_HD_MC(128, 256, 2, 4, 1, 3),   // 40
+    DC_VARIANT_HD(128, 64, 2, 2, 1, 2),       // 41: 48 KB -> three workgroups per CU (the bandwidth-class layers)
+    DC_VARIANT_HD(64, 128, 2, 2, 1, 2),       // 42
+    DC_VARIANT_HD(64, 64, 2, 2, 1, 2),        // 43: 32 KB
+    DC_VARIANT_HD2(64, 64, 2, 2, 2, 2),       // 44: 256-byte rows, 8 waves
+    DC_VARIANT_HD2(128, 128, 2, 2, 2, 2),     // 45
+    DC_VARIANT_HD2(32, 64, 1, 2, 4, 3),       // 46: split-K 4
+    // float32 through LDS-DMA
+    DC_VARIANT_FD(32, 64, 64, 1, 2, 4, 3),    // 47: the res4/res5 batch-1 tile (8 waves, split-K 4)
+    DC_VARIANT_FD(32, 64, 64, 1, 2, 4, 4),    // 48
+    DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 3),   // 49
+    DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 4),   // 50
+    DC_VARIANT_FD(64, 64, 32, 2, 2, 2, 4),    // 51
+    DC_VARIANT_FD(64, 64, 64, 2, 2, 2, 3),    // 52
+    DC_VARIANT_FD(128, 128, 32, 2, 2, 2, 3),  // 53
+    DC_VARIANT_FD(128, 64, 32, 2, 2, 2, 3),   // 54
+    DC_VARIANT_FD(32, 32, 64, 1, 1, 4, 4),    // 55
+    DC_VARIANT_FD(64, 64, 32, 2, 2, 1, 4),    // 56: 4 waves
+    DC_VARIANT_HD_T(128, 128, 2, 2, 1, 2),    // 57: A/B of the epilogue forms
+    DC_VARIANT_HD_T(128, 128, 2, 2, 2, 3),    // 58
+    DC_VARIANT_HD_T(64, 128, 2, 2, 1, 2),     // 59
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -882,6 +1118,15 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   static const int wide_epi = getenv("DC_WIDE_EPI") ? atoi(getenv("DC_WIDE_EPI")) : 1;
   p.wide_epi = wide_epi && p.esize == 2 && p.ncls <= 1 && p.Cout % 8 == 0 && p.y_pix_stride % 8 == 0 && p.y_row_stride % 8 == 0 &&
                p.y_img_stride % 8 == 0 && p.sigmoid_ch == 0 && ((uintptr_t)p.y & 15) == 0 && (!p.resid || ((uintptr_t)p.resid & 15) == 0);
+  {
+    const long es = p.esize;
+    p.vec_epi = p.ncls <= 1 && (p.Cout * es) % 16 == 0 && (p.y_pix_stride * es) % 16 == 0 && (p.y_row_stride * es) % 16 == 0 &&
+                (p.y_img_stride * es) % 16 == 0 && p.sigmoid_ch == 0 && ((uintptr_t)p.y & 15) == 0 && (!p.resid || ((uintptr_t)p.resid & 15) == 0);
+    static const int dense = getenv("DC_DENSE") ? atoi(getenv("DC_DENSE")) : 1;
+    p.dense_x = dense && p.ncls <= 1 && p.nty == 1 && p.ntx == 1 && p.dy0 == 0 && p.x0 == 0 && p.sy == 1 && p.x_rows == p.OH &&
+                p.x_row_stride == p.OW * p.sx && p.x_img_stride == (long)p.OH * p.x_row_stride && p.x_rowlen >= (p.OW - 1) * p.sx + p.klen;
+    p.dense_y = dense && p.ncls <= 1 && p.y_row_stride == p.OW * p.y_pix_stride && p.y_img_stride == (long)p.OH * p.y_row_stride;
+  }
   // n / d magic: sh = 31 + ceil(log2 d), mul = floor(2^sh / d) + 1, n/d = (n*mul) >> sh for 0 <= n < 2^31
   auto magic_of = [](unsigned d, unsigned (&mg)[2]) {
     if (d <= 1) {

@@ -107,6 +107,9 @@ def _load():
         "dc_net_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
         "dc_net_reserve": (ci, [vp, ci, ci, ci]),
         "dc_net_device": (ci, [vp]),
+        "dc_conv_variant_count": (ci, []),
+        "dc_conv_variant_name": (cp, [ci]),
+        "dc_conv_variant_esize": (ci, [ci]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -137,6 +140,11 @@ def set_device(device_id):
 
 def device_count():
     return _lib.dc_device_count()
+
+
+def conv_variants():
+    """[(name, element size)] of the gather-GEMM tile variants, in DC_CONV_VARIANT index order (diagnostics)."""
+    return [((_lib.dc_conv_variant_name(i) or b"").decode(), _lib.dc_conv_variant_esize(i)) for i in range(_lib.dc_conv_variant_count())]
 
 
 def canvas_size(height, width, scale):

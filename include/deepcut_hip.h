@@ -257,6 +257,12 @@ const char* dc_net_plan_text(dc_net* net);
 /* time each op of the current plan with hipEvents on the net's stream (iters runs each);
  * returns a text table (op, kernel, us, GFLOP, TFLOP/s); pointer valid until next call    */
 const char* dc_net_profile_text(dc_net* net, int iters);
+/* the gather-GEMM's tile-variant table (csrc/kernels.hip): number of entries, name and element size (4 float / 2 half) of
+ * entry i — what the environment switch DC_CONV_VARIANT=<i> forces and the names dc_net_plan_text / DC_TUNE_CACHE use.
+ * No reference counterpart: the reference has one SGEMM (math_functions.cu:13-27); diagnostics only.                  */
+int dc_conv_variant_count(void);
+const char* dc_conv_variant_name(int i);
+int dc_conv_variant_esize(int i);
 
 #ifdef __cplusplus
 }

@@ -276,7 +276,8 @@ def test_fp16_lowering_on_the_host():
     text = net.plan_text()
     lines = [l for l in text.splitlines() if not l.startswith("#")]
     assert "dtype=f16" in text.splitlines()[0] and len(lines) == 158
-    assert all("conv_gemm<h" in l for l in lines if "conv_gemm" in l)
+    half_tiles = set(n for n, es in caffe.conv_variants() if es == 2)  # "h..." register-ring tiles and "d..." LDS-DMA tiles
+    assert all(l.split("conv_gemm<")[1].split(">")[0] in half_tiles for l in lines if "conv_gemm" in l)
     assert "K=448 taps=7" in lines[0]  # stem: 7 row taps of 8 pixels x 8 channels (3 padded to one 16-byte vector)
     assert abs(net.flops() / 1e9 - 46.24) < 0.01
     net.set_option(3, 0)

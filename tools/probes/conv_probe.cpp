@@ -49,8 +49,11 @@ static const Shape kShapes[] = {
     {"res2_c", 136, 184, 64, 256, 1, 1, 1, 1},     // 3x
     {"res2_a", 136, 184, 256, 64, 1, 1, 0, 1},     // 2x
     {"res5_b1", 34, 46, 1024, 2048, 1, 1, 0, 0},   // projection shortcut
+    {"res4_c_nr", 34, 46, 256, 1024, 1, 1, 0, 1},  // res4_c without the shortcut (ablation: what the shortcut read costs)
+    {"res3_c_nr", 68, 92, 128, 512, 1, 1, 0, 1},
     {"tiny_3x3", 9, 11, 64, 64, 3, 1, 1, 1},       // ragged everything: M = 99*NB, exercises the zero padding
     {"tiny_d2", 7, 13, 128, 96, 3, 2, 0, 0},       // dilation 2, Cout not a multiple of 64
+    {"tiny_odd", 9, 11, 128, 70, 1, 1, 1, 1},      // Cout not a multiple of 8: element-wise epilogue
 };
 
 static unsigned short f2h(float f) {
@@ -67,7 +70,7 @@ static float h2f(unsigned short u) {
 
 int main(int argc, char** argv) {
   std::string dtype = "h", shapes = "all", variants = "all";
-  int batch = 8, reps = 30, nsets = 4;
+  int batch = 8, reps = 30, nsets = 4, stamps = 0;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -77,6 +80,7 @@ int main(int argc, char** argv) {
     else if (a == "--variants") variants = next();
     else if (a == "--reps") reps = std::atoi(next().c_str());
     else if (a == "--sets") nsets = std::atoi(next().c_str());
+    else if (a == "--stamps") stamps = 1;  // device-side phase stamps (ConvGemmParams::dbg) of every variant run
   }
   const int es = dtype == "h" ? 2 : 4;
   auto want = [](const std::string& list, const std::string& name, bool prefix_ok) {
@@ -243,6 +247,40 @@ int main(int argc, char** argv) {
       const double tol = es == 2 ? 1.5e-3 : 2e-5;
       std::printf("  %-26s grid %5ld  %8.2f us  %7.1f TF/s   err_vs_f64 %.2e  vs_first: %zu differ, max %.3g  %s\n", vn.c_str(), conv_grid(g, v), us,
                   flops / us * 1e-6, maxerr, ndiff, maxdiff, maxerr <= tol ? "ok" : "**WRONG**");
+      if (stamps) {
+        // per wave: shader-cycle stamps at 8 phase boundaries (slots 0..7), chip-wide 100 MHz clock at entry / start / end (8, 10, 9)
+        const ConvVariant& cv = conv_variant(v);
+        const int nwv = cv.WR * cv.WC * cv.WK;
+        const long nw = (conv_grid(g, v) * 2 + 64) * nwv;
+        long long* d = nullptr;
+        CK(hipMalloc((void**)&d, nw * 12 * sizeof(long long)));
+        CK(hipMemset(d, 0, nw * 12 * sizeof(long long)));
+        g.dbg = d;
+        run(1 % nsets);
+        run(2 % nsets);
+        CK(hipStreamSynchronize(st));
+        g.dbg = nullptr;
+        std::vector<long long> h(nw * 12);
+        CK(hipMemcpy(h.data(), d, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        CK(hipFree(d));
+        double dsum[8] = {0};
+        long cnt = 0;
+        long long t0min = 0, t0max = 0, t9max = 0;
+        for (long i = 0; i < nw; ++i) {
+          const long long* w = &h[i * 12];
+          if (w[7] == 0 || w[0] == 0) continue;
+          for (int k = 1; k < 8; ++k) dsum[k] += (double)(w[k] - w[k - 1]);
+          if (!cnt || w[8] < t0min) t0min = w[8];
+          if (!cnt || w[8] > t0max) t0max = w[8];
+          if (!cnt || w[9] > t9max) t9max = w[9];
+          ++cnt;
+        }
+        const double c = (double)std::max(cnt, 1L);
+        std::printf("      stamps (mean cycles/wave): B-issue %.0f | decode+A-issue %.0f | rowinfo %.0f | wait tile0 %.0f | K loop %.0f | split-K %.0f | epilogue %.0f"
+                    " || total %.0f | ramp %.2f us | span %.2f us\n",
+                    dsum[1] / c, dsum[2] / c, dsum[3] / c, dsum[4] / c, dsum[5] / c, dsum[6] / c, dsum[7] / c,
+                    (dsum[1] + dsum[2] + dsum[3] + dsum[4] + dsum[5] + dsum[6] + dsum[7]) / c, (t0max - t0min) / 100.0, (t9max - t0min) / 100.0);
+      }
       std::fflush(stdout);
     }
     for (int s = 0; s < nsets; ++s) {
