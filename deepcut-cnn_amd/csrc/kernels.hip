@@ -67,12 +67,17 @@ __device__ __forceinline__ void dc_dma16(i32x4 rs, unsigned lds, unsigned voff, 
 // a 4-byte buffer load the compiler does not track (no s_waitcnt of its own): the caller's counted vmcnt covers it
 __device__ __forceinline__ float dc_load_f32_untracked(i32x4 rs, unsigned voff) {
   float v;
-  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+  // s_nop: the hazard recogniser does not look inside inline asm, and "VALU writes SGPR -> VMEM reads that SGPR" needs 5
+  // wait states (a descriptor restored from an SGPR spill by v_readlane right in front of this statement read stale
+  // registers in the round-3 walking-tile experiment: wild addresses).  tools/check_asm_hazards.py scans for the pattern.
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
   return v;
 }
-__device__ __forceinline__ void dc_permlane32_swap(float& lo, float& hi) {
-  // lanes 32..63 of `lo` <-> lanes 0..31 of `hi` (inline asm: this compiler's builtin returns the first result twice)
-  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+// lanes 32..63 of lo[e] <-> lanes 0..31 of hi[e], e = 0..3 (inline asm: this compiler's builtin returns the first result
+// twice; one s_nop for the four: the VALU instructions that produced the operands need two wait states before a permlane)
+__device__ __forceinline__ void dc_permlane32_swap4(float (&lo)[4], float (&hi)[4]) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 }
 template <int N>
 __device__ __forceinline__ void dc_wait_vm() {
@@ -138,7 +143,10 @@ struct Elem<_Float16> {
 //      pixel (4 runs of 4 consecutive channels) instead of 16 pixels of one channel: the epilogue then forms 16-byte output
 //      vectors in registers (float16: one v_permlane32_swap per register pair) — no LDS transposition, no barriers.
 template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0, bool SWP = false>
-__global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGemmParams p) {
+// (second launch bound = waves per SIMD the register budget must allow: the 4-wave LDS-DMA tiles are meant to run two
+//  workgroups per CU, so their allocation has to stay within 256 registers — with it the compiler also keeps the
+//  accumulators in VGPRs instead of AGPRs: no v_accvgpr_read pass in front of the epilogue, 169 instead of 200 registers)
+__global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1) void conv_gemm_kernel(const ConvGemmParams p) {
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();  // before the first kernel-argument load (DC_DEBUG_TIMING)
   DC_KARG_TOUCH(ka0, ka1, ka2, ka3, ka4);
   constexpr int ES = sizeof(T);          // bytes per element
@@ -762,8 +770,12 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
               const int g0 = MYK * NG + (ES == 4 ? j : 2 * j);
               const int co = n0 + wc * TN + b * 32 + (ES == 4 ? 8 * g0 + 4 * h : 8 * (g0 + h));
               off[a][b][j] = (yo[a] >= 0 && co < p.Cout) ? (unsigned)yo[a] + (unsigned)co * ES : kOOB;
+              rv[a][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};  // no shortcut: + 0 (one add instead of a select per element)
               if (p.resid && !rd_on) rv[a][b][j] = dc_bload4(rr, off[a][b][j], 0);
             }
+        // ReLU as max(x, lo) with a uniform lo = 0 or -inf: one instruction per element, no select.  (A NaN would come out
+        // of a ReLU-less layer as -inf — v_max returns the non-NaN operand —; activations here are finite.)
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         if constexpr (RD_OK) {
           if (rd_on) {
             dc_wait_vm<0>();
@@ -795,11 +807,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
               for (int a = 0; a < FM; ++a) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float x = acc[a][b][4 * g0 + e] * s4[e] + h4[e] + (p.resid ? rv[a][b][j][e] : 0.f);
-                  if (p.relu) x = fmaxf(x, 0.f);
-                  o[e] = x;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[a][b][4 * g0 + e] * s4[e] + h4[e] + rv[a][b][j][e], relu_lo);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
               }
             } else {
@@ -813,16 +821,12 @@ __global__ __launch_bounds__(WR* WC* WK * 64) void conv_gemm_kernel(const ConvGe
                 for (int e = 0; e < 4; ++e) {
                   lo[e] = acc[a][b][4 * g0 + e] * s0[e] + h0[e];
                   hi[e] = acc[a][b][4 * g0 + 4 + e] * s1[e] + h1[e];
-                  dc_permlane32_swap(lo[e], hi[e]);
                 }
+                dc_permlane32_swap4(lo, hi);
                 const f16x8 rz = __builtin_bit_cast(f16x8, rv[a][b][j]);
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  float x = (e < 4 ? lo[e] : hi[e - 4]) + (p.resid ? (float)rz[e] : 0.f);
-                  if (p.relu) x = fmaxf(x, 0.f);
-                  o[e] = (_Float16)x;
-                }
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf((e < 4 ? lo[e] : hi[e - 4]) + (float)rz[e], relu_lo);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
               }
             }

@@ -54,6 +54,8 @@ static const Shape kShapes[] = {
     {"tiny_3x3", 9, 11, 64, 64, 3, 1, 1, 1},       // ragged everything: M = 99*NB, exercises the zero padding
     {"tiny_d2", 7, 13, 128, 96, 3, 2, 0, 0},       // dilation 2, Cout not a multiple of 64
     {"tiny_odd", 9, 11, 128, 70, 1, 1, 1, 1},      // Cout not a multiple of 8: element-wise epilogue
+    {"tiny_w1", 9, 11, 64, 320, 1, 1, 1, 1},       // 3 n tiles of 128 (the last one half full), one K tile each
+    {"tiny_w3", 9, 11, 64, 328, 3, 1, 1, 1},       // ... 3x3, 9 K tiles, ragged Cout
 };
 
 static unsigned short f2h(float f) {
@@ -186,17 +188,24 @@ int main(int argc, char** argv) {
       if (conv_variant_esize(v) != es || C % conv_variant_bk(v) != 0) continue;
       const std::string vn = conv_variant(v).name;
       if (!want(variants, vn, true)) continue;
+      bool refused = false;
       auto run = [&](int s) {
         g.x = dx[s], g.resid = sh.resid ? dr[s] : nullptr, g.y = dy[s];
         const int rc = launch_conv_gemm(g, v, st);
-        if (rc != 0) {
+        if (rc == (int)hipErrorInvalidValue) refused = true;  // the variant does not take this geometry (the library falls back)
+        else if (rc != 0) {
           std::fprintf(stderr, "launch %s failed: %d\n", vn.c_str(), rc);
           std::exit(3);
         }
       };
+      if (getenv("PROBE_TRACE")) std::fprintf(stderr, "[probe] %s %s\n", sh.name, vn.c_str());
       CK(hipMemsetAsync(dy[0], 0xff, yn * es, st));
       run(0);
       CK(hipStreamSynchronize(st));
+      if (refused) {
+        std::printf("  %-26s (refuses this geometry)\n", vn.c_str());
+        continue;
+      }
       // correctness
       double maxerr = 0, maxdiff = 0;
       size_t ndiff = 0;
