@@ -263,11 +263,18 @@ def main():
     if world > 1 and rank == 0:  # one set of receive buffers per in-flight forward
         recvs = [[torch.empty_like(outs[0], device=comm_dev) for _ in range(world)] for _ in range(S)]
     sizes = [outs[0].numel()] * world
+    # N > 1: the gather runs on ONE communication stream, ordered after each forward by an event — RCCL's send/recv kernels
+    # are then in no executor stream's dependency chain (with the gather waited for on the compute stream, every one of the
+    # S streams would carry them and rank 0's 7 receives per step would hold up the next forward of that slot)
+    comm = torch.cuda.Stream(dev) if world > 1 else None
+    sent = [None] * S  # per in-flight slot: event on `comm` after which outs[k] / recvs[k] may be reused
 
     def step(i, nstreams):
         # asynchronous on stream i % nstreams; inputs and outputs stay in HBM
         k = i % nstreams
         st, out, x = streams[k], outs[k], xs[k]
+        if world > 1 and sent[k] is not None:
+            st.wait_event(sent[k])  # the previous payload of this slot has left
         if half:
             nets[k].forward_device(x.data_ptr(), B, H, W, None, None, None, st.cuda_stream)
             nets[k].emit_maps_device(out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(), half=True, stream=st.cuda_stream)
@@ -275,11 +282,19 @@ def main():
             nets[k].forward_device(x.data_ptr(), B, H, W, out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(),
                                    st.cuda_stream)
         if world > 1:
-            with torch.cuda.stream(st):
-                if args.backend != "nccl":  # smoke-test transport: through the host
-                    st.synchronize()
-                    out = out.cpu()
-                gather_maps_known(out, sizes, 0, None, out=recvs[k])
+            if args.backend == "nccl":
+                done = torch.cuda.Event()
+                done.record(st)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    _bufs, reqs = gather_maps_known(out, sizes, 0, None, out=recvs[k], async_op=True)
+                    for q in reqs:
+                        q.wait()  # orders `comm` after the transfer; the host does not block
+                    sent[k] = torch.cuda.Event()
+                    sent[k].record(comm)
+            else:  # smoke-test transport (gloo): through the host, synchronously
+                st.synchronize()
+                gather_maps_known(out.cpu(), sizes, 0, None, out=recvs[k])
 
     def fence():
         if world > 1:

@@ -225,12 +225,12 @@ int dc_blob_shape(dc_blob* b, int* ndim, int* dims) {
 int dc_blob_count(dc_blob* b) { return b ? (int)B(b)->st->count() : 0; }
 int dc_blob_reshape(dc_blob* b, int ndim, const int* dims) {
   REQUIRE(b);
-  REQUIRE(dims);
   if (ndim < 0 || ndim > 8) return fail(DC_EINVAL, "bad number of axes");
+  if (ndim > 0) REQUIRE(dims);  // a 0-axis (scalar) shape has no dimension list, as in dc_blob_create
   return guard([&] {
     Storage& s = *B(b)->st;
     if (s.is_param) throw DcError(DC_EINVAL, "parameter blobs cannot be reshaped");
-    s.reshape(std::vector<int>(dims, dims + ndim));
+    s.reshape(ndim > 0 ? std::vector<int>(dims, dims + ndim) : std::vector<int>());
   });
 }
 static int blob_host(dc_blob* b, float** out, bool mut) {
@@ -485,6 +485,12 @@ const char* dc_net_profile_text(dc_net* net, int iters) {
   return rc == DC_OK ? n->text_buf.c_str() : nullptr;
 }
 
+const char* dc_net_debug_info(dc_net* net) {
+  if (!net) return nullptr;
+  Net* n = N(net);
+  int rc = guard([&] { n->text_buf = n->debug_info_text(); });
+  return rc == DC_OK ? n->text_buf.c_str() : nullptr;
+}
 
 // tile variants of the gather-GEMM (diagnostics / tests: DC_CONV_VARIANT takes an index into this table)
 int dc_conv_variant_count(void) { return dc::conv_num_variants(); }

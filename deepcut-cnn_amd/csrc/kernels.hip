@@ -1062,36 +1062,32 @@ const VariantEntry kVariants[] = {
     // 256-row / 256-column tiles (one workgroup per CU): half the operand traffic per flop for the long-K matrix-class layers
     DC_VARIANT_H(256, 128, 64, 4, 2, 1, 2),   // 30
     DC_VARIANT_H(128, 256, 64, 2, 4, 1, 2),   // 31
-    // float16 through LDS-DMA (round 3): no register ring, no ds_write, unpadded swizzled stages
+    // float16 through LDS-DMA (round 3): no register ring, no ds_write, unpadded swizzled stages, swapped-operand epilogue.
+    // (Measured and dropped: 4 waves with a 3-stage ring on 128x128 — one workgroup per CU without a second wave per SIMD —,
+    //  256-byte rows on 128x128, the LDS-transposed epilogue on the 8-wave tile.)
     DC_VARIANT_HD_MC(128, 128, 2, 2, 1, 2),   // 32: 66 KB -> two workgroups per CU
-    DC_VARIANT_HD(128, 128, 2, 2, 1, 3),      // 33: 96 KB, one workgroup per CU, two tiles ahead
-    DC_VARIANT_HD_MC(128, 128, 2, 2, 2, 3),   // 34: 8 waves
-    DC_VARIANT_HD(128, 128, 2, 2, 2, 4),      // 35: 8 waves, 128 KB, three tiles ahead
-    DC_VARIANT_HD(128, 64, 2, 2, 1, 3),       // 36: 72 KB -> two per CU
-    DC_VARIANT_HD(64, 128, 2, 2, 1, 3),       // 37
-    DC_VARIANT_HD(64, 64, 2, 2, 1, 4),        // 38: 64 KB
-    DC_VARIANT_HD_MC(256, 128, 4, 2, 1, 3),   // 39: 144 KB
-    DC_VARIANT_HD_MC(128, 256, 2, 4, 1, 3),   // 40
-    DC_VARIANT_HD(128, 64, 2, 2, 1, 2),       // 41: 48 KB -> three workgroups per CU (the bandwidth-class layers)
-    DC_VARIANT_HD(64, 128, 2, 2, 1, 2),       // 42
-    DC_VARIANT_HD(64, 64, 2, 2, 1, 2),        // 43: 32 KB
-    DC_VARIANT_HD2(64, 64, 2, 2, 2, 2),       // 44: 256-byte rows, 8 waves
-    DC_VARIANT_HD2(128, 128, 2, 2, 2, 2),     // 45
-    DC_VARIANT_HD2(32, 64, 1, 2, 4, 3),       // 46: split-K 4
-    // float32 through LDS-DMA
+    DC_VARIANT_HD_MC(128, 128, 2, 2, 2, 3),   // 33: 8 waves, 98 KB, two tiles ahead: the 196-workgroup res4 layers
+    DC_VARIANT_HD(128, 128, 2, 2, 2, 4),      // 34: 8 waves, 130 KB, three tiles ahead
+    DC_VARIANT_HD(128, 64, 2, 2, 1, 3),       // 35: 73 KB -> two per CU
+    DC_VARIANT_HD(64, 128, 2, 2, 1, 3),       // 36
+    DC_VARIANT_HD(64, 64, 2, 2, 1, 4),        // 37: 65 KB
+    DC_VARIANT_HD_MC(256, 128, 4, 2, 1, 3),   // 38: 146 KB, one per CU: the long-K matrix-class layers
+    DC_VARIANT_HD_MC(128, 256, 2, 4, 1, 3),   // 39
+    DC_VARIANT_HD(128, 64, 2, 2, 1, 2),       // 40: 49 KB -> three workgroups per CU (the bandwidth-class layers)
+    DC_VARIANT_HD(64, 128, 2, 2, 1, 2),       // 41
+    DC_VARIANT_HD(64, 64, 2, 2, 1, 2),        // 42: 33 KB
+    DC_VARIANT_HD2(64, 64, 2, 2, 2, 2),       // 43: 256-byte rows, 8 waves
+    DC_VARIANT_HD2(32, 64, 1, 2, 4, 3),       // 44: split-K 4 (small maps)
+    DC_VARIANT_HD_T(128, 128, 2, 2, 1, 2),    // 45: LDS-transposed epilogue instead of the swapped-operand one
+    DC_VARIANT_HD_T(64, 128, 2, 2, 1, 2),     // 46
+    // float32 through LDS-DMA: the fp32 matrix pipe is 16x slower than the fp16 one, staging is not its limiter — these
+    // tie with the register-ring tiles (+-3 % at batch 1, up to -5 % at batch 8: DESIGN 8b); the autotuner takes the wins
     DC_VARIANT_FD(32, 64, 64, 1, 2, 4, 3),    // 47: the res4/res5 batch-1 tile (8 waves, split-K 4)
-    DC_VARIANT_FD(32, 64, 64, 1, 2, 4, 4),    // 48
-    DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 3),   // 49
-    DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 4),   // 50
-    DC_VARIANT_FD(64, 64, 32, 2, 2, 2, 4),    // 51
-    DC_VARIANT_FD(64, 64, 64, 2, 2, 2, 3),    // 52
-    DC_VARIANT_FD(128, 128, 32, 2, 2, 2, 3),  // 53
-    DC_VARIANT_FD(128, 64, 32, 2, 2, 2, 3),   // 54
-    DC_VARIANT_FD(32, 32, 64, 1, 1, 4, 4),    // 55
-    DC_VARIANT_FD(64, 64, 32, 2, 2, 1, 4),    // 56: 4 waves
-    DC_VARIANT_HD_T(128, 128, 2, 2, 1, 2),    // 57: A/B of the epilogue forms
-    DC_VARIANT_HD_T(128, 128, 2, 2, 2, 3),    // 58
-    DC_VARIANT_HD_T(64, 128, 2, 2, 1, 2),     // 59
+    DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 3),   // 48
+    DC_VARIANT_FD(64, 64, 32, 2, 2, 2, 4),    // 49
+    DC_VARIANT_FD(128, 64, 32, 2, 2, 2, 3),   // 50
+    DC_VARIANT_FD(32, 32, 64, 1, 1, 4, 4),    // 51
+    DC_VARIANT_FD(64, 64, 32, 2, 2, 1, 4),    // 52: 4 waves
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
@@ -1909,6 +1905,8 @@ __global__ __launch_bounds__(256) void part_select_kernel(const T* __restrict__ 
       }
     }
     if (ok) {
+      // the raw bit pattern orders NON-NEGATIVE floats only (a set sign bit would sort above every positive score, in reverse):
+      // v >= thr >= 0 here — Net::detect_parts refuses a negative threshold — and key 0 (the padding) is below every candidate
       const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)cell);
       const int slot = atomicAdd(&cnt, 1);  // LDS counter: the slot order varies, the set and (after sorting) the result do not
       if (slot < kPartLds) keys[slot] = key;

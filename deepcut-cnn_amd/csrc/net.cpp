@@ -76,6 +76,14 @@ void Storage::reshape(const std::vector<int>& s) {
     host_cap = 0;
     head = UNINITIALIZED;
   }
+  // the same on the device side: a blob that lives only there (HEAD_AT_GPU without a host copy: mutable_gpu_data of a
+  // stand-alone blob, a Layer top, a net input after a device-side forward) and is reshaped beyond its device allocation
+  // must not keep handing out the old, too small pointer — gpu_data()/mutable_gpu_data()/to_host all return early on
+  // HEAD_AT_GPU.  Back to UNINITIALIZED: the next device access allocates (zero-filled), as a fresh SyncedMemory would.
+  if (dev && std::max<size_t>(dev_count(), 8) * (size_t)esize > dev_cap && (head == HEAD_AT_GPU || head == SYNCED)) {
+    if (head == SYNCED && host && count() <= host_cap) head = HEAD_AT_CPU;  // the (large enough) host copy stays authoritative
+    else head = UNINITIALIZED;
+  }
 }
 float* Storage::host_ptr() {
   size_t n = std::max<size_t>(count(), 1);
@@ -1743,6 +1751,12 @@ void storage_copy(Storage& dst, Storage& src, Storage* src_base, void* stream) {
   if (dst.count() != src.count()) throw DcError(DC_ESHAPE, "Trying to copy blobs of different sizes.");  // blob.cpp:437-443
   if (&dst == &src) return;
   const size_t n = src.count();
+  if (src.head == HEAD_AT_GPU && dst.is_param) {
+    // A parameter's authoritative image is its HOST copy: filter packing reads it and the weights generation is driven by
+    // its content hash.  A device-to-device copy would leave that copy stale and the forward would keep the old weights
+    // (layer->blobs()[0]->CopyFrom(gpu_blob) silently ignored).  Bring the source to the host and copy there.
+    storage_to_host(src, stream, src_base);
+  }
   if (src.head == HEAD_AT_GPU) {  // device -> device; the two images may differ in channel pitch / element type
     dst.ensure_dev(dst.dev_count());
     if (src.shape.size() == 4 && dst.shape.size() == 4) {
@@ -2445,6 +2459,62 @@ std::string Net::profile_text(int iters) {
   os << "# sum of per-launch times: " << total_us << " us\n";
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  return os.str();
+}
+
+
+// Net::ForwardDebugInfo / InputDebugInfo (net.cpp:648-681 of the reference, `debug_info: true`): the mean absolute value of
+// every top blob and every parameter blob, in the reference's own line format, from the blobs of the LAST forward — what
+// somebody bisecting a mismatch against a Caffe debug_info log needs.  Differences that follow from the lowering: an
+// in-place layer chain (conv -> BatchNorm -> Scale -> ReLU on one blob) runs as one kernel, so the blob is only ever
+// seen after the LAST layer of the chain: the line is printed for that layer, the earlier in-place layers of the chain get
+// a `(folded into ...)` note; a blob swallowed by residual / head fusion (DC_OPT_FUSE >= 1) is reported as elided — run with
+// DC_OPT_FUSE 0 to materialise all 220 Caffe-visible blobs.
+std::string Net::debug_info_text() {
+  if (!plan_valid) throw DcError(DC_EINVAL, "debug_info: run forward() first");
+  std::ostringstream os;
+  char buf[384];
+  auto mean_abs = [&](Storage& st) -> double {
+    sync_to_host(st);
+    const float* h = st.host_ptr();
+    const size_t n = st.count();
+    double a = 0;
+    for (size_t i = 0; i < n; ++i) a += std::fabs((double)h[i]);
+    return n ? a / (double)n : 0.0;
+  };
+  for (int b : inputs) {
+    std::snprintf(buf, sizeof buf, "    [Forward] Input %s data: %g\n", blobs[b]->name.c_str(), mean_abs(*blobs[b]->st));
+    os << buf;
+  }
+  // the last layer (in file order) that writes each blob: the only moment its value exists here
+  std::vector<int> last_writer(blobs.size(), -1);
+  for (size_t i = 0; i < layers.size(); ++i)
+    for (int t : layers[i].tops) last_writer[t] = (int)i;
+  for (size_t i = 0; i < layers.size(); ++i) {
+    const LayerRec& L = layers[i];
+    for (int t : L.tops) {
+      Storage& st = *blobs[t]->st;
+      if (last_writer[t] != (int)i) {
+        std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, top blob %s data: (in place: folded into layer %s)\n", L.name.c_str(),
+                      blobs[t]->name.c_str(), layers[last_writer[t]].name.c_str());
+      } else if (st.elided) {
+        std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, top blob %s data: (elided by fusion; DC_OPT_FUSE 0 materialises it)\n",
+                      L.name.c_str(), blobs[t]->name.c_str());
+      } else {
+        std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, top blob %s data: %g\n", L.name.c_str(), blobs[t]->name.c_str(), mean_abs(st));
+      }
+      os << buf;
+    }
+    for (size_t k = 0; k < L.params.size(); ++k) {
+      Storage& st = *L.params[k]->st;
+      const float* h = st.host_ptr();
+      const size_t n = st.count();
+      double a = 0;
+      for (size_t q = 0; q < n; ++q) a += std::fabs((double)h[q]);
+      std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, param blob %zu data: %g\n", L.name.c_str(), k, n ? a / (double)n : 0.0);
+      os << buf;
+    }
+  }
   return os.str();
 }
 

@@ -263,6 +263,7 @@ struct Net {
   void decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out);
   std::string plan_text();
   std::string profile_text(int iters);
+  std::string debug_info_text();  // Net::ForwardDebugInfo (net.cpp:648-681): mean |x| of every top / parameter blob
   int layer_index(const std::string& name) const;
 
  private:

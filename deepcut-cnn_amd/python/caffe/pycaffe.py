@@ -107,6 +107,7 @@ def _load():
         "dc_net_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
         "dc_net_reserve": (ci, [vp, ci, ci, ci]),
         "dc_net_device": (ci, [vp]),
+        "dc_net_debug_info": (cp, [vp]),
         "dc_conv_variant_count": (ci, []),
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
@@ -517,6 +518,13 @@ class Net(object):
 
     def num_launches(self):
         return _lib.dc_net_num_launches(self._h)
+
+    def debug_info(self):
+        """The reference's `debug_info` log of the last forward (net.cpp:648-681): mean |x| per top / parameter blob."""
+        t = _lib.dc_net_debug_info(self._h)
+        if t is None:
+            raise DeepcutError(-1, (_lib.dc_last_error() or b"").decode())
+        return t.decode()
 
     def plan_text(self):
         t = _lib.dc_net_plan_text(self._h)

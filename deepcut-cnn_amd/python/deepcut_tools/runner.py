@@ -136,6 +136,12 @@ class ShardedPoseRunner(object):
         busy = [None] * self.depth
         poses, payload, recv, uploaded = {}, {}, {}, {}
         reqs = []
+        sent = []          # (request, batch index) of this rank's sends: the payload is dropped once the send has completed
+        uses_left = {}     # image-id tuple -> batches still to be enqueued with it: the uint8 stack is dropped after the last one
+        for (_src, _s, _hw, chunk) in mine:
+            ids = tuple(items[k][0] for k in chunk)
+            uses_left[ids] = uses_left.get(ids, 0) + 1
+        checked_shapes = set()
 
         def msize(b):
             return len(b[3]) * ctot * (b[2][0] // 8) * (b[2][1] // 8)
@@ -170,7 +176,15 @@ class ShardedPoseRunner(object):
                             recv[(r, k)] = torch.empty(msize(batches_of[r][k]), dtype=mdtype, device=comm_dev)
                             ops.append(dist.P2POp(dist.irecv, recv[(r, k)], r, self.group))
                 if ops:
-                    reqs.extend(dist.batch_isend_irecv(ops))
+                    rq = dist.batch_isend_irecv(ops)
+                    reqs.extend(rq)
+                    if rank != 0 and k < len(mine):
+                        sent.append((rq[0], k))
+            # device memory must not grow with the data set: a payload that has been delivered is released
+            for rq0, kk in list(sent):
+                if rq0.is_completed():
+                    payload.pop(kk, None)
+                    sent.remove((rq0, kk))
 
         rounds = max([len(b) for b in batches_of]) if want_maps and world > 1 else 0
         for bi, (src_hw, s, in_hw, chunk) in enumerate(mine):
@@ -194,6 +208,9 @@ class ShardedPoseRunner(object):
                     uploaded[ids] = (up, ev)
                 img_t, up_ev = uploaded[ids]
                 st.wait_event(up_ev)  # the upload may have been enqueued on another executor's stream
+                uses_left[ids] -= 1
+                if uses_left[ids] == 0:
+                    del uploaded[ids]  # last scale of these images: busy[e] keeps the tensor alive until its forward is done
                 pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device=dev)
                 mbuf = torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None
             assert img_t.device == dev and pose_t.device == dev
@@ -202,6 +219,15 @@ class ShardedPoseRunner(object):
                                      stream=st.cuda_stream)
             done = None
             if want_maps:
+                if key not in checked_shapes:
+                    # the payload layout assumes stride-8 maps (msize): check it against the net once per shape instead of
+                    # letting emit_maps write past the buffer for a model with another stride
+                    checked_shapes.add(key)
+                    for name, c in zip(MAP_NAMES, chans):
+                        got = tuple(ex.blobs[name].shape)
+                        want = (len(chunk), c, in_hw[0] // 8, in_hw[1] // 8)
+                        if got != want:
+                            raise ValueError("map %r has shape %s, the exchange expects %s (stride-8 maps)" % (name, got, want))
                 hw8 = (in_hw[0] // 8) * (in_hw[1] // 8) * len(chunk)
                 o1, o2 = chans[0] * hw8, (chans[0] + chans[1]) * hw8
                 ex.emit_maps_device(mbuf[:o1].data_ptr(), mbuf[o1:o2].data_ptr(), mbuf[o2:].data_ptr(), half=half,

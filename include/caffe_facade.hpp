@@ -261,6 +261,9 @@ class Layer<float> {
     }
     return 0.f;  // no loss layers on the inference path
   }
+  // The parameter blobs are handles INTO this layer's private net: they are valid while the Layer lives and until its next
+  // LayerSetUp.  (The reference's shared_ptr<Blob> owns its memory, so weight sharing by keeping the pointer beyond the
+  // layer works there and does not here: copy with Blob::CopyFrom instead.)
   vector<shared_ptr<Blob<float> > >& blobs() { return blobs_; }
   const LayerParameter& layer_param() const { return layer_param_; }
   virtual inline const char* type() const { return net_ ? dc_net_layer_type(net_, layer_index_) : ""; }

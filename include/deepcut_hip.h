@@ -257,6 +257,13 @@ const char* dc_net_plan_text(dc_net* net);
 /* time each op of the current plan with hipEvents on the net's stream (iters runs each);
  * returns a text table (op, kernel, us, GFLOP, TFLOP/s); pointer valid until next call    */
 const char* dc_net_profile_text(dc_net* net, int iters);
+/* Net::ForwardDebugInfo / InputDebugInfo (src/caffe/net.cpp:648-681, `debug_info: true` in the NetParameter,
+ * caffe.proto:88): one line per input, top blob and parameter blob with its mean absolute value after the LAST
+ * forward, in the reference's log format ("    [Forward] Layer conv1, top blob conv1 data: 0.0645").  In-place chains
+ * run as one kernel here: the value is reported at the chain's last layer; with DC_OPT_FUSE 0 every Caffe-visible
+ * blob is materialised (fused blobs are reported as elided otherwise).  NULL + dc_last_error() on failure;
+ * pointer valid until the next call on this net.                                                                   */
+const char* dc_net_debug_info(dc_net* net);
 /* the gather-GEMM's tile-variant table (csrc/kernels.hip): number of entries, name and element size (4 float / 2 half) of
  * entry i — what the environment switch DC_CONV_VARIANT=<i> forces and the names dc_net_plan_text / DC_TUNE_CACHE use.
  * No reference counterpart: the reference has one SGEMM (math_functions.cu:13-27); diagnostics only.                  */

@@ -13,8 +13,10 @@ for p in (ROOT, os.path.join(ROOT, "deepcut-cnn_amd"), os.path.join(ROOT, "deepc
 SCALES = [0.75, 1.0, 1.25]
 
 
-def worker_images():
+def worker_images(mode="mixed"):
     rs = np.random.RandomState(5)
+    if mode == "c3":  # BASELINE configs[3] in small: 64 equal images, one scale, dealt 8 per rank over 8 ranks
+        return [rs.randint(0, 256, (96, 128, 3)).astype(np.uint8) for _ in range(64)]
     return [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for (h, w) in [(96, 128)] * 5 + [(120, 88)] * 2]
 
 
@@ -22,6 +24,7 @@ def main():
     import torch.distributed as dist
 
     weights, out = sys.argv[1], sys.argv[2]
+    mode = sys.argv[3] if len(sys.argv) > 3 else "mixed"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     import caffe
@@ -30,7 +33,10 @@ def main():
     caffe.set_mode_gpu()
     caffe.set_device(0)
     net = caffe.Net(deepercut_prototxt(152, 96, 128), weights, caffe.TEST, from_text=True, hipgraph=1)
-    res = ShardedPoseRunner(net, max_batch=4, depth=2).run(worker_images(), SCALES, want_maps=True)
+    if mode == "c3":
+        res = ShardedPoseRunner(net, max_batch=8, depth=2).run(worker_images("c3"), [1.0], want_maps=True)
+    else:
+        res = ShardedPoseRunner(net, max_batch=4, depth=2).run(worker_images(), SCALES, want_maps=True)
     if dist.get_rank() == 0:
         d = {"item_poses": res["item_poses"], "best_scale": np.array([s if s is not None else -1.0 for s in res["best_scale"]])}
         for k, m in res["maps"].items():

@@ -57,9 +57,13 @@ def test_library_has_no_cpu_forward_and_does_not_touch_the_oracle():
 
     out = subprocess.run(["nm", "-D", caffe.lib_path()], capture_output=True, text=True).stdout
     assert "oracle_" not in out
+    # the product sources never include, link or call anything of oracle/: the word may only appear in comments and in
+    # error strings that tell the user where the CPU restatement lives
     for src in os.listdir(os.path.join(ROOT, "deepcut-cnn_amd", "csrc")):
-        assert "oracle" not in open(os.path.join(ROOT, "deepcut-cnn_amd", "csrc", src)).read().replace(
-            "oracle/", "").lower() or True
+        for ln in open(os.path.join(ROOT, "deepcut-cnn_amd", "csrc", src)).read().splitlines():
+            code = ln.split("//")[0]
+            if "oracle" in code.lower():
+                assert "#include" not in code and "oracle_" not in code and '"' in code, (src, ln)
     for dirpath, _d, files in os.walk(os.path.join(ROOT, "deepcut-cnn_amd", "python")):
         for f in files:
             if f.endswith(".py"):

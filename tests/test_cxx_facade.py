@@ -179,6 +179,42 @@ int main(int argc, char** argv) {
     dump((dir + "/ly.bin").c_str(), y.cpu_data(), y.count());
     std::printf("layer %d %d %d %d\n", y.num(), y.channels(), y.height(), y.width());
   }
+  // --- Blob::Reshape beyond the device allocation of a blob that lives only on the device (blob.cpp:37-41) -----------
+  {
+    Blob<float> b(1, 2, 3, 4);
+    float* g0 = b.mutable_gpu_data();
+    if (!g0 || b.head() != SyncedMemory::HEAD_AT_GPU) return fail(30, "mutable_gpu_data");
+    if (hipMemset(g0, 0x7f, b.count() * 4) != hipSuccess) return fail(31, "hipMemset");
+    b.Reshape(4, 32, 24, 24);  // 73 728 floats: far beyond the first allocation
+    if (b.head() == SyncedMemory::HEAD_AT_GPU) return fail(32, "grown blob must not keep the stale HEAD_AT_GPU image");
+    float* g1 = b.mutable_gpu_data();
+    if (!g1) return fail(33, "mutable_gpu_data after growth");
+    if (hipMemset(g1, 0, (size_t)b.count() * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(34, "the new image holds count() floats");
+    const float* c = b.cpu_data();  // reads count() floats back: out of bounds on the old allocation
+    for (int i = 0; i < b.count(); i += 997) if (c[i] != 0.f) return fail(35, "host bytes after growth");
+  }
+  // --- layer->blobs()[0]->CopyFrom(a blob that lives on the device): the new weights must be the ones the forward uses ----
+  {
+    LayerParameter lp("name: \"c\" type: \"Convolution\" bottom: \"x\" top: \"y\" convolution_param { num_output: 6 kernel_size: 3 stride: 2 pad: 1 bias_term: false }");
+    shared_ptr<Layer<float> > conv = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> x(2, 64, 9, 11), y;
+    vector<Blob<float>*> bottom(1, &x), top(1, &y);
+    conv->SetUp(bottom, top);
+    std::vector<float> xv = slurp((dir + "/lx.bin").c_str()), wv = slurp((dir + "/lw.bin").c_str());
+    std::memcpy(x.mutable_cpu_data(), xv.data(), xv.size() * 4);
+    std::memset(conv->blobs()[0]->mutable_cpu_data(), 0, wv.size() * 4);
+    conv->Forward(bottom, top);  // all-zero filters: packs them, output 0
+    if (y.cpu_data()[7] != 0.f) return fail(40, "zero filters");
+    Blob<float> wsrc(6, 64, 3, 3);
+    std::memcpy(wsrc.mutable_cpu_data(), wv.data(), wv.size() * 4);
+    wsrc.gpu_data();
+    float* wg = wsrc.mutable_gpu_data();  // HEAD_AT_GPU: the device image is the authoritative one
+    (void)wg;
+    if (wsrc.head() != SyncedMemory::HEAD_AT_GPU) return fail(41, "source on the device");
+    conv->blobs()[0]->CopyFrom(wsrc);
+    conv->Forward(bottom, top);
+    dump((dir + "/ly2.bin").c_str(), y.cpu_data(), y.count());
+  }
   std::printf("OK\n");
   return 0;
 }
@@ -215,3 +251,7 @@ def test_facade_on_the_gpu_matches_the_oracle(tmp_path, gpu_caffe, synth152):
     got = np.fromfile(str(tmp_path / "ly.bin"), np.float32).reshape(yref.shape)
     assert float(np.abs(got - yref).max()) <= 1e-4
     assert (got >= 0).all() and (got == 0).any()
+    # a parameter overwritten from a device-resident blob: the second forward runs with the copied filters
+    y2ref = O.conv_forward(lx, lw, None, 2, 1, 1)
+    got2 = np.fromfile(str(tmp_path / "ly2.bin"), np.float32).reshape(y2ref.shape)
+    assert float(np.abs(got2 - y2ref).max()) <= 1e-4 and float(np.abs(got2).max()) > 0.1

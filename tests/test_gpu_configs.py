@@ -271,6 +271,43 @@ def test_two_ranks_sharing_gpu0_equal_world_size_1(gpu_caffe, synth152, tmp_path
             assert np.abs(got["%s_%d" % (name, k)] - single["maps"][k][name]).max() <= 1e-4, (k, name)
 
 
+def test_eight_ranks_sharing_gpu0_equal_world_size_1(gpu_caffe, synth152, tmp_path, monkeypatch):
+    """The design point of the N>1 path, on the hardware there is: EIGHT ranks (all on GPU 0, over gloo) run
+    ShardedPoseRunner with the real Net on configs[3] in small — 64 equal images dealt 8 per rank, the maps of every batch
+    sent to rank 0, which posts 7 receives per exchange round — and equal the single-process run."""
+    from deepcut_tools import ShardedPoseRunner, deepercut_prototxt
+
+    path, _ = synth152
+    out = str(tmp_path / "ranks8.npz")
+    monkeypatch.setenv("DC_AUTOTUNE", "0")  # eight processes timing tiles on one GPU at once would only measure each other
+    r = _run_ranks(8, [os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), path, out, "c3"], timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    from _gpu_rank_worker import worker_images
+
+    imgs = worker_images("c3")
+    net = gpu_caffe.Net(deepercut_prototxt(152, 96, 128), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    single = ShardedPoseRunner(net, max_batch=8, depth=2).run(imgs, [1.0], want_maps=True)
+    assert len(single["items"]) == 64
+    assert np.abs(got["item_poses"] - single["item_poses"]).max() <= 1e-2
+    for k in range(64):
+        for name in ("prob", "loc_pred", "next_pred"):
+            assert np.abs(got["%s_%d" % (name, k)] - single["maps"][k][name]).max() <= 1e-4, (k, name)
+
+
+def test_bench_eight_ranks_gloo_smoke(gpu_caffe, monkeypatch):
+    """bench.py --gpus 8 --config 3 (what the driver's scaling run launches, small maps, gloo transport, one GPU)."""
+    import json
+
+    monkeypatch.setenv("DC_AUTOTUNE", "0")
+    r = _run_ranks(8, [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--config", "3", "--height", "96", "--width", "128",
+                       "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["per_gpu_batch"] == 8 and res["config"]["global_batch"] == 64
+
+
 @pytest.mark.parametrize("extra", [[], ["--config", "3", "--dtype", "f16"]])
 def test_bench_two_ranks_gloo_smoke(gpu_caffe, extra):
     """bench.py --gpus 2 over gloo with both ranks on GPU 0: the N>1 bench path (per-rank forward, gather of the maps to

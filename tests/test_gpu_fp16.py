@@ -106,3 +106,51 @@ def test_fp16_single_layers(gpu_caffe, cfg):
     ref = (O.conv_forward if kind == "conv" else O.deconv_forward)(x, wt, b, s, p, d)
     assert got.shape == ref.shape
     assert float(np.abs(got - ref).max()) <= 2e-3 * max(1.0, float(np.abs(ref).max()))
+
+
+def _large_activation_weights(layers, gain):
+    """Synthetic weights whose trunk activations are `gain` times larger — what the un-normalised blocks of a trained
+    ResNet look like — with the head filters divided by `gain` so that the output maps stay O(1): conv1's Scale (gamma,
+    beta) is multiplied (the global-statistics BatchNorm layers do not re-normalise, ReLU is positively homogeneous), the
+    six head convolutions / deconvolutions (not their biases) are divided."""
+    out = []
+    for name, t, blobs in layers:
+        blobs = [b.copy() for b in blobs]
+        if name == "scale_conv1":
+            blobs = [b * np.float32(gain) for b in blobs]
+        if name.startswith("res5c_up_") or name.startswith("res3d_"):
+            blobs[0] = blobs[0] / np.float32(gain)
+        out.append((name, t, blobs))
+    return out
+
+
+@pytest.mark.parametrize("gain", [256.0, 2048.0])
+def test_fp16_on_trained_weight_like_magnitudes(gpu_caffe, synth152, tmp_path, gain):
+    """The float16 path on activations of trained-network magnitude: with the trunk scaled by `gain` the res4 / res5
+    activations reach 10^3 .. 10^4 (float16 tops out at 65504, its spacing there is 8 .. 32); the maps must stay finite
+    and inside the stated bounds against the float32 oracle of the SAME weights."""
+    from deepcut_tools import deepercut_prototxt, write_caffemodel
+
+    _, layers = synth152
+    big = _large_activation_weights(layers, gain)
+    path = str(tmp_path / "big.caffemodel")
+    write_caffemodel(path, "ResNet-152", big)
+    h, w = 104, 136
+    proto = deepercut_prototxt(152, h, w, 1)
+    img = rand_image(33, h, w)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    ref = O.OracleNet(proto, big).forward(data=img)
+    peak = {k: float(np.abs(ref[k]).max()) for k in ("res3b7", "res4b35", "res5c")}
+    assert peak["res4b35"] > 2.5 * gain and peak["res5c"] > 2.5 * gain, peak  # the activations ARE large (>= 6e2 / 5e3)
+    assert max(peak.values()) < 6.0e4, peak                                   # and still representable in float16
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, dtype="f16", fuse=0)
+    net.blobs["data"].data[...] = img
+    out = net.forward()
+    for k in ("prob", "loc_pred", "next_pred"):
+        assert np.isfinite(out[k]).all(), k
+    _check_maps(out, ref)
+    for name in ("res4b35", "res5c"):  # the large blobs themselves: relative to their range
+        r = ref[name]
+        got = net.blobs[name].data
+        assert np.isfinite(got).all(), name
+        assert float(np.abs(got - r).max()) <= 1e-2 * float(np.abs(r).max()), name

@@ -320,3 +320,44 @@ def test_sharded_runner_on_the_hip_path(gpu_caffe, synth152):
         assert (ref is None) == (got is None)
         if ref is not None:
             assert np.abs(got - ref).max() <= 1e-2  # batched vs single forward: fp32 summation order only
+
+
+def test_debug_info_matches_the_oracles_blobs(gpu_caffe, synth152):
+    """dc_net_debug_info = Net::ForwardDebugInfo (net.cpp:648-681): the mean |x| of every Caffe-visible top blob of the last
+    forward, in the reference's log format; with fusion off every one of them is a number and equals the oracle's."""
+    import re
+
+    from deepcut_tools import deepercut_prototxt
+    from oracle import oracle as O
+
+    path, layers = synth152
+    proto = deepercut_prototxt(152, 64, 64)
+    net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, fuse=0)
+    img = rand_image(41, 64, 64)
+    net.blobs["data"].data[...] = img
+    net.forward()
+    text = net.debug_info()
+    lines = text.splitlines()
+    assert lines[0].startswith("    [Forward] Input data data: ")
+    assert abs(float(lines[0].split(": ")[1]) - float(np.abs(img).mean())) < 1e-3
+    O.set_threads(min(16, os.cpu_count() or 1))
+    ref = O.OracleNet(proto, layers).forward(data=img)
+    tops = {}
+    for ln in lines:
+        m = re.match(r"    \[Forward\] Layer (\S+), top blob (\S+) data: (.*)$", ln)
+        if m and not m.group(3).startswith("("):
+            tops[m.group(2)] = float(m.group(3))
+    assert "elided" not in text
+    checked = 0
+    for name, val in tops.items():
+        if name in ref:
+            want = float(np.abs(ref[name]).mean())
+            assert abs(val - want) <= 1e-4 * max(1.0, want), (name, val, want)
+            checked += 1
+    assert checked >= 200 and {"prob", "loc_pred", "next_pred", "res5c"} <= set(tops)
+    assert sum(1 for ln in lines if ", param blob " in ln) >= 158 + 3 * 155 + 2 * 155  # conv + BN + Scale parameter blobs
+    # with fusion on, swallowed blobs are reported as such (never as stale numbers)
+    net2 = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, fuse=2)
+    net2.blobs["data"].data[...] = img
+    net2.forward()
+    assert "elided by fusion" in net2.debug_info()

@@ -10,7 +10,7 @@ from conftest import rand_image
 
 pytestmark = pytest.mark.gpu
 H, W = [int(v) for v in os.environ.get("DC_TEST_VARIANT_HW", "72,104").split(",")]  # override to sweep another input size
-MAX_VARIANTS = 96  # parametrisation bound; indices past the library's table (caffe.conv_variants()) are skipped, a longer table fails
+MAX_VARIANTS = 64  # parametrisation bound; indices past the library's table (caffe.conv_variants()) are skipped, a longer table fails
 
 
 @pytest.fixture(scope="module")

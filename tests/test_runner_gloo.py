@@ -128,3 +128,76 @@ def test_world2_gloo_with_a_rank_that_has_no_work():
         p.join(60)
         assert p.exitcode == 0
     assert np.allclose(item_poses, single["item_poses"], atol=1e-12) and map_keys == [0] and have == [True]
+
+
+def _run_world(world, n_images, scales, images=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, n_images, tuple(scales))) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return out
+
+
+def _images64(n):
+    """n equal-size 96x128 images (BASELINE configs[3]'s 64 equal images, small) / crops of one size (configs[4])."""
+    rs = np.random.RandomState(11)
+    return [rs.randint(0, 256, (96, 128, 3)).astype(np.uint8) for _ in range(n)]
+
+
+def _worker8(rank, world, port, q, n_images, scales):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "deepcut-cnn_amd", "python"))
+    sys.path.insert(0, here)
+    from test_runner_gloo import FakeNet, _images64
+    from deepcut_tools import ShardedPoseRunner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = ShardedPoseRunner(FakeNet()).run(_images64(n_images), list(scales), want_maps=True)
+        if rank == 0:
+            q.put((res["item_poses"], [p is not None for p in res["poses"]], sorted(res["maps"].keys()),
+                   float(sum(float(v["prob"].sum()) for v in res["maps"].values()))))
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_gloo_config3_64_equal_images():
+    """BASELINE configs[3] at its design point: 64 equal images dealt 8 per rank over 8 ranks, maps gathered to rank 0
+    (7 peers per exchange round), equal to the single-process run."""
+    from deepcut_tools import plan_work
+
+    items, shards = plan_work([(96, 128)] * 64, [1.0], 8)
+    assert [len(s) for s in shards] == [8] * 8
+    single = ShardedPoseRunner(FakeNet()).run(_images64(64), [1.0], want_maps=True)
+    item_poses, have, map_keys, checksum = _run_world(8, 64, [1.0])
+    assert np.allclose(item_poses, single["item_poses"], atol=1e-12)
+    assert map_keys == list(range(64)) and all(have)
+    assert abs(checksum - sum(float(v["prob"].sum()) for v in single["maps"].values())) < 1e-6 * abs(checksum)
+
+
+def test_world8_gloo_config4_crops_times_scales_lpt():
+    """BASELINE configs[4]: 32 crops x 4 scales = 128 items of four different costs, LPT over 8 ranks, maps on."""
+    scales = [0.5, 0.75, 1.0, 1.25]
+    single = ShardedPoseRunner(FakeNet()).run(_images64(32), scales, want_maps=True)
+    item_poses, have, map_keys, checksum = _run_world(8, 32, scales)
+    assert np.allclose(item_poses, single["item_poses"], atol=1e-12)
+    assert map_keys == list(range(128)) and all(have)
+    assert abs(checksum - sum(float(v["prob"].sum()) for v in single["maps"].values())) < 1e-6 * abs(checksum)
+
+
+def test_world8_gloo_with_idle_ranks():
+    """3 images at one scale on 8 ranks: five ranks are idle in every exchange round."""
+    single = ShardedPoseRunner(FakeNet()).run(_images64(3), [1.0], want_maps=True)
+    item_poses, have, map_keys, _c = _run_world(8, 3, [1.0])
+    assert np.allclose(item_poses, single["item_poses"], atol=1e-12) and map_keys == [0, 1, 2] and have == [True] * 3

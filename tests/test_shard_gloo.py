@@ -36,7 +36,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_items=7):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(here, "..", "deepcut-cnn_amd", "python"))
     from deepcut_tools import gather_maps, gather_maps_known, lpt_shards as lpt
@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # every rank "forwards" its shard with a deterministic fake detector, then maps are gathered
-        items = [(i, 8 * (2 + i % 3), 8 * (3 + i % 2)) for i in range(7)]
+        items = [(i, 8 * (2 + i % 3), 8 * (3 + i % 2)) for i in range(n_items)]
         shards = lpt([h * w for _, h, w in items], world)
 
         def fake_maps(i, h, w):
@@ -60,8 +60,8 @@ def _worker(rank, world, port, q):
         if rank == 0:
             ok = True
             for r in range(world):
-                exp = torch.cat([fake_maps(*items[i]) for i in shards[r]])
-                ok = ok and torch.equal(got[r], exp) and torch.equal(got2[r], exp)
+                exp = torch.cat([fake_maps(*items[i]) for i in shards[r]]) if shards[r] else torch.zeros(0)
+                ok = ok and torch.equal(got[r].view(-1), exp) and torch.equal(got2[r].view(-1), exp)
             q.put(("ok" if ok else "mismatch", [int(t.numel()) for t in got]))
         else:
             assert got is None and got2 is None
@@ -82,3 +82,28 @@ def test_gather_maps_world2_gloo():
         assert p.exitcode == 0
     status, sizes = q.get(timeout=5)
     assert status == "ok" and len(sizes) == 2 and sum(sizes) > 0
+
+
+def _spawn(world, n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_items)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    return q.get(timeout=5)
+
+
+def test_gather_maps_world8_gloo():
+    """The design point: 8 ranks, rank 0 posts 7 grouped receives per exchange (shard.py), sizes from the LPT deal."""
+    status, sizes = _spawn(8, 21)
+    assert status == "ok" and len(sizes) == 8 and all(s > 0 for s in sizes)
+
+
+def test_gather_maps_world8_gloo_with_idle_ranks():
+    """5 items on 8 ranks: three ranks have nothing to send — no message is posted for them."""
+    status, sizes = _spawn(8, 5)
+    assert status == "ok" and len(sizes) == 8 and sorted(s > 0 for s in sizes) == [False] * 3 + [True] * 5
