@@ -1089,6 +1089,48 @@ void Net::build_plan() {
       for (int c = 0; c < C; ++c) h[c] = (float)op.b[c];
     });
   };
+  // float16 filter images: per-output-channel power-of-two pre-scaling (exact in fp32; undone by the epilogue's fp32 scale), see
+  // DevVec::row_scale.  Called right after the image of a launch is made / found; replaces the launch's scale vector by
+  // a[c] * 2^-k(c) (keyed by the image, since k depends on the image's rows).
+  static const bool half_rowscale = env_int("DC_HALF_ROWSCALE", 1) != 0;
+  auto half_row_scale = [&](Launch& l, const LOp& op, int OC) {
+    if (dtype != 1 || !half_rowscale || !l.w) return;
+    DevVec& Wv = *l.w;
+    if (Wv.row_scale.empty()) {
+      if (Wv.host.empty()) return;  // an image uploaded before this feature existed in the process: leave it
+      struct Seg { size_t off; int K; };
+      std::vector<Seg> segs;
+      if (l.cg.ncls > 1)
+        for (int q = 0; q < l.cg.ncls; ++q) segs.push_back({(size_t)l.cg.cls[q].w_off, l.cg.cls[q].Ktot});
+      else
+        segs.push_back({0, l.cg.Ktot});
+      Wv.row_scale.assign(OC, 1.f);
+      for (int c = 0; c < OC; ++c) {
+        float mx = 0.f;
+        for (const Seg& sg : segs) {
+          const float* r = Wv.host.data() + sg.off + (size_t)c * sg.K;
+          for (int k = 0; k < sg.K; ++k) mx = std::max(mx, std::fabs(r[k]));
+        }
+        if (!(mx > 0.f) || !std::isfinite(mx)) continue;
+        int k = 13 - std::ilogb(mx);
+        k = std::max(-60, std::min(60, k));
+        if (k == 0) continue;
+        const float f = std::ldexp(1.f, k);
+        for (const Seg& sg : segs) {
+          float* r = Wv.host.data() + sg.off + (size_t)c * sg.K;
+          for (int q = 0; q < sg.K; ++q) r[q] *= f;
+        }
+        Wv.row_scale[c] = std::ldexp(1.f, -k);
+      }
+    }
+    std::shared_ptr<DevVec> rs = l.w;  // keeps row_scale alive inside the fill
+    char wkey[40];  // the image's identity: its address (images and these vectors live and die together in vec_by_key)
+    std::snprintf(wkey, sizeof wkey, "%p", (void*)l.w.get());
+    l.scale = get_vec(std::string("ha:") + wkey + ":" + std::to_string(op.lids.front()) + ":" + std::to_string(op.lids.size()), [&](std::vector<float>& h) {
+      h.resize(OC);
+      for (int c = 0; c < OC; ++c) h[c] = (float)((op.a.empty() ? 1.0 : op.a[c]) * (double)rs->row_scale[c]);
+    });
+  };
   const int wino_mode = env_int("DC_WINOGRAD", -1);  // -1: where measured faster (autotune); 0: never; 1: wherever eligible
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
@@ -1218,6 +1260,7 @@ void Net::build_plan() {
       l.flops = 2.0 * g.M * (double)OC * C * c.kh * c.kw;
       plan_flops += l.flops;
       l.w->as_half = dtype == 1;
+          half_row_scale(l, op, OC);
       choose_variant(l, kgcd);
       // stride-1 3x3 layers can also run as Winograd F(2x2,3x3): keep the transformed filters next to the direct ones
       // and let the per-shape timing decide (kernels.hip, wino_f23_kernel)
@@ -1364,6 +1407,7 @@ void Net::build_plan() {
             for (size_t q = 0; q < recs.size(); ++q) fill_class(recs[q], h.data() + l.cg.cls[q].w_off);
           });
           l.w->as_half = dtype == 1;
+          half_row_scale(l, op, OC);
           choose_variant(l, CP);
           plan.push_back(std::move(l));
           merged = true;
@@ -1383,6 +1427,7 @@ void Net::build_plan() {
           });
           l.flops = 2.0 * rec.g.M * (double)OC * C * rec.g.nty * rec.g.ntx;
           l.w->as_half = dtype == 1;
+          half_row_scale(l, op, OC);
           choose_variant(l, CP);
           plan.push_back(std::move(l));
         }

@@ -109,6 +109,10 @@ struct LayerRec {
 struct DevVec {  // a packed filter / affine vector; shared between a Net and its clones
   std::vector<float> host;
   bool as_half = false;  // filter image of an fp16 net: converted to _Float16 on upload
+  // fp16 filter images: output channel c of the image was multiplied by an exact power of two 2^k(c) that brings its largest
+  // weight into [2^13, 2^14) — filters of 1e-5 (a head on a trunk with large activations) would otherwise sit in float16's
+  // subnormal range with a handful of significant bits —; row_scale[c] = 2^-k(c) goes into the launch's fp32 epilogue scale
+  std::vector<float> row_scale;
   float* dev = nullptr;
   size_t uploaded = 0;
   DevVec() = default;

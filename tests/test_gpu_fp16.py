@@ -124,11 +124,12 @@ def _large_activation_weights(layers, gain):
     return out
 
 
-@pytest.mark.parametrize("gain", [256.0, 2048.0])
+@pytest.mark.parametrize("gain", [32.0, 256.0, 1024.0])
 def test_fp16_on_trained_weight_like_magnitudes(gpu_caffe, synth152, tmp_path, gain):
-    """The float16 path on activations of trained-network magnitude: with the trunk scaled by `gain` the res4 / res5
-    activations reach 10^3 .. 10^4 (float16 tops out at 65504, its spacing there is 8 .. 32); the maps must stay finite
-    and inside the stated bounds against the float32 oracle of the SAME weights."""
+    """The float16 path on activations of trained-network magnitude: the conditioned synthetic trunk peaks at ~33 (res4b35)
+    and ~45 (res5c); scaled by 32 / 256 / 1024 it reaches 1.4e3 / 1.1e4 / 4.6e4 — up to 70 % of float16's largest finite value
+    65504, where its spacing is 32.  The maps must stay finite and inside the stated bounds against the float32 oracle of the SAME
+    weights (rounding is relative: the bounds, relative to the maps' range, do not move with the magnitude)."""
     from deepcut_tools import deepercut_prototxt, write_caffemodel
 
     _, layers = synth152
@@ -141,7 +142,7 @@ def test_fp16_on_trained_weight_like_magnitudes(gpu_caffe, synth152, tmp_path, g
     O.set_threads(min(16, os.cpu_count() or 1))
     ref = O.OracleNet(proto, big).forward(data=img)
     peak = {k: float(np.abs(ref[k]).max()) for k in ("res3b7", "res4b35", "res5c")}
-    assert peak["res4b35"] > 2.5 * gain and peak["res5c"] > 2.5 * gain, peak  # the activations ARE large (>= 6e2 / 5e3)
+    assert peak["res4b35"] > 25 * gain and peak["res5c"] > 35 * gain, peak  # the activations ARE large (gain 1024: 3.3e4 / 4.6e4)
     assert max(peak.values()) < 6.0e4, peak                                   # and still representable in float16
     net = gpu_caffe.Net(proto, path, gpu_caffe.TEST, from_text=True, dtype="f16", fuse=0)
     net.blobs["data"].data[...] = img
