@@ -358,6 +358,16 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       const int ox = rem - oy * c_OW;
       avoff[i] = (unsigned)(int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES) + lcb;
       unsigned rowmask = 0, colmask = 0, full = 0;
+      if (DMA && c_nty == 3 && c_ntx == 3) {
+        // the 3x3 layers (a third of the float16 time): the same masks, straight-line — the generic loops below cost ~3 k
+        // cycles of every workgroup's prologue (dependent compares + branches, two to four rows per thread)
+        const int y0 = oy * p.sy + c_dy0, x0 = ox * p.sx + lce + c_x0;
+        const unsigned r0 = (unsigned)y0 < (unsigned)p.x_rows, r1 = (unsigned)(y0 + c_ddy) < (unsigned)p.x_rows, r2 = (unsigned)(y0 + 2 * c_ddy) < (unsigned)p.x_rows;
+        const unsigned cm = ((unsigned)x0 < (unsigned)p.x_rowlen ? 1u : 0u) | ((unsigned)(x0 + c_ddx) < (unsigned)p.x_rowlen ? 2u : 0u) |
+                            ((unsigned)(x0 + 2 * c_ddx) < (unsigned)p.x_rowlen ? 4u : 0u);
+        amask[i] = (r0 ? cm : 0u) | (r1 ? cm << 3 : 0u) | (r2 ? cm << 6 : 0u);
+        continue;
+      }
 #pragma nounroll
       for (int ty = 0; ty < c_nty; ++ty) rowmask |= ((unsigned)(oy * p.sy + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows ? 1u : 0u) << ty;
 #pragma nounroll
