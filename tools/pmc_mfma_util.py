@@ -6,6 +6,11 @@ stage (conv1 / res2 / res3 / res4 / res5 / heads): dispatches are matched to pla
 Counters needed: SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE."""
 import collections
 import sqlite3
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_names  # noqa: E402
 import sys
 
 
@@ -84,7 +89,7 @@ def main(path, desc, plan_path=None, bench_path=None):
         tm += mf
         tg += gui
         dur_cycles = d["GRBM_GUI_ACTIVE"][2] * 2.4  # ns x 2.4 cycles/ns
-        label = k[k.index("<"):k.index(">") + 1] if "<" in k else "wino_f23 (Winograd F(2x2,3x3))"
+        label = kernel_names.label(k)
         print("%-36s %6d %5d %9.1f %8.1f%% %10.1f%% %8.1f%% %8.1f%%" % (label, g // wg, n, d["GRBM_GUI_ACTIVE"][2] / n / 1e3,
                                                                      100 * mf / (gui * 1024), 100 * mf / (dur_cycles * 1024),
                                                                      100 * d["SQ_WAIT_ANY"][0] / wc, 100 * d["SQ_WAIT_INST_ANY"][0] / wc))

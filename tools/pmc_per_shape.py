@@ -2,8 +2,12 @@
 """Per kernel (name, grid): HBM-side bytes per dispatch from the FETCH_SIZE / WRITE_SIZE PMC passes (rocpd sqlite), with the
 gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x2, KB units).   python tools/pmc_per_shape.py fetch.db write.db"""
 import re
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_names  # noqa: E402
 
 
 def table(path, counter):
@@ -17,10 +21,7 @@ def table(path, counter):
 
 
 def short(name):
-    m = re.search(r"conv_gemm_kernel<([^>]*)>", name)
-    if m:
-        return "conv_gemm<" + m.group(1).replace(" ", "") + ">"
-    return name.split("(")[0][:40]
+    return kernel_names.label(name)
 
 
 def main(fdb, wdb):

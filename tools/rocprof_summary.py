@@ -3,8 +3,12 @@
 profiles/:  python tools/rocprof_summary.py gpurun_out/prof/x_results.db > profiles/x_kernel_stats.txt
 Durations are computed from the per-dispatch start/end timestamps (ns)."""
 import collections
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_names  # noqa: E402
 
 
 def main(path):
@@ -20,7 +24,8 @@ def main(path):
     print("# rocprofv3 --kernel-trace --stats summary of %s (from per-dispatch start/end, ns)" % path)
     print("%-112s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print("%-112s %8d %12.1f %10.2f %7.2f" % (name[:112], n, t / 1e3, t / n / 1e3, 100.0 * t / tot))
+        shown = kernel_names.label(name) if ("conv_gemm_kernel" in name or "wino_f23" in name) else name
+        print("%-112s %8d %12.1f %10.2f %7.2f" % (shown[:112], n, t / 1e3, t / n / 1e3, 100.0 * t / tot))
     print("# total kernel time: %.3f ms over %d dispatches" % (tot / 1e6, sum(a[0] for a in agg.values())))
     n = sum(a[0] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k)
     t = sum(a[1] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k)
