@@ -1049,11 +1049,11 @@ const VariantEntry kVariants[] = {
     // 8-wave workgroups: two waves per SIMD, so one wave's LDS/global/SALU work hides under the other's MFMAs
     DC_VARIANT_MC(32, 64, 64, 1, 2, 4, 4), // 10
     DC_VARIANT_MC(64, 64, 64, 2, 2, 2, 3), // 11
-    DC_VARIANT(128, 64, 32, 2, 2, 2, 2),   // 12
-    DC_VARIANT(128, 128, 32, 2, 2, 2, 2),  // 13
+    DC_VARIANT_MC(128, 64, 32, 2, 2, 2, 2), // 12 (multi-class too: the merged heads fetch 8.7x their minimum on 32x32 tiles)
+    DC_VARIANT_MC(128, 128, 32, 2, 2, 2, 2), // 13
     DC_VARIANT(64, 64, 32, 2, 2, 2, 3),    // 14
     DC_VARIANT_MC(32, 32, 128, 1, 1, 8, 3), // 15
-    DC_VARIANT(64, 128, 32, 2, 2, 2, 2),   // 16
+    DC_VARIANT_MC(64, 128, 32, 2, 2, 2, 2), // 16
     // fp16 operands (v_mfma_f32_32x32x16_f16, fp32 accumulate); BK in halves: 64 = one 128-B line per row
     DC_VARIANT_H_MC(128, 128, 64, 2, 2, 1, 2),   // 17 (multi-class too: the float16 heads at batch 8 run 26 % faster on 128-wide tiles)
     DC_VARIANT_H_MC(128, 64, 64, 2, 2, 1, 2),    // 18
