@@ -1104,6 +1104,10 @@ void Net::build_plan() {
         for (int q = 0; q < l.cg.ncls; ++q) segs.push_back({(size_t)l.cg.cls[q].w_off, l.cg.cls[q].Ktot});
       else
         segs.push_back({0, l.cg.Ktot});
+      for (const Seg& sg : segs)
+        if (sg.off + (size_t)OC * sg.K > Wv.host.size())
+          throw DcError(DC_EINVAL, "launch '" + l.label + "': filter image of " + std::to_string(Wv.host.size()) + " elements is smaller than " +
+                                       std::to_string(OC) + " rows of " + std::to_string(sg.K));
       Wv.row_scale.assign(OC, 1.f);
       for (int c = 0; c < OC; ++c) {
         float mx = 0.f;
@@ -1207,14 +1211,23 @@ void Net::build_plan() {
         g.klen = klen;
         g.Ktot = c.kh * klen;
         kgcd = klen;
-        l.w = get_vec(dkey + "w:" + std::to_string(op.wl), [&](std::vector<float>& h) {
-          h.assign((size_t)c.num_output * g.Ktot, 0.f);
-          const float* w = L.params[0]->st->host_ptr();  // [Cout][Cin][kh][kw]
-          for (int co = 0; co < c.num_output; ++co)
-            for (int ci = 0; ci < C; ++ci)
-              for (int ky = 0; ky < c.kh; ++ky)
-                for (int kx = 0; kx < c.kw; ++kx)
-                  h[(size_t)co * g.Ktot + ky * klen + kx * CP + ci] = w[(((size_t)co * C + ci) * c.kh + ky) * c.kw + kx];
+        // sibling layers merged into one launch (the skip convolutions of the heads) are concatenated along Cout here too:
+        // round 2 packed only the first member in this path — a float16 net whose skip level has fewer than 64 channels
+        // ran its second and third head on rows beyond the image (found by the row scaling's bounds check in round 3)
+        const std::vector<int> members = op.wls.empty() ? std::vector<int>{op.wl} : op.wls;
+        l.w = get_vec(dkey + "w:" + std::to_string(members.front()) + "x" + std::to_string(members.size()) + "r", [&](std::vector<float>& h) {
+          h.assign((size_t)OC * g.Ktot, 0.f);
+          int cbase = 0;
+          for (int ml : members) {
+            const float* w = layers[ml].params[0]->st->host_ptr();  // [Cout][Cin][kh][kw]
+            const int cm = layers[ml].conv.num_output;
+            for (int co = 0; co < cm; ++co)
+              for (int ci = 0; ci < C; ++ci)
+                for (int ky = 0; ky < c.kh; ++ky)
+                  for (int kx = 0; kx < c.kw; ++kx)
+                    h[(size_t)(cbase + co) * g.Ktot + ky * klen + kx * CP + ci] = w[(((size_t)co * C + ci) * c.kh + ky) * c.kw + kx];
+            cbase += cm;
+          }
         });
       } else {
         if (c.kh * c.kw > kMaxTaps)

@@ -155,3 +155,32 @@ def test_fp16_on_trained_weight_like_magnitudes(gpu_caffe, synth152, tmp_path, g
         got = net.blobs[name].data
         assert np.isfinite(got).all(), name
         assert float(np.abs(got - r).max()) <= 1e-2 * float(np.abs(r).max()), name
+
+
+def test_fp16_net_with_a_narrow_skip_level(gpu_caffe):
+    """A DeeperCut-shaped FCN whose layers have 16 / 32 input channels — fewer than the 64 halves of a float16 K tile, so they
+    take the row-tap packing — including the two sibling skip convolutions that run as ONE launch: round 2 packed only the
+    first sibling's filters in that path (the second head read rows beyond the image); found by round 3's bounds check."""
+    from test_gpu_tiling import _fill, local_fcn_prototxt
+
+    h, w = 64, 96
+    proto = local_fcn_prototxt(h, w)
+    net32 = gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True)
+    _fill(net32, 5)
+    layers = [(name, typ, [b.data.copy() for b in net32.params[name]])
+              for name, typ in zip(net32._layer_names, net32.layer_types) if name in net32.params]
+    img = rand_image(7, h, w)
+    O.set_threads(min(16, os.cpu_count() or 1))
+    ref = O.OracleNet(proto, layers).forward(data=img)
+    net32.blobs["data"].data[...] = img
+    out32 = net32.forward()
+    for k in ("prob", "loc_pred"):
+        assert float(np.abs(out32[k] - ref[k]).max()) <= 1e-3, k
+    for fuse in (0, 2):
+        net16 = gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True, dtype="f16", fuse=fuse)
+        _fill(net16, 5)
+        net16.blobs["data"].data[...] = img
+        out = net16.forward()
+        assert float(np.abs(out["prob"] - ref["prob"]).max()) <= 2.5e-3, fuse
+        rng = max(1.0, float(np.abs(ref["loc_pred"]).max()))
+        assert float(np.abs(out["loc_pred"] - ref["loc_pred"]).max()) <= 4e-3 * rng, fuse
