@@ -106,9 +106,11 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
 def hbm_traffic_from_profile():
     """HBM bytes per conv_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     corrected as MI355X_MICROARCH.md prescribes) — counters cannot be read inside the timed run."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")), reverse=True):  # newest round first
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"], name
+            return json.load(open(path))["hbm_bytes_per_launch"], os.path.basename(path)
         except Exception:
             continue
     return None, None
