@@ -103,12 +103,16 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
     }
 
 
-def hbm_traffic_from_profile():
+def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
     """HBM bytes per conv_gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md prescribes) — counters cannot be read inside the timed run."""
+    corrected as MI355X_MICROARCH.md prescribes) — counters cannot be read inside the timed run.  Passes exist for
+    the headline workload and for float16 at batch 8; any other workload reports null."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")), reverse=True):  # newest round first
+    suffix = {("f32", 1, 544, 736): "", ("f16", 8, 544, 736): "_f16_b8"}.get(tuple(workload))
+    if suffix is None:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic%s.json" % suffix)), reverse=True):  # newest round first
         try:
             return json.load(open(path))["hbm_bytes_per_launch"], os.path.basename(path)
         except Exception:
@@ -389,10 +393,10 @@ def main():
                 "flops_per_launch": per_launch_flops,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_image": conv_launches,
-                "traffic": hbm_traffic_from_profile()[0] if (args.dtype, B, H, W) == ("f32", 1, 544, 736) else None,
+                "traffic": hbm_traffic_from_profile((args.dtype, B, H, W))[0],
                 "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s); "
-                                "algorithmic minimum %.1f MB" % (hbm_traffic_from_profile()[1],
-                                                                 (2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) / conv_launches / 1e6),
+                                "algorithmic minimum %.1f MB" % (hbm_traffic_from_profile((args.dtype, B, H, W))[1],
+                                                                 (2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) * (0.5 if args.dtype == "f16" else 1.0) / conv_launches / 1e6),
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
             },
         }
