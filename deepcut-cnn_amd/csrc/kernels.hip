@@ -47,6 +47,8 @@ __device__ __forceinline__ int dc_fastdiv(int n, const unsigned (&mg)[2]) {
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // LDS-DMA (`buffer_load_dwordx4 ... lds`): 64 lanes x 16 bytes travel from global memory straight into LDS, no VGPRs and
 // no ds_write.  The LDS destination is M0 + 16*lane (lane-linear, 1 KiB per wave instruction); the SOURCE address is per
@@ -78,6 +80,18 @@ __device__ __forceinline__ float dc_load_f32_untracked(i32x4 rs, unsigned voff) 
 __device__ __forceinline__ void dc_permlane32_swap4(float (&lo)[4], float (&hi)[4]) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
       : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+// float32 + the low / high half of a packed float16 pair, exactly rounded once (v_fma_mix_f32 h * 1.0 + f): the conversion folded into
+// the add.  Plain (non-volatile) asm: pure functions of their inputs.
+__device__ __forceinline__ float dc_add_half_lo(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
+}
+__device__ __forceinline__ float dc_add_half_hi(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
 }
 template <int N>
 __device__ __forceinline__ void dc_wait_vm() {
@@ -154,11 +168,17 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   constexpr int SPC = Elem<T>::SPC;
   constexpr int NW = WR * WC * WK;       // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(NW == 4 || NW == 8 || (NW == 16 && DMA), "4 or 8 waves per workgroup (16 compiles for the LDS-DMA tiles: measured, no gain — DESIGN 8b)");
   constexpr int LDB = DMA ? BK * ES : BK * ES + 16;  // LDS row, bytes: padded (16-B aligned, bank-spread), or 128 swizzled (DMA)
   static_assert(!DMA || BK * ES == 128 || BK * ES == 256, "the LDS-DMA image has 128- or 256-byte rows (8 / 16 chunks of 16 bytes, XOR-swizzled)");
   static_assert(DMA == 0 || (DMA >= 2 && DMA <= 4), "ring of 2..4 LDS stages");
   constexpr int NSTG = DMA ? DMA : 2;
+#ifndef DC_PRO_FULL
+#define DC_PRO_FULL 1
+#endif
+  // LDS-DMA: tiles the prologue requests.  The whole ring (DMA) — not DMA-1 with the last stage filled during tile 0 — puts
+  // tile DMA-1 in flight a first-tile latency earlier; the steady state (tile it requests tile it+DMA-1) is the same.
+  constexpr int PRO = DMA ? (DC_PRO_FULL ? DMA : DMA - 1) : 0;
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1 && TM % 32 == 0 && TN % 32 == 0, "wave tile = multiples of 32x32");
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   };
   if constexpr (DMA) {
 #pragma unroll
-    for (int k = 0; k < DMA - 1; ++k)
+    for (int k = 0; k < PRO; ++k)
       if (k < T_) dma_b(k);
   } else {
 #pragma unroll
@@ -426,16 +446,21 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   };
   // ... and piece pc of that tile (0..NA-1: activation rows, NA..NA+NBV-1: filter rows) goes to stage `stg`
   auto dma_piece = [&](unsigned so, int pc) {  // so: byte offset of the stage
-    if (pc < NA)
+    if (pc < NA) {
+#ifdef DC_ABL  // diagnostic builds (wrong results, timing only): bit 0 = no in-loop DMA, 1 = no in-loop barrier, 2 = no in-loop
+               // fragment reads, 4 = activation pieces of 3 of 9 taps only (the bytes an LDS-resident halo would move)
+      if ((DC_ABL & 16) && c_nty == 3 && (d_bit & 0x1b6u)) return;
+#endif
       dc_dma16(xrs, ldsw + so + pc * RPP * LDB, (amask[pc < NA ? pc : 0] & d_bit) ? avoff[pc < NA ? pc : 0] : kOOB, d_soff);
+    }
     else
       dc_dma16(wrs, ldsw + so + BM * LDB + (pc - NA) * RPP * LDB, bvoff[pc >= NA ? pc - NA : 0], d_kg);
   };
   if constexpr (DMA) {
-    // the filter pieces of the first DMA-1 tiles are on their way already (dma_b advanced kg): only the activation pieces here
+    // the filter pieces of the first PRO tiles are on their way already (dma_b advanced kg): only the activation pieces here
     const int kg_keep = kg;
 #pragma unroll
-    for (int k = 0; k < DMA - 1; ++k)
+    for (int k = 0; k < PRO; ++k)
       if (k < T_) {
         dma_next();
 #pragma unroll
@@ -518,8 +543,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   // sweep the 256 MB Infinity Cache), so a single tile of lookahead does not cover their latency.
   if constexpr (DMA) {
     // tile 0 has landed when at most the later prologue tiles' activation pieces (requested after it) are outstanding
-    const int pt = T_ < DMA - 1 ? T_ : DMA - 1;  // tiles requested so far
-    if (pt >= 3) dc_wait_vm<2 * NA>();
+    const int pt = T_ < PRO ? T_ : PRO;  // tiles requested so far
+    if (PRO >= 4 && pt >= 4) dc_wait_vm<3 * NA>();
+    else if (pt >= 3) dc_wait_vm<2 * NA>();
     else if (pt == 2) dc_wait_vm<NA>();
     else dc_wait_vm<0>();
     if constexpr (SWP) {  // the constants were requested before every DMA piece: the wait above covers them
@@ -617,24 +643,40 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               if (i == 0) {
                 // tiles that may stay in flight: those after it+1 that exist, but never a prologue tile (the prologue requested
                 // all filter pieces before all activation pieces, so "the youngest n tiles" only means something for loop tiles)
-                if constexpr (moreD) {
-                  if (DMA >= 4 && it == 0) dc_wait_vm<PPW>();
-                  else dc_wait_vm<(DMA - 2) * PPW>();
+                if (moreD && it >= PRO - 1) {
+                  dc_wait_vm<(DMA - 2) * PPW>();  // steady state: the DMA-2 tiles after it+1 are loop tiles
                 } else {
-                  int left = T_ - 2 - it;
-                  if (left > it + 1) left = it + 1;
-                  if (DMA >= 4 && left >= 2) dc_wait_vm<2 * PPW>();
-                  else if (DMA >= 3 && left == 1) dc_wait_vm<PPW>();
+                  int lastq = it + DMA - 1;  // youngest tile requested so far (this tile's own requests precede this point)
+                  if (lastq > T_ - 1) lastq = T_ - 1;
+                  int npro = (PRO - 1 < lastq ? PRO - 1 : lastq) - (it + 1);  // younger prologue tiles: NA pieces each
+                  if (npro < 0) npro = 0;
+                  int nloop = lastq - (it + 1 > PRO - 1 ? it + 1 : PRO - 1);  // younger loop tiles: PPW pieces each
+                  if (nloop < 0) nloop = 0;
+                  if (DMA >= 4 && nloop == 2) dc_wait_vm<2 * PPW>();
+                  else if (DMA >= 4 && nloop == 1 && npro == 1) dc_wait_vm<NA + PPW>();
+                  else if (DMA >= 3 && nloop == 1) dc_wait_vm<PPW>();
+                  else if (DMA >= 4 && npro == 2) dc_wait_vm<2 * NA>();
+                  else if (DMA >= 3 && npro == 1) dc_wait_vm<NA>();
                   else dc_wait_vm<0>();
                 }
+#if defined(DC_ABL) && (DC_ABL & 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
                 dc_lds_barrier();
+#endif
               } else {
+#if !(defined(DC_ABL) && (DC_ABL & 4))
                 frag_one(sbn, 0, 0, i - 1);
+#endif
               }
             } else if (i < n_sync + n_rd) {
+#if !(defined(DC_ABL) && (DC_ABL & 4))
               frag_one(sb, q + 1, cur ^ 1, i - n_sync);
+#endif
             } else {
+#if !(defined(DC_ABL) && (DC_ABL & 1))
               dma_piece(sbp, pc_lo + (i - n_sync - n_rd));
+#endif
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -644,6 +686,10 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       sb = sbn;
     };
     int it = 0;
+    if (PRO == DMA && T_ > 1) {  // the prologue filled the whole ring: tile 0 has nothing to request
+      tile(std::true_type{}, std::false_type{}, 0);
+      it = 1;
+    }
     for (; it < T_ - (DMA - 1); ++it) tile(std::true_type{}, std::true_type{}, it);
     for (; it < T_ - 1; ++it) tile(std::true_type{}, std::false_type{}, it);
     if constexpr (RD_OK) {
@@ -805,42 +851,67 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
             }
           }
         }
+        // float16: the shortcut add reads its half straight from the packed register (v_fma_mix_f32: one instruction instead of a
+        // conversion and an add — the same exactly rounded sum), two results are rounded and packed by one v_cvt_pk_f16_f32 and the
+        // ReLU is a v_pk_max_f16 on the packed pair (rounding is monotonic and 0 / -inf are exact: max-then-round == round-then-max):
+        // 28 VALU instructions per 16-byte vector with a shortcut, 20 without, instead of 48 — with three workgroups per CU
+        // in their epilogues at once this phase is bound by VALU issue.
+        auto emit = [&](auto res_tag) {
+          constexpr bool HAS_RES = decltype(res_tag)::value;
+          const _Float16 rl = p.relu ? (_Float16)0.f : (_Float16)(-__builtin_inff());
+          const f16x2 rl2 = {rl, rl};
 #pragma unroll
-        for (int b = 0; b < FN; ++b)
+          for (int b = 0; b < FN; ++b)
 #pragma unroll
-          for (int j = 0; j < NV; ++j) {
-            const int g0 = MYK * NG + (ES == 4 ? j : 2 * j);
-            if constexpr (ES == 4) {
-              const int cb = wc * TN + b * 32 + 8 * g0 + 4 * h;
-              const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + cb), h4 = *reinterpret_cast<const f32x4*>(shl + cb);
+            for (int j = 0; j < NV; ++j) {
+              const int g0 = MYK * NG + (ES == 4 ? j : 2 * j);
+              if constexpr (ES == 4) {
+                const int cb = wc * TN + b * 32 + 8 * g0 + 4 * h;
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(scl + cb), h4 = *reinterpret_cast<const f32x4*>(shl + cb);
 #pragma unroll
-              for (int a = 0; a < FM; ++a) {
-                f32x4 o;
+                for (int a = 0; a < FM; ++a) {
+                  f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[a][b][4 * g0 + e] * s4[e] + h4[e] + rv[a][b][j][e], relu_lo);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
-              }
-            } else {
-              const int cb0 = wc * TN + b * 32 + 8 * g0 + 4 * h, cb1 = cb0 + 8;
-              const f32x4 s0 = *reinterpret_cast<const f32x4*>(scl + cb0), h0 = *reinterpret_cast<const f32x4*>(shl + cb0);
-              const f32x4 s1 = *reinterpret_cast<const f32x4*>(scl + cb1), h1 = *reinterpret_cast<const f32x4*>(shl + cb1);
-#pragma unroll
-              for (int a = 0; a < FM; ++a) {
-                float lo[4], hi[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  lo[e] = acc[a][b][4 * g0 + e] * s0[e] + h0[e];
-                  hi[e] = acc[a][b][4 * g0 + 4 + e] * s1[e] + h1[e];
+                  for (int e = 0; e < 4; ++e) {
+                    float v = acc[a][b][4 * g0 + e] * s4[e] + h4[e];
+                    if (HAS_RES) v += rv[a][b][j][e];
+                    o[e] = fmaxf(v, relu_lo);
+                  }
+                  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
                 }
-                dc_permlane32_swap4(lo, hi);
-                const f16x8 rz = __builtin_bit_cast(f16x8, rv[a][b][j]);
-                f16x8 o;
+              } else {
+                const int cb0 = wc * TN + b * 32 + 8 * g0 + 4 * h, cb1 = cb0 + 8;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(scl + cb0), h0 = *reinterpret_cast<const f32x4*>(shl + cb0);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(scl + cb1), h1 = *reinterpret_cast<const f32x4*>(shl + cb1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf((e < 4 ? lo[e] : hi[e - 4]) + (float)rz[e], relu_lo);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
+                for (int a = 0; a < FM; ++a) {
+                  float lo[4], hi[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    lo[e] = acc[a][b][4 * g0 + e] * s0[e] + h0[e];
+                    hi[e] = acc[a][b][4 * g0 + 4 + e] * s1[e] + h1[e];
+                  }
+                  dc_permlane32_swap4(lo, hi);
+                  const u32x4 rz = __builtin_bit_cast(u32x4, rv[a][b][j]);
+                  u32x4 o;
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    float x0 = i < 2 ? lo[2 * i] : hi[2 * i - 4], x1 = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+                    if (HAS_RES) {
+                      x0 = dc_add_half_lo(rz[i], x0);
+                      x1 = dc_add_half_hi(rz[i], x1);
+                    }
+                    const f32x2 xp = {x0, x1};
+                    const f16x2 hp = __builtin_elementwise_max(__builtin_convertvector(xp, f16x2), rl2);
+                    o[i] = __builtin_bit_cast(unsigned, hp);
+                  }
+                  __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[a][b][j], 0, 0);
+                }
               }
             }
-          }
+        };
+        if (p.resid) emit(std::true_type{});
+        else emit(std::false_type{});
       } else {
         // element-wise form (odd channel counts, sigmoid heads, unaligned views, split-K 4 in float16)
 #pragma unroll
@@ -1287,7 +1358,6 @@ constexpr int WRH = 2 * WBTY + 2, WRW = 2 * WBTX + 2;   // staged pixels: 10 x 1
 constexpr int WPSTR = WKC + 4;                           // floats per staged pixel (2*PSTR = 8 mod 64 banks)
 constexpr int WNTH = 512;
 constexpr int WNLD = (WRH * WRW * (WKC / 4) + WNTH - 1) / WNTH;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int wino_rowbase(int row) { return row * WRW * WPSTR + 4 * ((row >> 1) & 1); }
 __device__ __forceinline__ f32x2 wlo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }

@@ -13,6 +13,8 @@
 #   libs   <tag> name... [-- bench args]  interleaved A/B of library builds tools/probes/bin/lib_<name>.so vs the in-tree one
 #   sweep  <tag> streams|coalesce|queues  forwards in flight / cross-request batching / hardware-queue sweeps
 #   pmc    <tag> [bench args]             FETCH_SIZE and WRITE_SIZE passes (separate runs) -> HBM bytes per launch and per shape
+#   tiles  <tag> set... [-- bench args]   tune-cache overrides under load: a set is `key-prefix=tile[,key-prefix=tile...]` (key as in the
+#                                         cache file, e.g. h12512/256/2304=d128x256x64_w241_s3); `base` = the seeded cache as is
 #
 # TUNE=<file> seeds the tune cache (default: the newest profiles/r*_tune_cache.txt); TUNE=none tunes from scratch.
 set -u
@@ -74,6 +76,26 @@ ab)
   for rep in 1 2 3; do for v in $V0 $V1; do
     env $VAR=$v timeout 300 python bench.py $QUIET --steps 100 --warmup 10 "$@" > $OUT/$VAR$v.json 2> $OUT/$VAR$v.err
     line "$VAR=$v" $OUT/$VAR$v.json
+  done; done ;;
+tiles)
+  seed_cache; cp $OUT/tune_cache.txt $OUT/base_cache.txt
+  sets=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do sets+=("$1"); shift; done; [ $# -gt 0 ] && shift
+  for rep in 1 2; do for st in base "${sets[@]}"; do
+    python - $OUT/base_cache.txt $OUT/tune_cache.txt "$st" <<'PY'
+import sys
+src, dst, st = sys.argv[1:4]
+over = [] if st == "base" else [kv.split("=") for kv in st.split(",")]
+out = []
+for l in open(src):
+    k = l.split()[0] if l.split() else ""
+    for pre, tile in over:
+        if k.startswith(pre):
+            l = "%s %s\n" % (k, tile)
+    out.append(l)
+open(dst, "w").writelines(out)
+PY
+    timeout 300 python bench.py $QUIET --steps 30 --warmup 4 "$@" > $OUT/t.json 2> $OUT/t.err
+    line "$st" $OUT/t.json
   done; done ;;
 libs)
   names=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do names+=("$1"); shift; done; [ $# -gt 0 ] && shift
