@@ -120,7 +120,7 @@ def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
     return None, None
 
 
-def config2_f16_line(caffe, layers, depth, steps, dev, inject):
+def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2):
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
     680x920), float16 operands with float32 accumulation, device-resident, one pyramid batch at a time.  A step = the
     four batch-8 forwards of one pyramid batch (32 forwards = 8 images); shapes come from the per-shape plan cache."""
@@ -137,9 +137,10 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject):
     for s in shapes:
         net.blobs["data"].reshape(8, 3, *s)
         flops += net.flops()
-    nets = [net, net.clone()]  # two executors (shared weights and tile choices): two batch-8 forwards in flight
-    nets[1].reserve(8, *shapes[-1])
-    streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev)]
+    nets = [net] + [net.clone() for _ in range(execs - 1)]  # executors (shared weights and tile choices): `execs` batch-8 forwards in flight
+    for n in nets[1:]:
+        n.reserve(8, *shapes[-1])
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in nets[1:]]
     outs = [{s: [torch.empty(8, c, s[0] // 8, s[1] // 8, device=dev) for c in (14, 28, 364)] for s in shapes} for _ in nets]
 
     def pyramid(inflight, k0=0):
@@ -149,11 +150,12 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject):
             nets[e].forward_device(xs[s].data_ptr(), 8, s[0], s[1], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), streams[e].cuda_stream)
 
     def timed(inflight):
-        for k in range(3):  # lower, tune and capture every shape on every executor it will meet there
+        for k in range(4):  # lower, tune and capture every shape on every executor it will meet there
             pyramid(inflight, k)
         torch.cuda.synchronize(dev)
         before = [n.stats() for n in nets]
-        streams[1].wait_stream(streams[0])
+        for st in streams[1:]:
+            st.wait_stream(streams[0])
         t0 = time.perf_counter()
         for k in range(steps):
             pyramid(inflight, k)  # the scales rotate over the executors
@@ -164,11 +166,11 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject):
             a["graph_instantiations"] - b["graph_instantiations"] for a, b in zip(after, before))
 
     dt1, relow1, inst1 = timed(1)
-    dt2, relow2, inst2 = timed(2)
+    dt2, relow2, inst2 = timed(execs)
     tf1, tf2 = steps * flops / dt1 / 1e12, steps * flops / dt2 / 1e12
     return {"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
-                        "accumulate (BASELINE configs[2]); value = two batch-8 forwards in flight on two executors",
-            "value": steps * 8 / dt2, "unit": "image-pyramids/s", "forwards_in_flight": 2, "forwards_per_s": steps * 32 / dt2, "steps": steps,
+                        "accumulate (BASELINE configs[2]); value = %d batch-8 forwards in flight on %d executors (the scales rotate over them)" % (execs, execs),
+            "value": steps * 8 / dt2, "unit": "image-pyramids/s", "forwards_in_flight": execs, "forwards_per_s": steps * 32 / dt2, "steps": steps,
             "ms_per_pyramid_batch": dt2 / steps * 1e3, "gflop_per_image_pyramid": flops / 8 / 1e9, "tflops": tf2,
             "roofline_frac_f16": tf2 / PEAK_FP16_MFMA_TFLOPS,
             "one_forward_at_a_time": {"value": steps * 8 / dt1, "unit": "image-pyramids/s", "ms_per_pyramid_batch": dt1 / steps * 1e3,
@@ -485,7 +487,8 @@ def main():
             beside("cross_request_batching", cross_request_batching)
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
             # the other single-GPU configuration of BASELINE.json, timed by the same run
-            beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights))
+            beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights,
+                                                          int(os.environ.get("DC_BENCH_F16_EXECS", "2"))))
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()
