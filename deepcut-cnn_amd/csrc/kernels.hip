@@ -176,9 +176,13 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
 #ifndef DC_PRO_FULL
 #define DC_PRO_FULL 1
 #endif
-  // LDS-DMA: tiles the prologue requests.  The whole ring (DMA) — not DMA-1 with the last stage filled during tile 0 — puts
-  // tile DMA-1 in flight a first-tile latency earlier; the steady state (tile it requests tile it+DMA-1) is the same.
-  constexpr int PRO = DMA ? (DC_PRO_FULL ? DMA : DMA - 1) : 0;
+  // LDS-DMA: the prologue requests the first DMA-1 tiles (all their filter pieces before the row decode, their activation pieces
+  // after it) and then — LATE — the whole of tile DMA-1, which the steady state (tile `it` requests tile it+DMA-1) would only ask for
+  // during tile 0: a first-tile latency earlier, without putting another tile's filter pieces in front of tile 0's activations
+  // (requested with the first filter pieces instead, it cost the float32 batch-1 forward 1.4 %).
+  // float16 only: the float32 batch-1 launches are one round of workgroups that all start together, and a deeper initial burst
+  // delays their first tile more than the earlier tile DMA-1 gives back (one forward at a time 335.8 -> 331.5 images/s).
+  constexpr bool LATE = DMA && DC_PRO_FULL && ES == 2;
   constexpr int TM = BM / WR, TN = BN / WC;
   constexpr int FM = TM / 32, FN = TN / 32;
   static_assert(FM >= 1 && FN >= 1 && TM % 32 == 0 && TN % 32 == 0, "wave tile = multiples of 32x32");
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   };
   if constexpr (DMA) {
 #pragma unroll
-    for (int k = 0; k < PRO; ++k)
+    for (int k = 0; k < DMA - 1; ++k)
       if (k < T_) dma_b(k);
   } else {
 #pragma unroll
@@ -457,16 +461,21 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       dc_dma16(wrs, ldsw + so + BM * LDB + (pc - NA) * RPP * LDB, bvoff[pc >= NA ? pc - NA : 0], d_kg);
   };
   if constexpr (DMA) {
-    // the filter pieces of the first PRO tiles are on their way already (dma_b advanced kg): only the activation pieces here
+    // the filter pieces of the first DMA-1 tiles are on their way already (dma_b advanced kg): only the activation pieces here
     const int kg_keep = kg;
 #pragma unroll
-    for (int k = 0; k < PRO; ++k)
+    for (int k = 0; k < DMA - 1; ++k)
       if (k < T_) {
         dma_next();
 #pragma unroll
         for (int i = 0; i < NA; ++i) dma_piece(k * TILEB, i);
       }
     kg = kg_keep;
+    if (LATE && T_ >= DMA) {  // tile DMA-1, whole (activation and filter pieces), into the last stage
+      dma_next();
+#pragma unroll
+      for (int pc = 0; pc < NA + NBV; ++pc) dma_piece((DMA - 1) * TILEB, pc);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
@@ -543,11 +552,17 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   // sweep the 256 MB Infinity Cache), so a single tile of lookahead does not cover their latency.
   if constexpr (DMA) {
     // tile 0 has landed when at most the later prologue tiles' activation pieces (requested after it) are outstanding
-    const int pt = T_ < PRO ? T_ : PRO;  // tiles requested so far
-    if (PRO >= 4 && pt >= 4) dc_wait_vm<3 * NA>();
-    else if (pt >= 3) dc_wait_vm<2 * NA>();
-    else if (pt == 2) dc_wait_vm<NA>();
-    else dc_wait_vm<0>();
+    // (the early tiles' activation pieces after tile 0's, NA each, and the late tile's NA + NBV)
+    const int pt = T_ < DMA - 1 ? T_ : DMA - 1;  // early tiles requested
+    if (LATE && T_ >= DMA) {
+      if (pt >= 3) dc_wait_vm<2 * NA + NA + NBV>();
+      else if (pt == 2) dc_wait_vm<NA + NA + NBV>();
+      else dc_wait_vm<NA + NBV>();
+    } else {
+      if (pt >= 3) dc_wait_vm<2 * NA>();
+      else if (pt == 2) dc_wait_vm<NA>();
+      else dc_wait_vm<0>();
+    }
     if constexpr (SWP) {  // the constants were requested before every DMA piece: the wait above covers them
       if (t < 2 * BN) epi_sc[t] = epi_c;
     }
@@ -643,14 +658,15 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               if (i == 0) {
                 // tiles that may stay in flight: those after it+1 that exist, but never a prologue tile (the prologue requested
                 // all filter pieces before all activation pieces, so "the youngest n tiles" only means something for loop tiles)
-                if (moreD && it >= PRO - 1) {
+                if (moreD && it >= DMA - 1) {
                   dc_wait_vm<(DMA - 2) * PPW>();  // steady state: the DMA-2 tiles after it+1 are loop tiles
                 } else {
                   int lastq = it + DMA - 1;  // youngest tile requested so far (this tile's own requests precede this point)
                   if (lastq > T_ - 1) lastq = T_ - 1;
-                  int npro = (PRO - 1 < lastq ? PRO - 1 : lastq) - (it + 1);  // younger prologue tiles: NA pieces each
+                  const int nearly = T_ < DMA - 1 ? T_ : DMA - 1;  // early prologue tiles 0..nearly-1: what is younger than the
+                  int npro = (nearly - 1 < lastq ? nearly - 1 : lastq) - (it + 1);  // activation pieces of one of them is NA pieces per later one
                   if (npro < 0) npro = 0;
-                  int nloop = lastq - (it + 1 > PRO - 1 ? it + 1 : PRO - 1);  // younger loop tiles: PPW pieces each
+                  int nloop = lastq - (it + 1 > nearly - 1 ? it + 1 : nearly - 1);  // whole tiles (the late one, the loop's): PPW each
                   if (nloop < 0) nloop = 0;
                   if (DMA >= 4 && nloop == 2) dc_wait_vm<2 * PPW>();
                   else if (DMA >= 4 && nloop == 1 && npro == 1) dc_wait_vm<NA + PPW>();
@@ -686,7 +702,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       sb = sbn;
     };
     int it = 0;
-    if (PRO == DMA && T_ > 1) {  // the prologue filled the whole ring: tile 0 has nothing to request
+    if (LATE && T_ >= DMA) {  // the prologue filled the whole ring: tile 0 has nothing to request
       tile(std::true_type{}, std::false_type{}, 0);
       it = 1;
     }
