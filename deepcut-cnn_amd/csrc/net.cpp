@@ -1723,13 +1723,16 @@ void Net::autotune() {
   // launch of the signature, summed; best of 3 passes per candidate): measured on the float16 batch-8 forward, the isolated
   // timing took the 256x128 tile for the merged heads on two boxes of three where the 128-wide ones are 9 % faster in the
   // network.  (Like pass 1 this runs before the inputs of the forward are brought to the device: outputs are scratch here.)
-  if (timed_any && env_int("DC_TUNE_INSITU", 1) != 0) {
+  // Default: float32 only.  For the float16 batch-8 forward the in-situ choices are 1-2 % faster one forward at a time and 1.5-2.5 %
+  // slower with two forwards in flight (they lean to the one-workgroup-per-CU tiles, which leave the second forward no room).
+  if (timed_any && env_int("DC_TUNE_INSITU", dtype == 1 ? 0 : 1) != 0) {
     std::map<std::string, std::vector<int>> shortlist;
     size_t rounds = 0;
     for (auto& kv : timed) {
       std::vector<int> sl;
+      static const int max_cand = env_int("DC_TUNE_INSITU_MAX", 4), pct = env_int("DC_TUNE_INSITU_PCT", 12);  // experiment knobs
       for (auto& c : kv.second)
-        if (sl.size() < 4 && c.first <= kv.second.front().first * 1.12f) sl.push_back(c.second);
+        if ((int)sl.size() < max_cand && c.first <= kv.second.front().first * (1.f + 0.01f * pct)) sl.push_back(c.second);
       if (sl.size() >= 2) {
         rounds = std::max(rounds, sl.size());
         shortlist[kv.first] = sl;

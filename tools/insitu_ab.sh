@@ -1,10 +1,23 @@
-mkdir -p gpurun_out/i1
-for rep in 1 2; do for v in 0 1; do
-  rm -f gpurun_out/i1/tc_$v.txt
-  DC_TUNE_INSITU=$v DC_TUNE_CACHE=gpurun_out/i1/tc_$v.txt python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4 2>gpurun_out/i1/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f16 insitu=$v', round(d['value'],1), round(d['one_forward_at_a_time']['value'],1))"
-done; done
-for rep in 1 2; do for v in 0 1; do
-  rm -f gpurun_out/i1/tc32_$v.txt
-  DC_TUNE_INSITU=$v DC_TUNE_CACHE=gpurun_out/i1/tc32_$v.txt python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --steps 60 --warmup 5 2>>gpurun_out/i1/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f32 insitu=$v', round(d['value'],1), round(d['one_forward_at_a_time']['value'],1))"
-done; done
-diff gpurun_out/i1/tc_0.txt gpurun_out/i1/tc_1.txt | head -20
+#!/bin/bash
+# ON THE GPU BOX: tile tuning from scratch with and without the in-situ pass (and with wider shortlists), interleaved:
+#   gpurun -- 'bash tools/insitu_ab.sh [f16|f32|both]'
+mkdir -p gpurun_out/insitu
+W=${1:-both}
+run() {  # run <label> <bench args...>  (environment of the caller)
+  local label=$1; shift
+  rm -f gpurun_out/insitu/tc.txt
+  DC_TUNE_CACHE=gpurun_out/insitu/tc.txt python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 "$@" 2>>gpurun_out/insitu/err.txt |
+    python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s value %7.1f  one at a time %7.1f' % ('$label', d['value'], d['one_forward_at_a_time']['value']))"
+}
+for rep in 1 2; do
+  if [ $W != f32 ]; then
+    DC_TUNE_INSITU=0 run "f16 b8  pass 1 only" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
+    run "f16 b8  in situ 12%/4" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
+    DC_TUNE_INSITU_PCT=25 DC_TUNE_INSITU_MAX=6 run "f16 b8  in situ 25%/6" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
+  fi
+  if [ $W != f16 ]; then
+    DC_TUNE_INSITU=0 run "f32 b1  pass 1 only" --steps 60 --warmup 5
+    run "f32 b1  in situ 12%/4" --steps 60 --warmup 5
+    DC_TUNE_INSITU_PCT=25 DC_TUNE_INSITU_MAX=6 run "f32 b1  in situ 25%/6" --steps 60 --warmup 5
+  fi
+done
