@@ -198,6 +198,8 @@ def main():
                     help="device element type: f32 (the headline, BASELINE configs[1]) or f16 operands with fp32 "
                          "accumulation (BASELINE configs[2])")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-tune-in-flight", action="store_true",
+                    help="keep the latency-tuned tiles for the in-flight region too (default: deepcut_tools.tune_in_flight between the regions)")
     ap.add_argument("--breakdown", default="", help="write the per-launch hipEvent table to this file")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "0")),
                     help="independent batch-B forwards kept in flight per GPU (each on its own HIP stream and Net)")
@@ -277,18 +279,22 @@ def main():
     comm = torch.cuda.Stream(dev) if world > 1 else None
     sent = [None] * S  # per in-flight slot: event on `comm` after which outs[k] / recvs[k] may be reused
 
-    def step(i, nstreams):
-        # asynchronous on stream i % nstreams; inputs and outputs stay in HBM
-        k = i % nstreams
+    def forward_slot(k):
         st, out, x = streams[k], outs[k], xs[k]
-        if world > 1 and sent[k] is not None:
-            st.wait_event(sent[k])  # the previous payload of this slot has left
         if half:
             nets[k].forward_device(x.data_ptr(), B, H, W, None, None, None, st.cuda_stream)
             nets[k].emit_maps_device(out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(), half=True, stream=st.cuda_stream)
         else:
             nets[k].forward_device(x.data_ptr(), B, H, W, out[:a].data_ptr(), out[a:b].data_ptr(), out[b:].data_ptr(),
                                    st.cuda_stream)
+
+    def step(i, nstreams):
+        # asynchronous on stream i % nstreams; inputs and outputs stay in HBM
+        k = i % nstreams
+        st, out, x = streams[k], outs[k], xs[k]
+        if world > 1 and sent[k] is not None:
+            st.wait_event(sent[k])  # the previous payload of this slot has left
+        forward_slot(k)
         if world > 1:
             if args.backend == "nccl":
                 done = torch.cuda.Event()
@@ -335,7 +341,24 @@ def main():
 
     # (1) one forward at a time: per-kernel durations are undisturbed -> the roofline figure
     lat_dt, lat_ev_ms = timed_region(1, args.steps, args.warmup)
-    # (2) the reported throughput: S independent batch-B forwards in flight (S streams, S Nets)
+    # (2) the reported throughput: S independent batch-B forwards in flight (S streams, S Nets).  The tiles region (1) ran with were
+    # chosen for the latency of one forward; a service that keeps S forwards in flight tunes for THAT load (untimed, like the
+    # autotuning inside the warm-up): deepcut_tools.tune_in_flight, coordinate descent over the busiest GEMM signatures.
+    tuning = None
+    if S > 1 and not args.no_tune_in_flight:
+        from deepcut_tools import tune_in_flight
+
+        def load():
+            t0 = time.perf_counter()
+            for i in range(6 * S):
+                forward_slot(i % S)  # the forwards of a step without its gather (rank-local: no collective inside the tuner)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        try:
+            tuning = tune_in_flight(nets, load)
+        except Exception as e:  # noqa: BLE001  (the line is printed whatever happens here)
+            tuning = {"error": "%s: %s" % (type(e).__name__, e)}
     if S > 1:
         dt, ev_ms = timed_region(S, args.steps, args.warmup)
     else:
@@ -378,6 +401,9 @@ def main():
                 "launches_per_forward": launches,
                 "hipgraph": not args.no_graph,
                 "forwards_in_flight": S,
+                "tile_tuning": ("in flight (deepcut_tools.tune_in_flight: %d signatures re-tiled, %.2f -> %.2f ms per %d forwards, %d untimed runs)"
+                                % (len(tuning["changed"]), tuning["before"] * 1e3, tuning["after"] * 1e3, 6 * S, tuning["runs"])
+                                if tuning and "error" not in tuning else ("latency" if not tuning else tuning["error"])),
                 "parallelism": "dp%d (images sharded, maps gathered to rank 0 by RCCL send/recv)" % world if world > 1 else "single GPU",
             },
             "tflops": total_images * flops_img / dt / 1e12,

@@ -492,6 +492,19 @@ const char* dc_net_debug_info(dc_net* net) {
   return rc == DC_OK ? n->text_buf.c_str() : nullptr;
 }
 
+const char* dc_net_tune_report(dc_net* net) {
+  if (!net) return nullptr;
+  Net* n = N(net);
+  int rc = guard([&] { n->text_buf = n->tune_report_text(); });
+  return rc == DC_OK ? n->text_buf.c_str() : nullptr;
+}
+int dc_net_set_tile(dc_net* net, const char* signature, const char* tile) {
+  REQUIRE(net);
+  REQUIRE(signature);
+  REQUIRE(tile);
+  return guard([&] { N(net)->set_tile(signature, tile); });
+}
+
 // tile variants of the gather-GEMM (diagnostics / tests: DC_CONV_VARIANT takes an index into this table)
 int dc_conv_variant_count(void) { return dc::conv_num_variants(); }
 const char* dc_conv_variant_name(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant(i).name : nullptr; }

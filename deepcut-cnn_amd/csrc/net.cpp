@@ -1665,20 +1665,7 @@ void Net::autotune() {
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
   const int reps = 5;
-  auto key_of = [&](const Launch& l) {
-    const ConvGemmParams& g = l.cg;
-    char key[200];
-    // "+w": the Winograd form competes for this layer (a different candidate set than with DC_WINOGRAD=0);
-    // "+mcN:K..": a multi-class launch (N classes with these K)
-    std::string mck;
-    if (g.ncls > 1) {
-      mck = "+mc" + std::to_string(g.ncls);
-      for (int c = 0; c < g.ncls; ++c) mck += ":" + std::to_string(g.cls[c].Ktot) + "m" + std::to_string(g.cls[c].M);
-    }
-    std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty,
-                  g.ntx, g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w ? "+w" : "", mck.c_str());
-    return std::string(key);
-  };
+  auto key_of = [&](const Launch& l) { return tune_key(l); };
   auto burst_ms = [&](const Launch& trial) {  // best of two timed bursts: a single burst is noisy at 10-20 us per launch
     run_launch(trial, stream);  // warm
     float ms = 1e30f;
@@ -1716,6 +1703,7 @@ void Net::autotune() {
     }
     std::sort(c.begin(), c.end());
     tune_cache_[key] = c.empty() ? l.variant : c.front().second;
+    shared->tune_timings[key] = c;
   }
   // (2) in situ: a launch timed alone re-reads warm filters and starts on an idle chip; inside a forward it follows another
   // kernel's tail and finds its filters wherever the 263 MB sweep of the forward left them.  The candidates within 12 % of a
@@ -1815,6 +1803,88 @@ void Net::autotune() {
         std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
       std::fclose(f);
     }
+  }
+  release_graph();
+}
+
+// GEMM signature of a launch: the key of the tile choice ("h" prefix: float16; "+w": the Winograd form competes for this layer —
+// a different candidate set than with DC_WINOGRAD=0 —; "+mcN:K..": a multi-class launch, N classes with these K and M)
+std::string Net::tune_key(const Launch& l) const {
+  const ConvGemmParams& g = l.cg;
+  char key[200];
+  std::string mck;
+  if (g.ncls > 1) {
+    mck = "+mc" + std::to_string(g.ncls);
+    for (int c = 0; c < g.ncls; ++c) mck += ":" + std::to_string(g.cls[c].Ktot) + "m" + std::to_string(g.cls[c].M);
+  }
+  std::snprintf(key, sizeof key, "%s%d/%d/%d/%d/%dx%d/%d,%d/%d/%d%s%s", g.esize == 2 ? "h" : "", g.M, g.Cout, g.Ktot, g.klen, g.nty, g.ntx,
+                g.sy, g.sx, l.in2 >= 0 ? 1 : 0, g.OW, l.wino_w ? "+w" : "", mck.c_str());
+  return key;
+}
+
+// One line per GEMM signature of the current plan, in plan order:
+//   <signature> \t <tile in use> \t <launches with it> \t <tile>:<us per launch, timed alone> ...   (fastest first; empty if the
+// choice came from a DC_TUNE_CACHE file).  What deepcut_tools.tune_in_flight walks.
+std::string Net::tune_report_text() {
+  std::lock_guard<std::mutex> lk(shared->mu);
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<int, int>> seen;  // key -> (variant in use, launches)
+  for (auto& l : plan) {
+    if (l.kind != Launch::CONV) continue;
+    const std::string k = tune_key(l);
+    auto it = seen.find(k);
+    if (it == seen.end()) order.push_back(k), seen[k] = {l.variant, 1};
+    else ++it->second.second;
+  }
+  auto vname = [](int v) { return std::string(v == kWinoVariant ? "wino_f23" : conv_variant(v).name); };
+  std::string out;
+  for (auto& k : order) {
+    out += k + "\t" + vname(seen[k].first) + "\t" + std::to_string(seen[k].second) + "\t";
+    auto t = shared->tune_timings.find(k);
+    if (t != shared->tune_timings.end())
+      for (size_t i = 0; i < t->second.size(); ++i) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "%s%s:%.2f", i ? " " : "", vname(t->second[i].second).c_str(), t->second[i].first * 1000.f / 5.f);
+        out += buf;
+      }
+    out += "\n";
+  }
+  return out;
+}
+
+// The tile of one signature, chosen by the caller (a tuner working under its own load): checked against every launch of the
+// current plan that has the signature, recorded in the shared choice table (clones pick it up at their next lowering; call
+// set_tile on each executor to change their current plans), and the captured graph is dropped.
+void Net::set_tile(const std::string& key, const std::string& tile) {
+  int v = -1;
+  if (tile == "wino_f23") v = kWinoVariant;
+  for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
+    if (tile == conv_variant(i).name) v = i;
+  if (v < 0) throw DcError(DC_EINVAL, "no tile variant named '" + tile + "'");
+  bool any = false;
+  for (auto& l : plan) {
+    if (l.kind != Launch::CONV || tune_key(l) != key) continue;
+    const ConvGemmParams& g = l.cg;
+    const bool ok = v == kWinoVariant ? (bool)l.wino_w && g.ncls <= 1
+                                      : g.klen % conv_variant_bk(v) == 0 && conv_variant_esize(v) == g.esize && (g.ncls <= 1 || conv_variant_multiclass(v));
+    if (!ok) throw DcError(DC_EUNSUP, "tile '" + tile + "' cannot take launch '" + l.label + "' (" + key + ")");
+    any = true;
+  }
+  if (!any) throw DcError(DC_EINVAL, "the current plan has no launch with signature '" + key + "'");
+  for (auto& l : plan) {
+    if (l.kind != Launch::CONV || tune_key(l) != key) continue;
+    l.variant = v;
+    if (v == kWinoVariant) {
+      l.kernel = "wino_f23<4x8x16>";
+      l.grid = wino_grid(l.cg);
+    } else {
+      l.kernel = std::string("conv_gemm<") + conv_variant(v).name + ">";
+      l.grid = conv_grid(l.cg, v);
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(shared->mu);
+    shared->tune_cache[key] = v;
   }
   release_graph();
 }

@@ -134,6 +134,7 @@ struct ModelShared {
                                                 // in pycaffe, _caffe.cpp:273: a read must not cost a 263 MB re-pack)
   std::map<std::string, int> tune_cache;        // GEMM signature -> fastest variant, one timing per process and model
   bool tune_file_loaded = false;
+  std::map<std::string, std::vector<std::pair<float, int>>> tune_timings;  // signature -> (ms of a 5-launch burst, variant), sorted: pass 1 of autotune
 };
 
 struct ResampleTable {  // Pillow-style 8-bit bilinear resample of one axis: taps and 22-bit weights, on the device
@@ -267,6 +268,8 @@ struct Net {
   void decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out);
   std::string plan_text();
   std::string profile_text(int iters);
+  std::string tune_report_text();  // per GEMM signature of the current plan: tile in use, launches, the isolated timings of autotune
+  void set_tile(const std::string& key, const std::string& tile);  // override the tile of one signature (tuning under the caller's own load)
   std::string debug_info_text();  // Net::ForwardDebugInfo (net.cpp:648-681): mean |x| of every top / parameter blob
   int layer_index(const std::string& name) const;
 
@@ -283,6 +286,7 @@ struct Net {
   void check_weights();   // compare the shared weight generation / touched parameters with what the plans were built from
   void park_current();
   void autotune();
+  std::string tune_key(const Launch& l) const;
   Storage& begin_batch(int n, int h, int w);
   void enqueue_plan(void* s);
   void emit_maps(void* prob, void* loc, void* next, bool is_device, void* s, int dst_esize = 4);

@@ -108,6 +108,8 @@ def _load():
         "dc_net_reserve": (ci, [vp, ci, ci, ci]),
         "dc_net_device": (ci, [vp]),
         "dc_net_debug_info": (cp, [vp]),
+        "dc_net_tune_report": (cp, [vp]),
+        "dc_net_set_tile": (ci, [vp, cp, cp]),
         "dc_conv_variant_count": (ci, []),
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
@@ -525,6 +527,24 @@ class Net(object):
         if t is None:
             raise DeepcutError(-1, (_lib.dc_last_error() or b"").decode())
         return t.decode()
+
+    def tune_report(self):
+        """Tile choices of the current shape: [{signature, tile, launches, timed: [(tile, us alone), ...]}] in plan order."""
+        t = _lib.dc_net_tune_report(self._h)
+        if t is None:
+            raise DeepcutError(-1, (_lib.dc_last_error() or b"").decode())
+        out = []
+        for ln in t.decode().splitlines():
+            f = ln.split("\t")
+            if len(f) < 3:
+                continue
+            timed = [(c.rsplit(":", 1)[0], float(c.rsplit(":", 1)[1])) for c in (f[3].split() if len(f) > 3 else [])]
+            out.append({"signature": f[0], "tile": f[1], "launches": int(f[2]), "timed": timed})
+        return out
+
+    def set_tile(self, signature, tile):
+        """Override the tile of one GEMM signature in this executor's current plan (and the table shared with its clones)."""
+        _check(_lib.dc_net_set_tile(self._h, signature.encode(), tile.encode()))
 
     def plan_text(self):
         t = _lib.dc_net_plan_text(self._h)

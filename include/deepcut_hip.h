@@ -264,6 +264,14 @@ const char* dc_net_profile_text(dc_net* net, int iters);
  * blob is materialised (fused blobs are reported as elided otherwise).  NULL + dc_last_error() on failure;
  * pointer valid until the next call on this net.                                                                   */
 const char* dc_net_debug_info(dc_net* net);
+/* Tile choices of the current shape, for a tuner that works under the caller's own load (deepcut_tools.tune_in_flight): one line
+ * per GEMM signature of the plan, "<signature>\t<tile in use>\t<launches>\t<tile>:<us timed alone> ..." (fastest first; the
+ * signature is the key DC_TUNE_CACHE files use).  dc_net_set_tile overrides the tile of one signature in this executor's
+ * current plan and in the choice table it shares with its clones; the captured graph is dropped (re-captured by the next
+ * forward).  DC_EUNSUP if the tile cannot take a launch of the signature.  No reference counterpart: the reference has one
+ * SGEMM per layer (math_functions.cu:13-27).                                                                            */
+const char* dc_net_tune_report(dc_net* net);
+int dc_net_set_tile(dc_net* net, const char* signature, const char* tile);
 /* the gather-GEMM's tile-variant table (csrc/kernels.hip): number of entries, name and element size (4 float / 2 half) of
  * entry i — what the environment switch DC_CONV_VARIANT=<i> forces and the names dc_net_plan_text / DC_TUNE_CACHE use.
  * No reference counterpart: the reference has one SGEMM (math_functions.cu:13-27); diagnostics only.                  */
