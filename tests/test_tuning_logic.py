@@ -1,0 +1,72 @@
+"""CPU: the coordinate descent of deepcut_tools.tune_in_flight on fake executors — which signatures it visits, which tiles it
+tries, when it keeps one (the GPU side, dc_net_tune_report / dc_net_set_tile, is tests/test_gpu_tuning.py)."""
+from deepcut_tools import tune_in_flight
+
+
+class FakeNet(object):
+    def __init__(self, report, log):
+        self.report = [dict(r, timed=list(r["timed"])) for r in report]
+        self.log = log
+
+    def tune_report(self):
+        return [dict(r) for r in self.report]
+
+    def set_tile(self, signature, tile):
+        for r in self.report:
+            if r["signature"] == signature:
+                assert tile in [t for t, _ in r["timed"]]
+                r["tile"] = tile
+                self.log.append((signature, tile))
+                return
+        raise KeyError(signature)
+
+
+REPORT = [
+    {"signature": "busy", "tile": "a", "launches": 36, "timed": [("a", 10.0), ("b", 10.5), ("c", 11.9), ("d", 30.0)]},
+    {"signature": "small", "tile": "a", "launches": 1, "timed": [("a", 5.0), ("b", 5.1)]},
+    {"signature": "cached", "tile": "z", "launches": 50, "timed": []},          # from a cache file: nothing to walk
+    {"signature": "single", "tile": "a", "launches": 40, "timed": [("a", 9.0)]},  # one candidate only
+    {"signature": "mid", "tile": "b", "launches": 10, "timed": [("a", 20.0), ("b", 20.2)]},
+]
+# seconds of the load as a function of the tiles in place: "b" is the in-flight winner for `busy`, "a" (alone-best) for `mid`
+COST = {"busy": {"a": 1.00, "b": 0.90, "c": 0.95, "d": 0.50}, "small": {"a": 0.010, "b": 0.0099}, "mid": {"a": 0.30, "b": 0.33}}
+
+
+def _setup():
+    log = []
+    nets = [FakeNet(REPORT, log), FakeNet(REPORT, log)]
+    calls = [0]
+
+    def load():
+        calls[0] += 1
+        return sum(COST[r["signature"]][r["tile"]] for r in nets[0].report if r["signature"] in COST) + 1.0
+
+    return nets, load, log, calls
+
+
+def test_descent_keeps_only_real_gains_on_every_executor():
+    nets, load, log, calls = _setup()
+    res = tune_in_flight(nets, load, top=10, margin=1.20, min_gain=0.004, reps=2)
+    final = {r["signature"]: r["tile"] for r in nets[0].report}
+    assert final == {r["signature"]: r["tile"] for r in nets[1].report}  # every executor carries the same choices
+    assert final["busy"] == "b"       # 10 % better under load although 5 % slower alone
+    assert final["mid"] == "a"        # the alone-best also wins under load
+    assert final["small"] == "a"      # 0.004 % of the load: below min_gain, the incumbent stays
+    assert final["cached"] == "z" and final["single"] == "a"
+    assert ("busy", "d") not in log   # 3x slower alone: outside the margin, never tried (although it would have won)
+    assert [c[0] for c in res["changed"]] == ["busy", "mid"]  # busiest first: 36 x 10 us, then 10 x 20.2 us
+    assert abs(res["before"] - (1.0 + 1.00 + 0.010 + 0.33)) < 1e-9 and abs(res["after"] - (1.0 + 0.90 + 0.010 + 0.30)) < 1e-9
+    assert res["runs"] == calls[0]
+
+
+def test_top_limits_the_signatures_walked():
+    nets, load, log, _ = _setup()
+    res = tune_in_flight(nets, load, top=1, reps=1)
+    assert set(s for s, _ in log) == {"busy"} and len(res["changed"]) == 1
+
+
+def test_nothing_to_tune_is_not_an_error():
+    log = []
+    nets = [FakeNet([REPORT[2], REPORT[3]], log)]
+    res = tune_in_flight(nets, lambda: 1.0)
+    assert res["changed"] == [] and log == [] and res["before"] == res["after"] == 1.0
