@@ -120,7 +120,7 @@ def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
     return None, None
 
 
-def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2):
+def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=True):
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
     680x920), float16 operands with float32 accumulation, device-resident, one pyramid batch at a time.  A step = the
     four batch-8 forwards of one pyramid batch (32 forwards = 8 images); shapes come from the per-shape plan cache."""
@@ -166,11 +166,30 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2):
             a["graph_instantiations"] - b["graph_instantiations"] for a, b in zip(after, before))
 
     dt1, relow1, inst1 = timed(1)
+    # between the regions: the tiles of every scale re-tuned for `execs` forwards in flight (untimed; deepcut_tools.tune_in_flight)
+    retiled = None
+    if execs > 1 and tune:
+        from deepcut_tools import tune_in_flight
+
+        retiled = 0
+        for s in shapes:
+            def load(s=s):
+                t0 = time.perf_counter()
+                for r in range(3 * execs):
+                    e = r % execs
+                    o = outs[e][s]
+                    nets[e].forward_device(xs[s].data_ptr(), 8, s[0], s[1], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), streams[e].cuda_stream)
+                torch.cuda.synchronize(dev)
+                return time.perf_counter() - t0
+
+            load()  # every executor at this scale: the report and the overrides address its current plan
+            retiled += len(tune_in_flight(nets[:execs], load, top=8)["changed"])
     dt2, relow2, inst2 = timed(execs)
     tf1, tf2 = steps * flops / dt1 / 1e12, steps * flops / dt2 / 1e12
     return {"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
                         "accumulate (BASELINE configs[2]); value = %d batch-8 forwards in flight on %d executors (the scales rotate over them)" % (execs, execs),
-            "value": steps * 8 / dt2, "unit": "image-pyramids/s", "forwards_in_flight": execs, "forwards_per_s": steps * 32 / dt2, "steps": steps,
+            "value": steps * 8 / dt2, "unit": "image-pyramids/s", "forwards_in_flight": execs,
+            "tile_tuning": "latency" if retiled is None else "in flight (%d signatures re-tiled over the four scales)" % retiled, "forwards_per_s": steps * 32 / dt2, "steps": steps,
             "ms_per_pyramid_batch": dt2 / steps * 1e3, "gflop_per_image_pyramid": flops / 8 / 1e9, "tflops": tf2,
             "roofline_frac_f16": tf2 / PEAK_FP16_MFMA_TFLOPS,
             "one_forward_at_a_time": {"value": steps * 8 / dt1, "unit": "image-pyramids/s", "ms_per_pyramid_batch": dt1 / steps * 1e3,
@@ -514,7 +533,7 @@ def main():
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
             # the other single-GPU configuration of BASELINE.json, timed by the same run
             beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights,
-                                                          int(os.environ.get("DC_BENCH_F16_EXECS", "2"))))
+                                                          int(os.environ.get("DC_BENCH_F16_EXECS", "2")), not args.no_tune_in_flight))
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()
