@@ -82,3 +82,26 @@ class Pipeline(object):
         tags = list(self._done)
         self._done.clear()
         return tags
+
+    def tune(self, requests, rounds=4, **kw):
+        """Re-tune the tiles of the requests' shape for THIS pipeline's load (depth executors, this coalescing): the
+        autotuner chose them for one forward alone.  `requests`: a list of submit() argument tuples (in_ptr, n, h, w,
+        prob_ptr, loc_ptr, next_ptr) of one shape, at least depth * coalesce of them, whose buffers may be overwritten; the
+        burst is replayed `rounds` times per measurement.  Returns what deepcut_tools.tune_in_flight returns."""
+        import time
+
+        from .tuning import tune_in_flight
+
+        if self._pending or self._held:
+            raise RuntimeError("tune() wants an idle pipeline")
+
+        def load():
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                for r in requests:
+                    self.submit(*r)
+            self.drain()
+            return time.perf_counter() - t0
+
+        load()  # every executor has lowered (and tuned, for latency) the shape
+        return tune_in_flight(self.nets, load, **kw)

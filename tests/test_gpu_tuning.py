@@ -96,3 +96,24 @@ def test_tune_in_flight_keeps_or_improves(gpu_caffe, synth152, monkeypatch):
     assert res["after"] <= res["before"] * 1.5 and res["runs"] >= 2
     net.forward()
     assert float(np.abs(net.blobs["prob"].data - ref).max()) <= 2e-4
+
+
+def test_pipeline_tune_runs_its_own_load(gpu_caffe, synth152, monkeypatch):
+    import torch
+
+    from deepcut_tools import Pipeline
+
+    monkeypatch.delenv("DC_TUNE_CACHE", raising=False)
+    net = _net(gpu_caffe, synth152)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(rand_image(11, H, W)).to(dev)
+    ref = net.blobs["prob"].data.copy()
+    pipe = Pipeline(net, depth=2)
+    outs = [[torch.empty(1, c, H // 8, W // 8, device=dev) for c in (14, 28, 364)] for _ in range(4)]
+    reqs = [(x.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()) for o in outs]
+    res = pipe.tune(reqs, rounds=2, top=3, reps=1)
+    assert res["runs"] >= 2 and res["after"] <= res["before"] * 1.5
+    pipe.submit(*reqs[0], tag="t")
+    assert pipe.drain() == ["t"]
+    torch.cuda.synchronize(dev)
+    assert float(np.abs(outs[0][0].cpu().numpy() - ref).max()) <= 2e-4
