@@ -1711,9 +1711,11 @@ void Net::autotune() {
   // launch of the signature, summed; best of 3 passes per candidate): measured on the float16 batch-8 forward, the isolated
   // timing took the 256x128 tile for the merged heads on two boxes of three where the 128-wide ones are 9 % faster in the
   // network.  (Like pass 1 this runs before the inputs of the forward are brought to the device: outputs are scratch here.)
-  // Default: float32 only.  For the float16 batch-8 forward the in-situ choices are 1-2 % faster one forward at a time and 1.5-2.5 %
-  // slower with two forwards in flight (they lean to the one-workgroup-per-CU tiles, which leave the second forward no room).
-  if (timed_any && env_int("DC_TUNE_INSITU", dtype == 1 ? 0 : 1) != 0) {
+  // These are latency choices: for the float16 batch-8 forward they are 1-3 % faster one forward at a time (the 4-scale pyramid:
+  // 535 -> 560 image-pyramids/s) and 1-2 % slower with two forwards in flight (they lean to the one-workgroup-per-CU tiles,
+  // which leave the second forward no room) — a service that keeps forwards in flight re-tunes for its load (set_tile,
+  // deepcut_tools.tune_in_flight).
+  if (timed_any && env_int("DC_TUNE_INSITU", 1) != 0) {
     std::map<std::string, std::vector<int>> shortlist;
     size_t rounds = 0;
     for (auto& kv : timed) {
