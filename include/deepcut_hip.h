@@ -268,7 +268,8 @@ const char* dc_net_debug_info(dc_net* net);
  * per GEMM signature of the plan, "<signature>\t<tile in use>\t<launches>\t<tile>:<us timed alone> ..." (fastest first; the
  * signature is the key DC_TUNE_CACHE files use).  dc_net_set_tile overrides the tile of one signature in this executor's
  * current plan and in the choice table it shares with its clones; the captured graph is dropped (re-captured by the next
- * forward).  DC_EUNSUP if the tile cannot take a launch of the signature.  No reference counterpart: the reference has one
+ * forward): call it while the executor is idle (nothing of it in flight on any stream).  DC_EUNSUP if the tile cannot take a
+ * launch of the signature.  No reference counterpart: the reference has one
  * SGEMM per layer (math_functions.cu:13-27).                                                                            */
 const char* dc_net_tune_report(dc_net* net);
 int dc_net_set_tile(dc_net* net, const char* signature, const char* tile);
