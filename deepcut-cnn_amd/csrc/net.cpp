@@ -1720,9 +1720,8 @@ void Net::autotune() {
     size_t rounds = 0;
     for (auto& kv : timed) {
       std::vector<int> sl;
-      static const int max_cand = env_int("DC_TUNE_INSITU_MAX", 4), pct = env_int("DC_TUNE_INSITU_PCT", 12);  // experiment knobs
-      for (auto& c : kv.second)
-        if ((int)sl.size() < max_cand && c.first <= kv.second.front().first * (1.f + 0.01f * pct)) sl.push_back(c.second);
+      for (auto& c : kv.second)  // (25 % / six candidates were tried: same choices, three times the passes)
+        if (sl.size() < 4 && c.first <= kv.second.front().first * 1.12f) sl.push_back(c.second);
       if (sl.size() >= 2) {
         rounds = std::max(rounds, sl.size());
         shortlist[kv.first] = sl;

@@ -14,11 +14,6 @@ def tune_in_flight(nets, run, top=10, margin=1.20, min_gain=0.004, reps=3, max_c
     """nets: the executors of ONE model (a net and its clones), all at the shape to tune, each having run a forward.
     run(): enqueue the representative load on the executors, synchronise, return the wall seconds.
     Returns {"before": s, "after": s, "changed": [(signature, old tile, new tile, seconds before, seconds after)], "runs": n}."""
-    import os
-
-    top = int(os.environ.get("DC_TUNE_TOP", top))  # experiment knobs
-    margin = float(os.environ.get("DC_TUNE_MARGIN", margin))
-    max_candidates = int(os.environ.get("DC_TUNE_MAXC", max_candidates))
     report = nets[0].tune_report()
     ranked = []
     for sig in report:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ON THE GPU BOX: tile tuning from scratch with and without the in-situ pass (and with wider shortlists), interleaved:
+# ON THE GPU BOX: tile tuning from scratch with and without the in-situ pass interleaved:
 #   gpurun -- 'bash tools/insitu_ab.sh [f16|f32|both]'
 mkdir -p gpurun_out/insitu
 W=${1:-both}
@@ -13,11 +13,9 @@ for rep in 1 2; do
   if [ $W != f32 ]; then
     DC_TUNE_INSITU=0 run "f16 b8  pass 1 only" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
     run "f16 b8  in situ 12%/4" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
-    DC_TUNE_INSITU_PCT=25 DC_TUNE_INSITU_MAX=6 run "f16 b8  in situ 25%/6" --dtype f16 --batch 8 --streams 2 --steps 30 --warmup 4
   fi
   if [ $W != f16 ]; then
     DC_TUNE_INSITU=0 run "f32 b1  pass 1 only" --steps 60 --warmup 5
     run "f32 b1  in situ 12%/4" --steps 60 --warmup 5
-    DC_TUNE_INSITU_PCT=25 DC_TUNE_INSITU_MAX=6 run "f32 b1  in situ 25%/6" --steps 60 --warmup 5
   fi
 done
