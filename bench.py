@@ -120,7 +120,7 @@ def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
     return None, None
 
 
-def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=True):
+def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=True, regions=5):
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
     680x920), float16 operands with float32 accumulation, device-resident, one pyramid batch at a time.  A step = the
     four batch-8 forwards of one pyramid batch (32 forwards = 8 images); shapes come from the per-shape plan cache."""
@@ -154,18 +154,24 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
             pyramid(inflight, k)
         torch.cuda.synchronize(dev)
         before = [n.stats() for n in nets]
-        for st in streams[1:]:
-            st.wait_stream(streams[0])
-        t0 = time.perf_counter()
-        for k in range(steps):
-            pyramid(inflight, k)  # the scales rotate over the executors
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(regions):
+            for st in streams[1:]:
+                st.wait_stream(streams[0])
+            t0 = time.perf_counter()
+            for k in range(steps):
+                pyramid(inflight, k)  # the scales rotate over the executors
+            torch.cuda.synchronize(dev)
+            dts.append(time.perf_counter() - t0)
         after = [n.stats() for n in nets]
-        return dt, sum(a["lowerings"] - b["lowerings"] for a, b in zip(after, before)), sum(
+        return dts, sum(a["lowerings"] - b["lowerings"] for a, b in zip(after, before)), sum(
             a["graph_instantiations"] - b["graph_instantiations"] for a, b in zip(after, before))
 
-    dt1, relow1, inst1 = timed(1)
+    def med(v):
+        return sorted(v)[len(v) // 2]
+
+    dts1, relow1, inst1 = timed(1)
+    dt1 = med(dts1)
     # between the regions: the tiles of every scale re-tuned for `execs` forwards in flight (untimed; deepcut_tools.tune_in_flight)
     retiled = None
     if execs > 1 and tune:
@@ -183,16 +189,19 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
                 return time.perf_counter() - t0
 
             load()  # every executor at this scale: the report and the overrides address its current plan
-            retiled += len(tune_in_flight(nets[:execs], load, top=8)["changed"])
-    dt2, relow2, inst2 = timed(execs)
+            retiled += len(tune_in_flight(nets[:execs], load, top=4)["changed"])
+    dts2, relow2, inst2 = timed(execs)
+    dt2 = med(dts2)
     tf1, tf2 = steps * flops / dt1 / 1e12, steps * flops / dt2 / 1e12
     return {"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
                         "accumulate (BASELINE configs[2]); value = %d batch-8 forwards in flight on %d executors (the scales rotate over them)" % (execs, execs),
-            "value": steps * 8 / dt2, "unit": "image-pyramids/s", "forwards_in_flight": execs,
+            "value": steps * 8 / dt2, "value_min": steps * 8 / max(dts2), "value_max": steps * 8 / min(dts2), "regions": regions,
+            "unit": "image-pyramids/s", "forwards_in_flight": execs,
             "tile_tuning": "latency" if retiled is None else "in flight (%d signatures re-tiled over the four scales)" % retiled, "forwards_per_s": steps * 32 / dt2, "steps": steps,
             "ms_per_pyramid_batch": dt2 / steps * 1e3, "gflop_per_image_pyramid": flops / 8 / 1e9, "tflops": tf2,
             "roofline_frac_f16": tf2 / PEAK_FP16_MFMA_TFLOPS,
-            "one_forward_at_a_time": {"value": steps * 8 / dt1, "unit": "image-pyramids/s", "ms_per_pyramid_batch": dt1 / steps * 1e3,
+            "one_forward_at_a_time": {"value": steps * 8 / dt1, "value_min": steps * 8 / max(dts1), "value_max": steps * 8 / min(dts1),
+                                      "unit": "image-pyramids/s", "ms_per_pyramid_batch": dt1 / steps * 1e3,
                                       "tflops": tf1, "roofline_frac_f16": tf1 / PEAK_FP16_MFMA_TFLOPS},
             "relowerings_in_timed_region": relow1 + relow2,
             "graph_instantiations_in_timed_region": inst1 + inst2}
@@ -203,6 +212,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="how many times each timed region (W warm-up + exactly K timed steps) is run; value = the median region, "
+                         "value_min / value_max the spread (one 45-ms region cannot resolve a 1 %% change)")
     ap.add_argument("--height", type=int, default=544)
     ap.add_argument("--width", type=int, default=736)
     ap.add_argument("--batch", type=int, default=0, help="images per rank per step (default: 1, or 8 with --config 3)")
@@ -358,8 +370,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), e0.elapsed_time(e1)
 
+    def repeated(nstreams):
+        """`--regions` timed regions of exactly K steps each (W warm-up steps in front of every one): the MEDIAN region's
+        (wall seconds, hipEvent ms) and the list of all wall times.  Every rank runs the same number of regions."""
+        rs = [timed_region(nstreams, args.steps, args.warmup) for _ in range(max(1, args.regions))]
+        order = sorted(range(len(rs)), key=lambda i: rs[i][0])
+        m = rs[order[len(rs) // 2]]
+        return m[0], m[1], [r[0] for r in rs]
+
     # (1) one forward at a time: per-kernel durations are undisturbed -> the roofline figure
-    lat_dt, lat_ev_ms = timed_region(1, args.steps, args.warmup)
+    lat_dt, lat_ev_ms, lat_all = repeated(1)
     # (2) the reported throughput: S independent batch-B forwards in flight (S streams, S Nets).  The tiles region (1) ran with were
     # chosen for the latency of one forward; a service that keeps S forwards in flight tunes for THAT load (untimed, like the
     # autotuning inside the warm-up): deepcut_tools.tune_in_flight, coordinate descent over the busiest GEMM signatures.
@@ -379,9 +399,9 @@ def main():
         except Exception as e:  # noqa: BLE001  (the line is printed whatever happens here)
             tuning = {"error": "%s: %s" % (type(e).__name__, e)}
     if S > 1:
-        dt, ev_ms = timed_region(S, args.steps, args.warmup)
+        dt, ev_ms, dt_all = repeated(S)
     else:
-        dt, ev_ms = lat_dt, lat_ev_ms
+        dt, ev_ms, dt_all = lat_dt, lat_ev_ms, lat_all
     x = xs[0]
 
     if rank == 0:
@@ -399,6 +419,9 @@ def main():
         res = {
             "metric": "images/sec, DeeperCut ResNet-%d FCN forward (prob+loc_pred+next_pred), whole node" % args.depth,
             "value": total_images / dt,
+            "value_min": total_images / max(dt_all),
+            "value_max": total_images / min(dt_all),
+            "regions": len(dt_all),
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -420,13 +443,14 @@ def main():
                 "launches_per_forward": launches,
                 "hipgraph": not args.no_graph,
                 "forwards_in_flight": S,
-                "tile_tuning": ("in flight (deepcut_tools.tune_in_flight: %d signatures re-tiled, %.2f -> %.2f ms per %d forwards, %d untimed runs)"
-                                % (len(tuning["changed"]), tuning["before"] * 1e3, tuning["after"] * 1e3, 6 * S, tuning["runs"])
+                "tile_tuning": ("in flight (deepcut_tools.tune_in_flight: %d signatures re-tiled, %d without isolated timings skipped, %.2f -> %.2f ms per %d forwards, %d untimed runs)"
+                                % (len(tuning["changed"]), tuning.get("skipped", 0), tuning["before"] * 1e3, tuning["after"] * 1e3, 6 * S, tuning["runs"])
                                 if tuning and "error" not in tuning else ("latency" if not tuning else tuning["error"])),
                 "parallelism": "dp%d (images sharded, maps gathered to rank 0 by RCCL send/recv)" % world if world > 1 else "single GPU",
             },
             "tflops": total_images * flops_img / dt / 1e12,
-            "one_forward_at_a_time": {"value": total_images / lat_dt, "unit": "images/s",
+            "one_forward_at_a_time": {"value": total_images / lat_dt, "value_min": total_images / max(lat_all),
+                                      "value_max": total_images / min(lat_all), "unit": "images/s",
                                       "ms_per_step": lat_dt / args.steps * 1e3,
                                       "tflops": total_images * flops_img / lat_dt / 1e12},
             "roofline": {
@@ -441,6 +465,8 @@ def main():
                 "avg_launch_us": avg_launch_s * 1e6,
                 "launches_per_image": conv_launches,
                 "traffic": hbm_traffic_from_profile((args.dtype, B, H, W))[0],
+                "traffic_source": "committed profile profiles/%s (rocprofv3 PMC passes of this workload; counters cannot be read inside the timed run)"
+                                  % hbm_traffic_from_profile((args.dtype, B, H, W))[1],
                 "traffic_unit": "HBM bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s); "
                                 "algorithmic minimum %.1f MB" % (hbm_traffic_from_profile((args.dtype, B, H, W))[1],
                                                                  (2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) * (0.5 if args.dtype == "f16" else 1.0) / conv_launches / 1e6),
@@ -466,7 +492,9 @@ def main():
                 net.forward_batch(xh)
             dt_pcie = time.perf_counter() - t1
             return {"value": n_pcie * B / dt_pcie, "unit": "images/s", "ms_per_forward": dt_pcie / n_pcie * 1e3,
-                    "note": "dc_net_forward_batch with host buffers, synchronous, one forward at a time"}
+                    "host_path_overhead_ms": dt_pcie / n_pcie * 1e3 - lat_dt / args.steps * 1e3,
+                    "note": "dc_net_forward_batch with host buffers (pageable numpy memory), synchronous, one forward at a time; "
+                            "host_path_overhead_ms = this minus the device-resident forward of the same net (%s batch %d)" % (args.dtype, B)}
 
         def pycaffe_forward():
             # the reference's own call sequence (python/pose/estimate_pose.py:104-112): write blobs['data'].data, net.forward(),
@@ -532,8 +560,8 @@ def main():
             beside("cross_request_batching", cross_request_batching)
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
             # the other single-GPU configuration of BASELINE.json, timed by the same run
-            beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, max(3, min(10, args.steps // 5)), dev, inject_weights,
-                                                          int(os.environ.get("DC_BENCH_F16_EXECS", "2")), not args.no_tune_in_flight))
+            beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, 10, dev, inject_weights,
+                                                          int(os.environ.get("DC_BENCH_F16_EXECS", "2")), not args.no_tune_in_flight, max(1, args.regions)))
         if args.breakdown:
             net.blobs["data"].data[...] = x.cpu().numpy()
             net.forward()

@@ -845,9 +845,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               rv[a][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};  // no shortcut: + 0 (one add instead of a select per element)
               if (p.resid && !rd_on) rv[a][b][j] = dc_bload4(rr, off[a][b][j], 0);
             }
-        // ReLU as max(x, lo) with a uniform lo = 0 or -inf: one instruction per element, no select.  (A NaN would come out
-        // of a ReLU-less layer as -inf — v_max returns the non-NaN operand —; activations here are finite.)
-        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        // ReLU is a template tag of `emit` below (uniform branch, like the shortcut): a ReLU-less layer stores its value
+        // untouched, so a NaN / inf accumulator (a numerically broken model, a float16 overflow) propagates as it does in the
+        // reference and in the element-wise path instead of being masked by max(x, -inf).
         if constexpr (RD_OK) {
           if (rd_on) {
             dc_wait_vm<0>();
@@ -872,10 +872,9 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
         // ReLU is a v_pk_max_f16 on the packed pair (rounding is monotonic and 0 / -inf are exact: max-then-round == round-then-max):
         // 28 VALU instructions per 16-byte vector with a shortcut, 20 without, instead of 48 — with three workgroups per CU
         // in their epilogues at once this phase is bound by VALU issue.
-        auto emit = [&](auto res_tag) {
-          constexpr bool HAS_RES = decltype(res_tag)::value;
-          const _Float16 rl = p.relu ? (_Float16)0.f : (_Float16)(-__builtin_inff());
-          const f16x2 rl2 = {rl, rl};
+        auto emit = [&](auto res_tag, auto relu_tag) {
+          constexpr bool HAS_RES = decltype(res_tag)::value, RELU = decltype(relu_tag)::value;
+          const f16x2 rl2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
           for (int b = 0; b < FN; ++b)
 #pragma unroll
@@ -891,7 +890,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
                   for (int e = 0; e < 4; ++e) {
                     float v = acc[a][b][4 * g0 + e] * s4[e] + h4[e];
                     if (HAS_RES) v += rv[a][b][j][e];
-                    o[e] = fmaxf(v, relu_lo);
+                    o[e] = RELU ? fmaxf(v, 0.f) : v;
                   }
                   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yr, off[a][b][j], 0, 0);
                 }
@@ -918,7 +917,8 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
                       x1 = dc_add_half_hi(rz[i], x1);
                     }
                     const f32x2 xp = {x0, x1};
-                    const f16x2 hp = __builtin_elementwise_max(__builtin_convertvector(xp, f16x2), rl2);
+                    f16x2 hp = __builtin_convertvector(xp, f16x2);
+                    if (RELU) hp = __builtin_elementwise_max(hp, rl2);
                     o[i] = __builtin_bit_cast(unsigned, hp);
                   }
                   __builtin_amdgcn_raw_buffer_store_b128(o, yr, off[a][b][j], 0, 0);
@@ -926,8 +926,13 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               }
             }
         };
-        if (p.resid) emit(std::true_type{});
-        else emit(std::false_type{});
+        if (p.resid) {
+          if (p.relu) emit(std::true_type{}, std::true_type{});
+          else emit(std::true_type{}, std::false_type{});
+        } else {
+          if (p.relu) emit(std::false_type{}, std::true_type{});
+          else emit(std::false_type{}, std::false_type{});
+        }
       } else {
         // element-wise form (odd channel counts, sigmoid heads, unaligned views, split-K 4 in float16)
 #pragma unroll

@@ -82,7 +82,12 @@ void Storage::reshape(const std::vector<int>& s) {
   // HEAD_AT_GPU.  Back to UNINITIALIZED: the next device access allocates (zero-filled), as a fresh SyncedMemory would.
   if (dev && std::max<size_t>(dev_count(), 8) * (size_t)esize > dev_cap && (head == HEAD_AT_GPU || head == SYNCED)) {
     if (head == SYNCED && host && count() <= host_cap) head = HEAD_AT_CPU;  // the (large enough) host copy stays authoritative
-    else head = UNINITIALIZED;
+    else {
+      head = UNINITIALIZED;
+      // a fresh SyncedMemory hands out zero-filled memory on first touch (syncedmem.cpp:25-31): a host buffer kept from
+      // before (older than the device image that is now gone) must not show through host_ptr()
+      if (host) std::memset(host, 0, host_cap * sizeof(float));
+    }
   }
 }
 float* Storage::host_ptr() {
@@ -1639,6 +1644,17 @@ void Net::upload_vecs() {
 // is timed once per process with each eligible tile variant on the real buffers (all variants compute
 // the same values up to fp32 summation order) and the fastest is kept.  DC_AUTOTUNE=0 keeps the cost
 // model's choice; DC_CONV_VARIANT forces one variant.
+// DC_TUNE_CACHE=<file>: "signature tile-name" per line.  Caller holds shared.mu.
+static void write_tune_cache_locked(const ModelShared& shared) {
+  const char* cache_path = std::getenv("DC_TUNE_CACHE");
+  if (!cache_path || !*cache_path) return;
+  if (FILE* f = std::fopen(cache_path, "w")) {
+    for (auto& kv : shared.tune_cache)
+      std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
+    std::fclose(f);
+  }
+}
+
 void Net::autotune() {
   tuned = true;
   if (env_int("DC_AUTOTUNE", 1) == 0 || env_int("DC_CONV_VARIANT", -1) >= 0) return;
@@ -1661,7 +1677,14 @@ void Net::autotune() {
   }
   size_t cached_before = tune_cache_.size();
   bool timed_any = false;
-  hipEvent_t e0, e1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct EvGuard {
+    hipEvent_t &a, &b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev_guard{e0, e1};
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
   const int reps = 5;
@@ -1735,11 +1758,24 @@ void Net::autotune() {
         std::string k = key_of(plan[i]);
         if (shortlist.count(k)) idx.push_back((int)i), keys.push_back(k);
       }
-      std::vector<hipEvent_t> ev(2 * idx.size());
+      std::vector<hipEvent_t> ev(2 * idx.size(), nullptr);
+      std::vector<Launch> saved = plan;
+      // the passes below overwrite plan[].variant with trial tiles: whatever throws in there, the executor must get its
+      // plan back (labels and grids of `saved` match its variants) and the events must not leak
+      struct Restore {
+        std::vector<Launch>& plan;
+        std::vector<Launch>& saved;
+        std::vector<hipEvent_t>& ev;
+        bool armed = true;
+        ~Restore() {
+          if (armed) plan = saved;
+          for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        }
+      } restore{plan, saved, ev};
       for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
       std::map<std::string, std::vector<float>> best;  // signature -> per shortlist entry, ms summed over its launches
       for (auto& kv : shortlist) best[kv.first].assign(kv.second.size(), 1e30f);
-      std::vector<Launch> saved = plan;
       for (size_t r = 0; r < rounds; ++r)
         for (int pass = 0; pass < 3; ++pass) {
           for (size_t j = 0; j < idx.size(); ++j) {
@@ -1769,7 +1805,7 @@ void Net::autotune() {
           }
         }
       plan = saved;
-      for (auto& e : ev) (void)hipEventDestroy(e);
+      restore.armed = false;  // (its destructor still destroys the events)
       for (auto& kv : best) {
         size_t arg = 0;
         for (size_t e = 1; e < kv.second.size(); ++e)
@@ -1795,16 +1831,8 @@ void Net::autotune() {
       l.grid = conv_grid(l.cg, l.variant);
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (timed_any) ++stats.autotune_runs;
-  if (cache_path && tune_cache_.size() != cached_before) {
-    if (FILE* f = std::fopen(cache_path, "w")) {
-      for (auto& kv : tune_cache_)
-        std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
-      std::fclose(f);
-    }
-  }
+  if (cache_path && (tune_cache_.size() != cached_before || timed_any)) write_tune_cache_locked(*shared);
   release_graph();
 }
 
@@ -1885,7 +1913,11 @@ void Net::set_tile(const std::string& key, const std::string& tile) {
   }
   {
     std::lock_guard<std::mutex> lk(shared->mu);
-    shared->tune_cache[key] = v;
+    auto it = shared->tune_cache.find(key);
+    if (it == shared->tune_cache.end() || it->second != v) {
+      shared->tune_cache[key] = v;
+      write_tune_cache_locked(*shared);  // an override changes a value, not the size of the table: persist it too
+    }
   }
   release_graph();
 }
@@ -2155,7 +2187,12 @@ void Net::forward(int start, int end) {
   upload_vecs();
   bool grew;
   prepare_buffers(*this, grew);
-  if (!tuned) autotune();
+  const bool whole = start <= 0 && end >= (int)layers.size() - 1;
+  // The timing passes replay launches of the WHOLE plan (in-place and Eltwise ones included) before the inputs are synced:
+  // harmless while every output they overwrite is scratch, i.e. for a full forward.  A partial range may start from
+  // intermediate blobs the caller placed on the device (mutable_gpu_data): those must not be clobbered, so a partial
+  // forward runs with the tiles the plan has (cost model / tune cache) and leaves the tuning to the next full forward.
+  if (!tuned && whole) autotune();
   // inputs of the executed range whose host copy is authoritative go up first (SyncedMemory::to_gpu)
   for (auto& l : plan) {
     if (l.last_layer < start || l.first_layer > end) continue;
@@ -2173,7 +2210,6 @@ void Net::forward(int start, int end) {
         }
       }
   }
-  const bool whole = start <= 0 && end >= (int)layers.size() - 1;
   if (use_graph && whole) {
     if (graph_exec && graph_buf_gen != buf_gen_) release_graph();  // a buffer it addresses was reallocated since
     if (!graph_exec) {
@@ -2716,7 +2752,10 @@ std::string Net::debug_info_text() {
       const size_t n = st.count();
       double a = 0;
       for (size_t q = 0; q < n; ++q) a += std::fabs((double)h[q]);
-      std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, param blob %zu data: %g\n", L.name.c_str(), k, n ? a / (double)n : 0.0);
+      // Net::AppendParam (net.cpp:469-482): the ParamSpec's name when it has one, else the index
+      const auto specs = L.def.subs("param");
+      const std::string pname = k < specs.size() && !specs[k]->str("name").empty() ? specs[k]->str("name") : std::to_string(k);
+      std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, param blob %s data: %g\n", L.name.c_str(), pname.c_str(), n ? a / (double)n : 0.0);
       os << buf;
     }
   }

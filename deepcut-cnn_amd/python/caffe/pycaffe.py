@@ -2,6 +2,7 @@
 (python/caffe/pycaffe.py:22-108, python/caffe/_caffe.cpp:76-96,159-193,219-277)."""
 import ctypes as C
 import os
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -368,8 +369,39 @@ class Net(object):
         _check(_lib.dc_net_save(self._h, path.encode()))
 
     # --- extensions (no pycaffe counterpart) ---------------------------------------------------
-    def forward_batch(self, images, want=("prob", "loc_pred", "next_pred")):
-        """images: float32 [n,3,H,W] host array -> dict of NCHW host arrays (one batched launch plan)."""
+    def _out_array(self, key, shape, out=None):
+        """Destination array of one output map.  `out` (a dict of C-contiguous float32 arrays of the right shape) wins.
+        Otherwise an array from a small per-net pool is handed out again once NOBODY else references it any more (the
+        caller dropped the previous result, views included: a view keeps its base alive), else a new one is made.
+        Why: a fresh 73 MB `np.empty` is untouched virtual memory; the device-to-host copy then faults every page of it
+        inside the driver's pin-on-the-fly path, which cost the float16 batch-8 host entry 7-35 ms per call (review r3,
+        weak 2) against 2.4 ms for the same copy into pages that exist."""
+        if out is not None and key in out:
+            a = out[key]
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and tuple(a.shape) == tuple(shape)):
+                raise ValueError("out[%r] must be a C-contiguous float32 array of shape %s" % (key, tuple(shape)))
+            return a
+        pools = self.__dict__.setdefault("_out_pool", OrderedDict())
+        pk = (key, tuple(shape))
+        pool = pools.get(pk)
+        if pool is None:
+            pool = pools[pk] = []
+            while len(pools) > 24:  # shapes of long ago go first
+                pools.popitem(last=False)
+        else:
+            pools.move_to_end(pk)
+        for a in pool:
+            if sys.getrefcount(a) <= 3:  # the pool's list, this loop variable, getrefcount's argument
+                return a
+        a = np.empty(shape, np.float32)
+        if len(pool) < 4:
+            pool.append(a)
+        return a
+
+    def forward_batch(self, images, want=("prob", "loc_pred", "next_pred"), out=None):
+        """images: float32 [n,3,H,W] host array -> dict of NCHW host arrays (one batched launch plan).  The arrays of a
+        result that the caller no longer references are recycled by a later call (see _out_array); `out` = {name: array}
+        writes into the caller's own buffers."""
         x = np.ascontiguousarray(images, dtype=np.float32)
         n, c, h, w = x.shape
         self.blobs["data"].reshape(n, c, h, w)
@@ -378,7 +410,7 @@ class Net(object):
         ptrs = {}
         for k in ("prob", "loc_pred", "next_pred"):
             if k in want:
-                outs[k] = np.empty(self.blobs[k].shape, np.float32)
+                outs[k] = self._out_array(k, self.blobs[k].shape, out)
                 ptrs[k] = outs[k].ctypes.data_as(C.c_void_p)
             else:
                 ptrs[k] = None
@@ -432,7 +464,7 @@ class Net(object):
         outs, ptrs = {}, {}
         for k in ("prob", "loc_pred", "next_pred"):
             if k in want:
-                outs[k] = np.empty(self.blobs[k].shape, np.float32)
+                outs[k] = self._out_array(k, self.blobs[k].shape)
                 ptrs[k] = outs[k].ctypes.data_as(C.c_void_p)
             else:
                 ptrs[k] = None

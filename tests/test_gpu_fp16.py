@@ -189,3 +189,52 @@ def test_fp16_net_with_a_narrow_skip_level(gpu_caffe):
         if fuse == 0:
             lg = ref["fc_pose"]
             assert float(np.abs(net16.blobs["fc_pose"].data - lg).max()) <= 4e-3 * max(1.0, float(np.abs(lg).max()))
+
+
+def test_host_entry_of_the_fp16_batch8_net_stays_close_to_the_device_forward(gpu_caffe, synth152):
+    """Review r3, weak 2: `Net.forward_batch(ndarray)` on a float16 batch-8 net took 39 ms against 4 ms device-resident —
+    the result arrays were fresh `np.empty` memory on every call and the device-to-host copy faulted 81 MB of pages inside
+    the driver.  Ten consecutive calls must move none of the net's lowering / graph / re-pack / buffer counters and stay
+    under twice the device-resident forward of the same net (measured: 6.4 ms against 3.9)."""
+    import time
+
+    import torch
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    h, w, b = 544, 736, 8
+    net = gpu_caffe.Net(deepercut_prototxt(152, h, w, b), path, gpu_caffe.TEST, from_text=True, dtype="f16", hipgraph=1)
+    x = rand_image(77, h, w, n=b)
+    xd = torch.from_numpy(x).cuda()
+    od = [torch.empty(net.blobs[k].shape, device="cuda") for k in ("prob", "loc_pred", "next_pred")]
+
+    def dev():
+        net.forward_device(xd.data_ptr(), b, h, w, od[0].data_ptr(), od[1].data_ptr(), od[2].data_ptr())
+        torch.cuda.synchronize()
+
+    dev()
+    dev()
+    t_dev = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        dev()
+        t_dev.append(time.perf_counter() - t0)
+    first = {k: v.copy() for k, v in net.forward_batch(x).items()}  # also warms the pool of result arrays
+    net.forward_batch(x)
+    before = net.stats()
+    t_host = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        out = net.forward_batch(x)
+        t_host.append(time.perf_counter() - t0)
+        del out
+    after = net.stats()
+    for k in ("lowerings", "graph_instantiations", "repacks", "buffer_growths"):
+        assert after[k] == before[k], (k, before[k], after[k])
+    out = net.forward_batch(x)
+    for k in first:
+        assert np.array_equal(out[k], first[k]), k  # recycled destinations, same values
+    held = net.forward_batch(x)  # `out` is still referenced: its arrays must not be handed out again
+    assert all(held[k] is not out[k] for k in out)
+    d, hmed = sorted(t_dev)[2], sorted(t_host)[5]
+    assert hmed < 2.0 * d + 1e-3, "host entry %.2f ms vs device-resident %.2f ms" % (hmed * 1e3, d * 1e3)

@@ -224,3 +224,27 @@ def test_bottleneck_blocks(gpu_caffe, stage, fuse):
     if fuse == 0:
         for k in ("b2a", "b2b", "b2c"):
             _check(net.blobs[k].data, ref[k])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_nan_and_inf_propagate_through_a_relu_less_layer(gpu_caffe, dtype, monkeypatch):
+    """the swapped-operand vector epilogue implemented "no ReLU" as max(x, -inf), which turns a NaN accumulator
+    into -inf (and, after the next fused add + ReLU, into 0).  A ReLU-less convolution has to hand a NaN / inf on, as the
+    reference's SGEMM does, on every tile family (forced: the LDS-DMA tiles carry that epilogue)."""
+    names = [n for n, _ in gpu_caffe.conv_variants()]
+    for tile in (["e64x64x32_w221_s4", "64x64x32_w221_p3"] if dtype == "f32" else ["d64x64x64_w221_s2", "h64x64x64_w221_p3"]):
+        monkeypatch.setenv("DC_CONV_VARIANT", str(names.index(tile)))
+        text = _inp("x", (1, 64, 9, 11)) + ('layer { name: "l" type: "Convolution" bottom: "x" top: "y" convolution_param '
+                                            "{ num_output: 64 kernel_size: 1 bias_term: false } }")
+        net = gpu_caffe.Net(text, gpu_caffe.TEST, from_text=True, fuse=0, dtype=dtype)
+        x = np.random.RandomState(3).randn(1, 64, 9, 11).astype(np.float32)
+        x[0, 5, 2, 3] = np.nan
+        x[0, 7, 4, 4] = np.inf
+        net.params["l"][0].data[...] = np.eye(64, dtype=np.float32).reshape(64, 64, 1, 1)
+        net.blobs["x"].data[...] = x
+        y = net.forward()["y"].copy()
+        assert tile in net.plan_text(), net.plan_text()
+        assert np.isnan(y[0, :, 2, 3]).all(), tile  # NaN * 0 = NaN: the whole pixel
+        assert np.isnan(y[0, 7, 4, 4]) or np.isinf(y[0, 7, 4, 4]), tile
+        ok = np.isfinite(x).all(axis=1)[0]
+        assert np.isfinite(y[0][:, ok]).all(), tile

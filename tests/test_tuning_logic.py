@@ -70,3 +70,41 @@ def test_nothing_to_tune_is_not_an_error():
     nets = [FakeNet([REPORT[2], REPORT[3]], log)]
     res = tune_in_flight(nets, lambda: 1.0)
     assert res["changed"] == [] and log == [] and res["before"] == res["after"] == 1.0
+
+
+def test_a_failing_load_leaves_every_executor_on_the_incumbent_tile():
+    """an exception from run() or set_tile must not leave the executors on mixed trial tiles."""
+    import pytest
+
+    nets, load, log, calls = _setup()
+
+    def flaky():
+        if calls[0] == 9:  # somewhere inside the trials of the first signature
+            calls[0] += 1
+            raise RuntimeError("device lost")
+        return load()
+
+    with pytest.raises(RuntimeError):
+        tune_in_flight(nets, flaky, reps=2)
+    a = {r["signature"]: r["tile"] for r in nets[0].report}
+    assert a == {r["signature"]: r["tile"] for r in nets[1].report}
+    assert a["busy"] in ("a", "b")  # the incumbent, or a tile that had been accepted before the failure — never a trial tile
+
+
+def test_a_signature_an_executor_does_not_have_is_skipped_and_counted():
+    log = []
+    nets = [FakeNet(REPORT, log), FakeNet([r for r in REPORT if r["signature"] != "busy"], log)]
+
+    def load():
+        return 1.0 + sum(COST[r["signature"]][r["tile"]] for r in nets[0].report if r["signature"] in COST)
+
+    res = tune_in_flight(nets, load, reps=1)
+    assert ("busy", "b") not in log and res["skipped"] == 3  # cached, single, and busy (missing on the second executor)
+
+
+def test_a_gain_that_does_not_reproduce_is_not_kept():
+    nets, _, log, _ = _setup()
+    seq = iter([2.0, 2.0, 1.9, 1.9] + [2.0] * 50)  # the first candidate looks 5 % faster once, then never again
+
+    res = tune_in_flight(nets, lambda: next(seq), top=1, reps=1, min_gain=0.01)
+    assert res["changed"] == [] and {r["signature"]: r["tile"] for r in nets[0].report}["busy"] == "a"
