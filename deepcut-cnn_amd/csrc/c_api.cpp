@@ -6,6 +6,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/deepcut_hip.h"
 #include "net.h"
@@ -509,5 +510,75 @@ int dc_net_set_tile(dc_net* net, const char* signature, const char* tile) {
 int dc_conv_variant_count(void) { return dc::conv_num_variants(); }
 const char* dc_conv_variant_name(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant(i).name : nullptr; }
 int dc_conv_variant_esize(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant_esize(i) : 0; }
+
+// ---- pyramid-grouped execution ---------------------------------------------------------------------------------------
+namespace {
+inline NetGroup* G(dc_group* g) { return reinterpret_cast<NetGroup*>(g); }
+}
+int dc_group_create(dc_net* const* nets, int n, dc_group** out) {
+  REQUIRE(nets);
+  REQUIRE(out);
+  *out = nullptr;
+  if (n <= 0) return fail(DC_EINVAL, "a group needs at least one net");
+  return guard([&] {
+    std::vector<Net*> m;
+    for (int i = 0; i < n; ++i) m.push_back(N(nets[i]));
+    *out = reinterpret_cast<dc_group*>(NetGroup::create(m));
+  });
+}
+int dc_group_destroy(dc_group* group) {
+  delete G(group);
+  return DC_OK;
+}
+int dc_group_size(dc_group* group) { return group ? (int)G(group)->nets.size() : 0; }
+int dc_group_forward_batch(dc_group* group, const float* const* inputs, const int* n, const int* h, const int* w, int is_device,
+                           float* const* prob, float* const* loc_pred, float* const* next_pred, void* stream) {
+  REQUIRE(group);
+  REQUIRE(inputs);
+  REQUIRE(n);
+  REQUIRE(h);
+  REQUIRE(w);
+  for (size_t c = 0; c < G(group)->nets.size(); ++c) {
+    if (!inputs[c]) return fail(DC_EINVAL, "null input for group member " + std::to_string(c));
+    if (n[c] <= 0 || h[c] <= 0 || w[c] <= 0) return fail(DC_EINVAL, "bad batch shape for group member " + std::to_string(c));
+  }
+  return guard([&] { G(group)->forward_batch(inputs, n, h, w, is_device != 0, prob, loc_pred, next_pred, stream); });
+}
+int dc_group_forward_images(dc_group* group, const unsigned char* const* images, const int* n, const int* height, const int* width,
+                            const double* scale, int is_device, float* const* prob, float* const* loc_pred, float* const* next_pred,
+                            double* const* pose, void* stream) {
+  REQUIRE(group);
+  REQUIRE(images);
+  REQUIRE(n);
+  REQUIRE(height);
+  REQUIRE(width);
+  REQUIRE(scale);
+  for (size_t c = 0; c < G(group)->nets.size(); ++c) {
+    if (!images[c]) return fail(DC_EINVAL, "null images for group member " + std::to_string(c));
+    if (n[c] <= 0 || height[c] <= 0 || width[c] <= 0 || !(scale[c] > 0)) return fail(DC_EINVAL, "bad image shape / scale for group member " + std::to_string(c));
+  }
+  return guard([&] { G(group)->forward_images(images, n, height, width, scale, is_device != 0, prob, loc_pred, next_pred, pose, stream); });
+}
+const char* dc_group_plan_text(dc_group* group) {
+  if (!group) return nullptr;
+  NetGroup* g = G(group);
+  int rc = guard([&] { g->text_buf = g->plan_text(); });
+  return rc == DC_OK ? g->text_buf.c_str() : nullptr;
+}
+int dc_group_stats(dc_group* group, long long* out, int n) {
+  REQUIRE(group);
+  REQUIRE(out);
+  NetGroup* g = G(group);
+  const long long v[DC_NUM_GSTATS] = {g->stats.merges, g->stats.graph_instantiations, g->stats.autotune_runs, g->stats.plan_hits,
+                                      (long long)g->num_launches(), (long long)g->num_multi_launches()};
+  for (int i = 0; i < n && i < DC_NUM_GSTATS; ++i) out[i] = v[i];
+  return DC_OK;
+}
+int dc_group_flops(dc_group* group, double* out) {
+  REQUIRE(group);
+  REQUIRE(out);
+  *out = G(group)->flops();
+  return DC_OK;
+}
 
 }  // extern "C"

@@ -31,6 +31,39 @@ struct ConvClass {
   long y_off;           // element offset of the class's first output inside `y` (and `resid`)
 };
 
+// MULTI-PROBLEM launches (round 4): the SAME layer over several tensors in one launch — the four scales of an image pyramid
+// (python/pose/estimate_pose.py:81-128 runs them as four forwards; base_conv_layer.cpp:326-341 as one SGEMM per image), the
+// crops of a crowd image, and, inside each of them, the residue classes of a strided deconvolution.  Filters, epilogue
+// constants, klen, sy/sx, Cout are the layer's and stay in ConvGemmParams; everything that depends on a tensor's shape or
+// address is per problem.  The table lives in device memory (ConvGemmParams::multi), read with scalar loads like the
+// argument block itself: filters are pulled through the L2s once per layer instead of once per scale, one dispatch
+// ramp and one tail per layer instead of four.
+constexpr int kMaxProblems = 16;
+struct ConvProblem {
+  const void* x;
+  void* y;            // pre-offset to the first output element of the problem
+  const void* resid;  // same addressing as y, or null (all problems of a launch alike)
+  long x_img_stride, y_img_stride;
+  long w_off;         // element offset of the problem's filter image inside `w` (deconvolution classes)
+  int x_row_stride, x_rows, x_rowlen;
+  int nty, ntx, dy0, ddy, x0, ddx, Ktot, x_bias;
+  int OH, OW, M;
+  int tiles_m;          // (filled by prepare_conv_multi)
+  unsigned div_ohw[2];  // (filled)
+  unsigned div_ow[2];   // (filled)
+  int y_row_stride, y_pix_stride;
+  int dense_x, dense_y;  // (filled) as ConvGemmParams::dense_x / dense_y
+  int NB;
+  int pad_;
+};
+struct ConvMultiTable {
+  // XCD row qy of the (1 << mc_lgx) x (8 >> mc_lgx) arrangement walks, of EVERY problem k in turn, the m tiles
+  // [tiles_m[k]*qy/gy, tiles_m[k]*(qy+1)/gy): end[qy][k] = m tiles of problems 0..k in that walk (INT_MAX past the last
+  // problem), so a workgroup finds its problem with 16 scalar compares on one 64-byte line
+  int end[8][kMaxProblems];
+  ConvProblem prob[kMaxProblems];
+};
+
 struct ConvGemmParams {
   int esize;          // bytes per activation / filter element: 4 (float) or 2 (_Float16); strides are in elements
   const void* x;
@@ -83,6 +116,9 @@ struct ConvGemmParams {
   int ncls;
   int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)
   ConvClass cls[kMaxClasses];
+  // --- multi-problem launches: nprob > 0 and multi[0] (device memory) replace every per-tensor field above
+  int nprob;
+  const ConvMultiTable* multi;
 };
 
 // Tile variants of conv_gemm.  BM x BN output tile per 256-thread workgroup, 4 waves arranged
@@ -100,6 +136,13 @@ bool conv_variant_multiclass(int i);  // has a multi-class instantiation (ConvGe
 long conv_grid(const ConvGemmParams& p, int variant);
 // returns hipError_t as int
 int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream);
+// Multi-problem launch, prepared once (host side): `p` carries the layer's common fields (esize, klen, sy, sx, w, Cout, scale,
+// shift, relu, sigmoid_ch), `table.prob[0..nprob)` the per-tensor ones (pointers included).  Fills the derived fields of both
+// (x_bias, magic numbers, tiles, dense / vector-epilogue flags, the XCD arrangement and table.cum) and returns the grid, or
+// -1 if this variant cannot take the launch.  The caller uploads `table` and sets p.multi to the device copy.
+long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& table, int nprob, int variant);
+bool conv_variant_multiproblem(int i);
+int launch_conv_multi(const ConvGemmParams& p, int variant, long grid, void* stream);
 
 // ---- Winograd F(2x2, 3x3) for the stride-1, dilation-1, pad-1 3x3 convolutions (float32) -------------------------
 // Same ConvGemmParams as the gather-GEMM (x/y/resid/scale/shift/relu, NB, OH, OW, Cout, strides; klen = input channels,

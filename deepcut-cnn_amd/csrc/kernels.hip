@@ -156,7 +156,9 @@ struct Elem<_Float16> {
 // SWP: the MFMA operands are swapped (filters as the row operand), so that a lane's accumulators are 16 CHANNELS of one
 //      pixel (4 runs of 4 consecutive channels) instead of 16 pixels of one channel: the epilogue then forms 16-byte output
 //      vectors in registers (float16: one v_permlane32_swap per register pair) — no LDS transposition, no barriers.
-template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0, bool SWP = false>
+// MP: multi-problem launch (ConvGemmParams::nprob > 0): every per-tensor scalar AND pointer comes from the device-resident
+//     table p.multi->prob[problem of this block] — the same layer over the scales of a pyramid / the classes of a deconvolution.
+template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bool MC = false, int DMA = 0, bool SWP = false, bool MP = false>
 // (second launch bound = waves per SIMD the register budget must allow: the 4-wave LDS-DMA tiles are meant to run two
 //  workgroups per CU, so their allocation has to stay within 256 registers — with it the compiler also keeps the
 //  accumulators in VGPRs instead of AGPRs: no v_accvgpr_read pass in front of the epilogue, 169 instead of 200 registers)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   int* rowinfo = reinterpret_cast<int*>(smem + MAINB);
   float* epi_sc = reinterpret_cast<float*>(smem + MAINB + 4 * BM);  // SWP: scale[BN], shift[BN] of the tile's channels
   // per tile row: byte offset of its output pixel, or -1
-  const T* px = reinterpret_cast<const T*>(p.x);
+  static_assert(!(MC && MP), "a multi-problem launch carries its deconvolution classes as problems");
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -238,8 +240,48 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   int c_OH = p.OH, c_OW = p.OW, c_M = p.M;
   unsigned c_dohw[2] = {p.div_ohw[0], p.div_ohw[1]}, c_dow[2] = {p.div_ow[0], p.div_ow[1]};
   long c_woff = 0, c_yoff = 0;
+  // per-tensor scalars (uniform): the argument block's in a single-problem launch, the problem's in a multi-problem one
+  const T* px = reinterpret_cast<const T*>(p.x);
+  long c_ximg = p.x_img_stride, c_yimg = p.y_img_stride;
+  int c_xrow = p.x_row_stride, c_xrows = p.x_rows, c_xrowlen = p.x_rowlen, c_yrow = p.y_row_stride, c_ypix = p.y_pix_stride;
+  void* c_y = p.y;
+  const void* c_resid = p.resid;
+  int c_densex = p.dense_x, c_densey = p.dense_y;
   int tile_n, tile_m;
-  if constexpr (MC) {
+  if constexpr (MP) {
+    // XCD (qx, qy) owns the n tiles [tn*qx/gx, tn*(qx+1)/gx) and walks, problem after problem, the m tiles
+    // [tm_k*qy/gy, tm_k*(qy+1)/gy) of every problem k, n fastest: the layer's filters (shared by all problems) are fetched
+    // once per L2 that needs them.  The grid is 8 x the longest XCD list; surplus workgroups exit.
+    typedef const __attribute__((address_space(4))) ConvMultiTable* tab_t;  // constant address space: scalar loads
+    tab_t tb = (tab_t)p.multi;
+    const int xq = blockIdx.x & 7, lgx = p.mc_lgx, lgy = 3 - lgx;
+    const int qx = xq & ((1 << lgx) - 1), qy = xq >> lgx;
+    const int n_lo = (p.tiles_n * qx) >> lgx, n_cnt = ((p.tiles_n * (qx + 1)) >> lgx) - n_lo;
+    const int slot = blockIdx.x >> 3;
+    const int mrow = n_cnt == (p.tiles_n >> lgx) ? dc_fastdiv(slot, p.div_rw[0]) : dc_fastdiv(slot, p.div_rw[1]);  // slot / n_cnt
+    int k = 0, start = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxProblems; ++j) {
+      const int e = tb->end[qy][j];
+      const int ge = (e - 1 - mrow) >> 31;  // -1 iff mrow >= e (sign arithmetic: stays on the scalar unit; e <= INT_MAX, mrow >= 0)
+      k -= ge;
+      start = (e & ge) | (start & ~ge);
+    }
+    if (k >= p.nprob) return;
+    const __attribute__((address_space(4))) ConvProblem& q = tb->prob[k];
+    c_Ktot = q.Ktot, c_nty = q.nty, c_ntx = q.ntx, c_dy0 = q.dy0, c_ddy = q.ddy, c_x0 = q.x0, c_ddx = q.ddx, c_xbias = q.x_bias;
+    c_OH = q.OH, c_OW = q.OW, c_M = q.M;
+    c_dohw[0] = q.div_ohw[0], c_dohw[1] = q.div_ohw[1], c_dow[0] = q.div_ow[0], c_dow[1] = q.div_ow[1];
+    c_woff = q.w_off;
+    px = reinterpret_cast<const T*>(q.x);
+    c_ximg = q.x_img_stride, c_yimg = q.y_img_stride;
+    c_xrow = q.x_row_stride, c_xrows = q.x_rows, c_xrowlen = q.x_rowlen, c_yrow = q.y_row_stride, c_ypix = q.y_pix_stride;
+    c_y = q.y;
+    c_resid = q.resid;
+    c_densex = q.dense_x, c_densey = q.dense_y;
+    tile_m = ((q.tiles_m * qy) >> lgy) + (mrow - start);
+    tile_n = n_lo + (slot - mrow * n_cnt);
+  } else if constexpr (MC) {
     // Workgroup b runs on XCD (b % 8), each with its own L2.  XCD (qx, qy) of a gx x gy arrangement owns the n tiles
     // [tn*qx/gx, tn*(qx+1)/gx) and, of EVERY class, the m tiles [tm*qy/gy, tm*(qy+1)/gy); it walks its classes heaviest
     // first.  So an L2 fetches 1/gx of the filter images and 1/gy of the pixels instead of everything (the heads'
@@ -373,29 +415,29 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
     const int m = m0 + lrow + RPP * i;
     avoff[i] = kOOB;
     amask[i] = 0;
-    if (!MC && p.dense_x) {  // 1x1 over a dense tensor: pixel m starts at element m * sx, its one tap is always inside
+    if (!MC && c_densex) {  // 1x1 over a dense tensor: pixel m starts at element m * sx, its one tap is always inside
       if (m < c_M) avoff[i] = (unsigned)(m * p.sx) * ES + lcb, amask[i] = 1u;
     } else if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
       const int ox = rem - oy * c_OW;
-      avoff[i] = (unsigned)(int)(((long)n * p.x_img_stride + (long)(oy * p.sy) * p.x_row_stride + ox * p.sx) * ES) + lcb;
+      avoff[i] = (unsigned)(int)(((long)n * c_ximg + (long)(oy * p.sy) * c_xrow + ox * p.sx) * ES) + lcb;
       unsigned rowmask = 0, colmask = 0, full = 0;
       if (DMA && c_nty == 3 && c_ntx == 3) {
         // the 3x3 layers (a third of the float16 time): the same masks, straight-line — the generic loops below cost ~3 k
         // cycles of every workgroup's prologue (dependent compares + branches, two to four rows per thread)
         const int y0 = oy * p.sy + c_dy0, x0 = ox * p.sx + lce + c_x0;
-        const unsigned r0 = (unsigned)y0 < (unsigned)p.x_rows, r1 = (unsigned)(y0 + c_ddy) < (unsigned)p.x_rows, r2 = (unsigned)(y0 + 2 * c_ddy) < (unsigned)p.x_rows;
-        const unsigned cm = ((unsigned)x0 < (unsigned)p.x_rowlen ? 1u : 0u) | ((unsigned)(x0 + c_ddx) < (unsigned)p.x_rowlen ? 2u : 0u) |
-                            ((unsigned)(x0 + 2 * c_ddx) < (unsigned)p.x_rowlen ? 4u : 0u);
+        const unsigned r0 = (unsigned)y0 < (unsigned)c_xrows, r1 = (unsigned)(y0 + c_ddy) < (unsigned)c_xrows, r2 = (unsigned)(y0 + 2 * c_ddy) < (unsigned)c_xrows;
+        const unsigned cm = ((unsigned)x0 < (unsigned)c_xrowlen ? 1u : 0u) | ((unsigned)(x0 + c_ddx) < (unsigned)c_xrowlen ? 2u : 0u) |
+                            ((unsigned)(x0 + 2 * c_ddx) < (unsigned)c_xrowlen ? 4u : 0u);
         amask[i] = (r0 ? cm : 0u) | (r1 ? cm << 3 : 0u) | (r2 ? cm << 6 : 0u);
         continue;
       }
 #pragma nounroll
-      for (int ty = 0; ty < c_nty; ++ty) rowmask |= ((unsigned)(oy * p.sy + c_dy0 + ty * c_ddy) < (unsigned)p.x_rows ? 1u : 0u) << ty;
+      for (int ty = 0; ty < c_nty; ++ty) rowmask |= ((unsigned)(oy * p.sy + c_dy0 + ty * c_ddy) < (unsigned)c_xrows ? 1u : 0u) << ty;
 #pragma nounroll
-      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ox * p.sx + lce + c_x0 + tx * c_ddx) < (unsigned)p.x_rowlen ? 1u : 0u) << tx;
+      for (int tx = 0; tx < c_ntx; ++tx) colmask |= ((unsigned)(ox * p.sx + lce + c_x0 + tx * c_ddx) < (unsigned)c_xrowlen ? 1u : 0u) << tx;
 #pragma nounroll
       for (int ty = 0; ty < c_nty; ++ty)
         if ((rowmask >> ty) & 1u) full |= colmask << (ty * c_ntx);
@@ -408,7 +450,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   const i32x4 xrs = dc_rsrc_words(px + c_xbias);
   // tap cursor, all uniform (SALU): (tx, c0, running bit) and the element displacement of the current tap
   int tx = 0, c0 = 0, tbit = 0;
-  int row_soff = c_dy0 * p.x_row_stride + c_x0 - c_xbias;  // displacement of tap (ty, 0)
+  int row_soff = c_dy0 * c_xrow + c_x0 - c_xbias;  // displacement of tap (ty, 0)
   int tap_soff = row_soff;
   auto gload_a = [&](int slot) {
     const unsigned soff = (unsigned)(tap_soff + c0) * ES;
@@ -423,7 +465,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       tap_soff += c_ddx;
       if (tx >= c_ntx) {
         tx = 0;
-        row_soff += c_ddy * p.x_row_stride;
+        row_soff += c_ddy * c_xrow;
         tap_soff = row_soff;
       }
     }
@@ -443,7 +485,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       tap_soff += c_ddx;
       if (tx >= c_ntx) {
         tx = 0;
-        row_soff += c_ddy * p.x_row_stride;
+        row_soff += c_ddy * c_xrow;
         tap_soff = row_soff;
       }
     }
@@ -486,20 +528,20 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   if (t < BM) {
     const int m = m0 + t;
     int yo = -1;
-    if (!MC && p.dense_y) {
-      if (m < c_M) yo = m * p.y_pix_stride * ES;
+    if (!MC && c_densey) {
+      if (m < c_M) yo = m * c_ypix * ES;
     } else if (m < c_M) {
       const int n = dc_fastdiv(m, c_dohw);
       const int rem = m - n * (c_OH * c_OW);
       const int oy = dc_fastdiv(rem, c_dow);
       const int ox = rem - oy * c_OW;
-      yo = (int)(((long)n * p.y_img_stride + (long)oy * p.y_row_stride + (long)ox * p.y_pix_stride) * ES);
+      yo = (int)(((long)n * c_yimg + (long)oy * c_yrow + (long)ox * c_ypix) * ES);
     }
     rowinfo[t] = yo;
   }
   stamp(3);
-  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(reinterpret_cast<T*>(p.y) + c_yoff, 0x7fffffffu);
-  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(reinterpret_cast<const T*>(p.resid ? p.resid : p.y) + c_yoff, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t yr = dc_rsrc(reinterpret_cast<T*>(c_y) + c_yoff, 0x7fffffffu);
+  const __amdgpu_buffer_rsrc_t rr = dc_rsrc(reinterpret_cast<const T*>(c_resid ? c_resid : c_y) + c_yoff, 0x7fffffffu);
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -580,7 +622,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   //     MFMA 32x32 C layout: col = lane&31 (channel), row = (r&3)+8*(r>>2)+4*(lane>>5).
   //     With in-workgroup split-K every one of the WK waves finalises RPW of the 16 accumulator registers.
   float rs[EARLY_RESID ? FM * FN * RPW : 1];
-  if (EARLY_RESID && p.resid) {
+  if (EARLY_RESID && c_resid) {
 #pragma unroll
     for (int a = 0; a < FM; ++a)
 #pragma unroll
@@ -613,7 +655,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
     // for the last DMA-1 tiles, one for the last tile): with an unrolled ring and an early exit in the middle the
     // register allocator parked the 64 accumulators in different register classes on the two sides of the loop header
     // and copied all of them (v_accvgpr_read/write) once per round.
-    rd_on = RD_OK && p.resid && p.vec_epi && !MC;
+    rd_on = RD_OK && c_resid && p.vec_epi && !MC;
     unsigned sb = 0;                    // byte offset of the stage tile `it` is read from
     unsigned sbp = (DMA - 1) * TILEB;   // ... of the stage tile it+DMA-1 goes to (tile it-1 was read from it)
     auto tile = [&](auto more1_tag, auto moreD_tag, int it) {
@@ -716,7 +758,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       if (rd_on) {
         rd_off = sbp;
         constexpr int RB = BN * ES, LPR = RB / 16, PPP = 1024 / RB;  // row bytes, lanes per row, pixels per 1 KiB piece
-        const i32x4 rrs = dc_rsrc_words(reinterpret_cast<const T*>(p.resid) + c_yoff);
+        const i32x4 rrs = dc_rsrc_words(reinterpret_cast<const T*>(c_resid) + c_yoff);
 #pragma unroll
         for (int j = 0; j < RD_PCS; ++j) {
           const int px_ = (j * NW + wave) * PPP + lane / LPR;        // tile row
@@ -784,7 +826,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
           const int yo = rowinfo[row];
           const int co = n0 + cv * 8;
           woff[i] = (yo >= 0 && co < p.Cout) ? (unsigned)yo + co * ES : kOOB;  // Cout % 8 == 0: a vector is all in or all out
-          if (p.resid) wres[i] = dc_bload4(rr, woff[i], 0);
+          if (c_resid) wres[i] = dc_bload4(rr, woff[i], 0);
         }
       }
     }
@@ -843,7 +885,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               const int co = n0 + wc * TN + b * 32 + (ES == 4 ? 8 * g0 + 4 * h : 8 * (g0 + h));
               off[a][b][j] = (yo[a] >= 0 && co < p.Cout) ? (unsigned)yo[a] + (unsigned)co * ES : kOOB;
               rv[a][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};  // no shortcut: + 0 (one add instead of a select per element)
-              if (p.resid && !rd_on) rv[a][b][j] = dc_bload4(rr, off[a][b][j], 0);
+              if (c_resid && !rd_on) rv[a][b][j] = dc_bload4(rr, off[a][b][j], 0);
             }
         // ReLU is a template tag of `emit` below (uniform branch, like the shortcut): a ReLU-less layer stores its value
         // untouched, so a NaN / inf accumulator (a numerically broken model, a float16 overflow) propagates as it does in the
@@ -926,7 +968,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               }
             }
         };
-        if (p.resid) {
+        if (c_resid) {
           if (p.relu) emit(std::true_type{}, std::true_type{});
           else emit(std::true_type{}, std::false_type{});
         } else {
@@ -950,7 +992,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
               for (int e = 0; e < 4; ++e) {
                 const int co = n0 + cb + e;
                 eo[e] = (yo[a] >= 0 && co < p.Cout) ? (unsigned)yo[a] + (unsigned)co * ES : kOOB;
-                rvv[e] = p.resid ? Elem<T>::load(rr, eo[e]) : 0.f;
+                rvv[e] = c_resid ? Elem<T>::load(rr, eo[e]) : 0.f;
               }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -987,7 +1029,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
           f16x8 o;
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            float x = (q < 4 ? lo[q] : hi[q - 4]) + (p.resid ? (float)rz[q] : 0.f);
+            float x = (q < 4 ? lo[q] : hi[q - 4]) + (c_resid ? (float)rz[q] : 0.f);
             if (p.relu) x = fmaxf(x, 0.f);
             o[q] = (_Float16)x;
           }
@@ -1013,8 +1055,8 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
         }
         if (EARLY_RESID) {
 #pragma unroll
-          for (int e = 0; e < RPW; ++e) rv[e] = p.resid ? rs[(a * FN + b) * RPW + e] : 0.f;
-        } else if (p.resid) {  // all shortcut loads of the fragment in flight at once
+          for (int e = 0; e < RPW; ++e) rv[e] = c_resid ? rs[(a * FN + b) * RPW + e] : 0.f;
+        } else if (c_resid) {  // all shortcut loads of the fragment in flight at once
 #pragma unroll
           for (int e = 0; e < RPW; ++e) rv[e] = Elem<T>::load(rr, off[e]);
         } else {
@@ -1077,56 +1119,32 @@ struct VariantEntry {
   int BK;
   int esize;
   void (*kernel_mc)(const ConvGemmParams);  // multi-class instantiation (the deconvolution heads), or null
+  void (*kernel_mp)(const ConvGemmParams);  // multi-problem instantiation (pyramid-grouped launches)
 };
-#define DC_VARIANT(BM, BN, BK, WR, WC, WK, PF)                                     \
-  {                                                                                \
-    {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
-        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4, nullptr        \
-  }
-#define DC_VARIANT_MC(BM, BN, BK, WR, WC, WK, PF)                                  \
-  {                                                                                \
-    {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},             \
-        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF>, BK, 4,                \
-        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, PF, true>                  \
-  }
-#define DC_VARIANT_H(BM, BN, BK, WR, WC, WK, PF)                                   \
-  {                                                                                \
-    {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},         \
-        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2, nullptr     \
-  }
-#define DC_VARIANT_H_MC(BM, BN, BK, WR, WC, WK, PF)                                \
-  {                                                                                \
-    {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK},         \
-        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF>, BK, 2,             \
-        conv_gemm_kernel<_Float16, BM, BN, BK, WR, WC, WK, PF, true>               \
-  }
+// the three instantiations of one tile: single problem, multi-class (or null), multi-problem
+#define DC_K3(T, BM, BN, BK, WR, WC, WK, PF, DMA, SWP, ES, WITH_MC)                                            \
+  conv_gemm_kernel<T, BM, BN, BK, WR, WC, WK, PF, false, DMA, SWP>, BK, ES,                                     \
+      WITH_MC ? conv_gemm_kernel<T, BM, BN, BK, WR, WC, WK, PF, WITH_MC, DMA, SWP> : nullptr,                   \
+      conv_gemm_kernel<T, BM, BN, BK, WR, WC, WK, PF, false, DMA, SWP, true>
+#define DC_VARIANT(BM, BN, BK, WR, WC, WK, PF) \
+  { {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK}, DC_K3(float, BM, BN, BK, WR, WC, WK, PF, 0, false, 4, false) }
+#define DC_VARIANT_MC(BM, BN, BK, WR, WC, WK, PF) \
+  { {#BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK}, DC_K3(float, BM, BN, BK, WR, WC, WK, PF, 0, false, 4, true) }
+#define DC_VARIANT_H(BM, BN, BK, WR, WC, WK, PF) \
+  { {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, BK, WR, WC, WK, PF, 0, false, 2, false) }
+#define DC_VARIANT_H_MC(BM, BN, BK, WR, WC, WK, PF) \
+  { {"h" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_p" #PF, BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, BK, WR, WC, WK, PF, 0, false, 2, true) }
 // LDS-DMA variants: "d" prefix, BK fixed by the 128-byte row (64 halves), S = LDS stages of the ring
-#define DC_VARIANT_HD(BM, BN, WR, WC, WK, S)                                        \
-  {                                                                                \
-    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, true>, 64, 2, nullptr \
-  }
-#define DC_VARIANT_HD_T(BM, BN, WR, WC, WK, S)  /* LDS-transposed epilogue instead of the swapped-operand one (A/B) */ \
-  {                                                                                \
-    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S "_t", BM, BN, WR, WC, WK},         \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, false>, 64, 2, nullptr \
-  }
-#define DC_VARIANT_HD_MC(BM, BN, WR, WC, WK, S)                                     \
-  {                                                                                \
-    {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},              \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, false, S, true>, 64, 2, \
-        conv_gemm_kernel<_Float16, BM, BN, 64, WR, WC, WK, 1, true, S, true>        \
-  }
-#define DC_VARIANT_HD2(BM, BN, WR, WC, WK, S)  /* 256-byte rows: BK = 128 halves */  \
-  {                                                                                \
-    {"d" #BM "x" #BN "x128_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},             \
-        conv_gemm_kernel<_Float16, BM, BN, 128, WR, WC, WK, 1, false, S, true>, 128, 2, nullptr \
-  }
-#define DC_VARIANT_FD(BM, BN, BK, WR, WC, WK, S)  /* float32: BK = 32 (128-byte rows) or 64 (256-byte rows) */ \
-  {                                                                                \
-    {"e" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK},          \
-        conv_gemm_kernel<float, BM, BN, BK, WR, WC, WK, 1, false, S, true>, BK, 4, nullptr \
-  }
+#define DC_VARIANT_HD(BM, BN, WR, WC, WK, S) \
+  { {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, 64, WR, WC, WK, 1, S, true, 2, false) }
+#define DC_VARIANT_HD_T(BM, BN, WR, WC, WK, S) /* LDS-transposed epilogue instead of the swapped-operand one (A/B) */ \
+  { {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S "_t", BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, 64, WR, WC, WK, 1, S, false, 2, false) }
+#define DC_VARIANT_HD_MC(BM, BN, WR, WC, WK, S) \
+  { {"d" #BM "x" #BN "x64_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, 64, WR, WC, WK, 1, S, true, 2, true) }
+#define DC_VARIANT_HD2(BM, BN, WR, WC, WK, S) /* 256-byte rows: BK = 128 halves */ \
+  { {"d" #BM "x" #BN "x128_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK}, DC_K3(_Float16, BM, BN, 128, WR, WC, WK, 1, S, true, 2, false) }
+#define DC_VARIANT_FD(BM, BN, BK, WR, WC, WK, S) /* float32: BK = 32 (128-byte rows) or 64 (256-byte rows) */ \
+  { {"e" #BM "x" #BN "x" #BK "_w" #WR #WC #WK "_s" #S, BM, BN, WR, WC, WK}, DC_K3(float, BM, BN, BK, WR, WC, WK, 1, S, true, 4, false) }
 const VariantEntry kVariants[] = {
     DC_VARIANT(128, 128, 32, 2, 2, 1, 2),  // 0: big-M layers (res2/res3)
     DC_VARIANT(128, 64, 32, 2, 2, 1, 2),   // 1
@@ -1356,6 +1374,111 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   }
   const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
   hipLaunchKernelGGL(e.kernel, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+bool conv_variant_multiproblem(int i) { return kVariants[i].kernel_mp != nullptr; }
+
+// Multi-problem launch: host-side preparation (once per plan), see kernels.h.
+long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& tb, int nprob, int variant) {
+  if (variant < 0 || variant >= kNumVariants || nprob < 1 || nprob > kMaxProblems) return -1;
+  const VariantEntry& e = kVariants[variant];
+  if (!e.kernel_mp || p.esize != e.esize || p.klen % e.BK != 0) return -1;
+  const long es = p.esize;
+  const double lim = 2147483647.0;
+  static const int dense = getenv("DC_DENSE") ? atoi(getenv("DC_DENSE")) : 1;
+  const long tn = (p.Cout + e.v.BN - 1) / e.v.BN;
+  bool vec = (p.Cout * es) % 16 == 0 && p.sigmoid_ch == 0;
+  double wtot = 0, atot = 0;
+  long w_lo = 0, w_hi = 0;
+  for (int c = 0; c < nprob; ++c) {
+    ConvProblem& q = tb.prob[c];
+    const int ntaps = q.nty * q.ntx;
+    if (ntaps < 1 || ntaps > kMaxTaps || q.Ktot != ntaps * p.klen || q.M <= 0 || q.NB <= 0) return -1;
+    if ((double)es * q.NB * (double)q.x_img_stride >= lim || (double)es * q.NB * (double)q.y_img_stride >= lim) return -1;
+    if ((q.resid != nullptr) != (tb.prob[0].resid != nullptr)) return -1;
+    int bias = 0;
+    for (int ty : {0, q.nty - 1})
+      for (int tx : {0, q.ntx - 1}) bias = std::min(bias, (q.dy0 + ty * q.ddy) * q.x_row_stride + q.x0 + tx * q.ddx);
+    q.x_bias = bias;
+    dc_magic((unsigned)(q.OH * q.OW), q.div_ohw);
+    dc_magic((unsigned)q.OW, q.div_ow);
+    q.tiles_m = (q.M + e.v.BM - 1) / e.v.BM;
+    q.dense_x = dense && q.nty == 1 && q.ntx == 1 && q.dy0 == 0 && q.x0 == 0 && p.sy == 1 && q.x_rows == q.OH && q.x_row_stride == q.OW * p.sx &&
+                q.x_img_stride == (long)q.OH * q.x_row_stride && q.x_rowlen >= (q.OW - 1) * p.sx + p.klen;
+    q.dense_y = dense && q.y_row_stride == q.OW * q.y_pix_stride && q.y_img_stride == (long)q.OH * q.y_row_stride;
+    vec = vec && (q.y_pix_stride * es) % 16 == 0 && (q.y_row_stride * es) % 16 == 0 && (q.y_img_stride * es) % 16 == 0 && ((uintptr_t)q.y & 15) == 0 &&
+          (!q.resid || ((uintptr_t)q.resid & 15) == 0);
+    w_lo = std::min(w_lo, q.w_off);
+    w_hi = std::max(w_hi, q.w_off + (long)p.Cout * q.Ktot);
+    atot += (double)es * q.M * (double)p.klen * q.nty;
+  }
+  wtot = (double)es * (double)(w_hi - w_lo);
+  if (wtot >= lim) return -1;
+  p.nprob = nprob;
+  p.ncls = 0;
+  p.vec_epi = vec ? 1 : 0;
+  p.wide_epi = 0;  // (the LDS-transposed float16 epilogue addresses one tensor: the element-wise form takes its place here)
+  {
+    static const int wide_epi = getenv("DC_WIDE_EPI") ? atoi(getenv("DC_WIDE_EPI")) : 1;
+    bool w8 = wide_epi && p.esize == 2 && p.Cout % 8 == 0 && p.sigmoid_ch == 0;
+    for (int c = 0; c < nprob; ++c) {
+      const ConvProblem& q = tb.prob[c];
+      w8 = w8 && q.y_pix_stride % 8 == 0 && q.y_row_stride % 8 == 0 && q.y_img_stride % 8 == 0 && ((uintptr_t)q.y & 15) == 0 &&
+           (!q.resid || ((uintptr_t)q.resid & 15) == 0);
+    }
+    p.wide_epi = w8 ? 1 : 0;
+  }
+  p.dense_x = p.dense_y = 0;
+  p.xcd_on = 0;
+  p.tiles_n = (int)tn;
+  dc_magic((unsigned)tn, p.div_tn);
+  // XCD arrangement gx x gy minimising what one L2 has to fetch (its share of the filters + its share of the pixels)
+  long blk = 0;
+  double best = 1e300;
+  long total = 0;
+  for (int c = 0; c < nprob; ++c) total += tb.prob[c].tiles_m * tn;
+  for (int lgx = 0; lgx <= 3; ++lgx) {
+    const int gx = 1 << lgx;
+    if (gx > tn) continue;
+    long longest = 0;
+    for (int xq = 0; xq < 8; ++xq) {
+      const int qx = xq & (gx - 1), qy = xq >> lgx;
+      const long ncnt = ((tn * (qx + 1)) >> lgx) - ((tn * qx) >> lgx);
+      long cnt = 0;
+      for (int c = 0; c < nprob; ++c)
+        cnt += ((((long)tb.prob[c].tiles_m * (qy + 1)) >> (3 - lgx)) - (((long)tb.prob[c].tiles_m * qy) >> (3 - lgx))) * ncnt;
+      longest = std::max(longest, cnt);
+    }
+    const double cost = (wtot / gx + atot / (8 >> lgx)) * (1.0 + 0.02 * (longest * 8 - total) / (double)std::max(total, 1L));
+    if (cost < best) best = cost, p.mc_lgx = lgx, blk = longest * 8;
+  }
+  if (blk <= 0 || blk > 0x7fffffffL) return -1;
+  {
+    const int lgx = p.mc_lgx, lgy = 3 - lgx;
+    const unsigned w0 = (unsigned)(tn >> lgx);
+    dc_magic(std::max(w0, 1u), p.div_rw[0]);
+    dc_magic(w0 + 1, p.div_rw[1]);
+    for (int qy = 0; qy < 8; ++qy) {
+      int run = 0;
+      for (int c = 0; c < kMaxProblems; ++c) {
+        if (c < nprob && qy < (8 >> lgx)) {
+          run += (int)((((long)tb.prob[c].tiles_m * (qy + 1)) >> lgy) - (((long)tb.prob[c].tiles_m * qy) >> lgy));
+          tb.end[qy][c] = run;
+        } else {
+          tb.end[qy][c] = 0x7fffffff;
+        }
+      }
+    }
+  }
+  return blk;
+}
+
+int launch_conv_multi(const ConvGemmParams& p, int variant, long grid, void* stream) {
+  if (variant < 0 || variant >= kNumVariants || !kVariants[variant].kernel_mp || !p.multi || p.nprob < 1 || grid <= 0) return (int)hipErrorInvalidValue;
+  const VariantEntry& e = kVariants[variant];
+  const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
+  hipLaunchKernelGGL(e.kernel_mp, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }
 

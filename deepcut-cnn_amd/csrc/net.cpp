@@ -2459,6 +2459,20 @@ void Net::forward_images(const unsigned char* bgr, int n, int h, int w, double s
                          float* next, double* pose, void* user_stream) {
   if (Context::get().mode != DC_MODE_GPU)
     throw DcError(DC_ENOCPU, "forward_images() in CPU mode: libdeepcut_hip provides the MI355X path only");
+  const bool own_async = user_stream == (void*)-1;
+  if (own_async) user_stream = nullptr;
+  // (the net's own stream exists only after ensure_device(): prep_images resolves a null `s` to it)
+  prep_images(bgr, n, h, w, scale, is_device, user_stream);
+  void* s = user_stream ? user_stream : stream;
+  enqueue_plan(s);
+  emit_maps(prob, loc, next, is_device, s);
+  if (pose) {
+    decode_pose(scale, pose, is_device, (user_stream || own_async) ? s : nullptr);
+  }
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+void Net::prep_images(const unsigned char* bgr, int n, int h, int w, double scale, bool is_device, void* s) {
   if (n <= 0 || h <= 0 || w <= 0 || !(scale > 0)) throw DcError(DC_EINVAL, "forward_images: n, height, width and scale must be positive");
   int out_h, out_w, new_h, new_w;
   image_canvas_size(h, w, scale, out_h, out_w, new_h, new_w);
@@ -2467,9 +2481,7 @@ void Net::forward_images(const unsigned char* bgr, int n, int h, int w, double s
                                  std::to_string(w) + " image");
   Storage& in = begin_batch(n, out_h, out_w);
   if (in.dim(1) != 3) throw DcError(DC_ESHAPE, "forward_images needs a 3-channel input blob");
-  const bool own_async = user_stream == (void*)-1;
-  if (own_async) user_stream = nullptr;
-  void* s = user_stream ? user_stream : stream;
+  if (!s) s = stream;
   const int kPad = 64;
   const int ph = h + kPad, pw = w + kPad;              // the replicate-padded image (never materialised)
   const int use_h = std::min(out_h, new_h), use_w = std::min(out_w, new_w);  // part of the resized image on the canvas
@@ -2518,12 +2530,6 @@ void Net::forward_images(const unsigned char* bgr, int n, int h, int w, double s
   }
   KCHECK(launch_image_prep(q, s));
   in.head = HEAD_AT_GPU;
-  enqueue_plan(s);
-  emit_maps(prob, loc, next, is_device, s);
-  if (pose) {
-    decode_pose(scale, pose, is_device, (user_stream || own_async) ? s : nullptr);
-  }
-  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
 // _pose_from_mats (python/pose/estimate_pose.py:131-143) on the device: reads the `prob` and `loc_pred`
@@ -2758,6 +2764,439 @@ std::string Net::debug_info_text() {
       std::snprintf(buf, sizeof buf, "    [Forward] Layer %s, param blob %s data: %g\n", L.name.c_str(), pname.c_str(), n ? a / (double)n : 0.0);
       os << buf;
     }
+  }
+  return os.str();
+}
+
+// ---- NetGroup: the same model over several tensors as ONE launch sequence (net.h) ---------------------------------------
+NetGroup* NetGroup::create(const std::vector<Net*>& members) {
+  if (members.empty()) throw DcError(DC_EINVAL, "a group needs at least one net");
+  for (Net* n : members) {
+    if (!n) throw DcError(DC_EINVAL, "null net in group");
+    if (n->shared != members[0]->shared)
+      throw DcError(DC_EINVAL, "the members of a group must be executors of ONE model: a net and its clones (dc_net_clone)");
+    if (n->dtype != members[0]->dtype || n->fuse != members[0]->fuse)
+      throw DcError(DC_EINVAL, "the members of a group must agree on DC_OPT_DTYPE and DC_OPT_FUSE");
+    if (n->inputs.size() != 1) throw DcError(DC_EINVAL, "group members must be single-input nets");
+  }
+  for (size_t i = 0; i < members.size(); ++i)
+    for (size_t j = i + 1; j < members.size(); ++j)
+      if (members[i] == members[j]) throw DcError(DC_EINVAL, "the same net twice in a group (every member needs its own activations: clone it)");
+  std::unique_ptr<NetGroup> g(new NetGroup());
+  g->nets = members;
+  return g.release();
+}
+
+void* NetGroup::stream() { return nets[0]->stream; }
+
+void NetGroup::drop_plan(GroupPlan& gp) {
+  // nothing enqueued may still read the tables or replay the graph
+  for (Net* n : nets)
+    if (n->stream) (void)hipStreamSynchronize((hipStream_t)n->stream);
+  (void)hipDeviceSynchronize();
+  if (gp.graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)gp.graph_exec);
+  gp.graph_exec = nullptr;
+  if (gp.tables_dev) (void)hipFree(gp.tables_dev);
+  gp.tables_dev = nullptr;
+}
+
+NetGroup::~NetGroup() {
+  for (auto& gp : plans_) drop_plan(*gp);
+  if (scratch_table_) (void)hipFree(scratch_table_);
+}
+
+// The merged plan of the members' CURRENT shapes (every member has been through begin_batch: its plan is active, its
+// buffers allocated, its filter images uploaded, its own tiles chosen).
+GroupPlan& NetGroup::ensure_plan() {
+  std::vector<std::vector<int>> shapes;
+  for (Net* n : nets) shapes.push_back(n->plan_input_shape);
+  GroupPlan* hit = nullptr;
+  for (auto& gp : plans_)
+    if (gp->shapes == shapes) hit = gp.get();
+  if (hit) {
+    bool stale = false;
+    for (size_t c = 0; c < nets.size(); ++c)
+      if (hit->lowerings[c] != (uint64_t)nets[c]->stats.lowerings || hit->buf_gens[c] != nets[c]->buf_gen_ ||
+          hit->weight_gens[c] != nets[c]->seen_weights_gen)
+        stale = true;
+    if (!stale) {
+      hit->last_use = ++use_clock_;
+      ++stats.plan_hits;
+      return *hit;
+    }
+    drop_plan(*hit);  // a member re-lowered (weights, options) or reallocated a buffer: merge again (tile choices are cached)
+    hit->launches.clear();
+    hit->tuned = false;
+    merge(*hit);
+    hit->last_use = ++use_clock_;
+    return *hit;
+  }
+  static const size_t cap = (size_t)std::max(1, env_int("DC_GROUP_PLAN_CACHE", 8));
+  while (plans_.size() >= cap) {
+    size_t lru = 0;
+    for (size_t i = 1; i < plans_.size(); ++i)
+      if (plans_[i]->last_use < plans_[lru]->last_use) lru = i;
+    drop_plan(*plans_[lru]);
+    plans_.erase(plans_.begin() + lru);
+  }
+  plans_.emplace_back(new GroupPlan());
+  GroupPlan& gp = *plans_.back();
+  gp.shapes = shapes;
+  merge(gp);
+  gp.last_use = ++use_clock_;
+  return gp;
+}
+
+void NetGroup::merge(GroupPlan& gp) {
+  const size_t NM = nets.size();
+  gp.lowerings.resize(NM), gp.buf_gens.resize(NM), gp.weight_gens.resize(NM);
+  for (size_t c = 0; c < NM; ++c) {
+    gp.lowerings[c] = (uint64_t)nets[c]->stats.lowerings;
+    gp.buf_gens[c] = nets[c]->buf_gen_;
+    gp.weight_gens[c] = nets[c]->seen_weights_gen;
+  }
+  ++stats.merges;
+  gp.flops = 0;
+  for (Net* n : nets) gp.flops += n->plan_flops;
+  const size_t NL = nets[0]->plan.size();
+  for (Net* n : nets)
+    if (n->plan.size() != NL) throw DcError(DC_EINVAL, "group: the members' plans differ in length (different fusion options or graphs?)");
+  const bool grouping = env_int("DC_GROUP", 1) != 0;  // 0: every launch member by member (A/B of the merge itself)
+  std::vector<ConvMultiTable> tables;
+  for (size_t i = 0; i < NL; ++i) {
+    const Launch& l0 = nets[0]->plan[i];
+    bool mergeable = grouping && l0.kind == Launch::CONV && NM >= 1;
+    for (size_t c = 0; c < NM && mergeable; ++c) {
+      const Launch& l = nets[c]->plan[i];
+      const ConvGemmParams &g = l.cg, &g0 = l0.cg;
+      if (l.kind != Launch::CONV || l.variant == kWinoVariant || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift ||
+          (l.in2 >= 0) != (l0.in2 >= 0) || g.esize != g0.esize || g.klen != g0.klen || g.sy != g0.sy || g.sx != g0.sx || g.Cout != g0.Cout ||
+          g.relu != g0.relu || g.sigmoid_ch != g0.sigmoid_ch)
+        mergeable = false;
+    }
+    if (mergeable) {
+      // a multi-problem tile must exist for this K granularity
+      bool have = false;
+      for (int v = 0; v < conv_num_variants(); ++v)
+        if (conv_variant_multiproblem(v) && l0.cg.klen % conv_variant_bk(v) == 0 && conv_variant_esize(v) == l0.cg.esize) have = true;
+      mergeable = have;
+    }
+    if (!mergeable) {
+      for (size_t c = 0; c < NM; ++c) {
+        if (nets[c]->plan[i].kind != l0.kind) throw DcError(DC_EINVAL, "group: the members' plans differ at launch " + std::to_string(i));
+        GroupLaunch gl;
+        gl.multi = false;
+        gl.index = (int)i;
+        gl.member = (int)c;
+        gl.label = nets[c]->plan[i].label;
+        gp.launches.push_back(std::move(gl));
+      }
+      continue;
+    }
+    // the problems: per member, its single problem or its deconvolution classes; heaviest K first, then the most pixels
+    struct Rec {
+      ConvProblem q;
+      int member;
+      std::string key;
+    };
+    std::vector<Rec> recs;
+    std::string keys;
+    for (size_t c = 0; c < NM; ++c) {
+      Net& n = *nets[c];
+      const Launch& l = n.plan[i];
+      const ConvGemmParams& g = l.cg;
+      Storage& X = *n.storages[l.in];
+      Storage& Y = *n.storages[l.out];
+      const int nc = g.ncls > 1 ? g.ncls : 1;
+      for (int k = 0; k < nc; ++k) {
+        ConvProblem q{};
+        const long yo = g.ncls > 1 ? g.cls[k].y_off : l.y_off;
+        q.x = X.dev;
+        q.y = Y.dev_at(yo);
+        q.resid = l.in2 >= 0 ? n.storages[l.in2]->dev_at(yo) : nullptr;
+        q.x_img_stride = g.x_img_stride, q.y_img_stride = g.y_img_stride;
+        q.x_row_stride = g.x_row_stride, q.x_rows = g.x_rows, q.x_rowlen = g.x_rowlen;
+        q.y_row_stride = g.y_row_stride, q.y_pix_stride = g.y_pix_stride;
+        q.NB = g.NB;
+        if (g.ncls > 1) {
+          const ConvClass& cl = g.cls[k];
+          q.w_off = cl.w_off;
+          q.nty = cl.nty, q.ntx = cl.ntx, q.dy0 = cl.dy0, q.ddy = cl.ddy, q.x0 = cl.x0, q.ddx = cl.ddx, q.Ktot = cl.Ktot;
+          q.OH = cl.OH, q.OW = cl.OW, q.M = cl.M;
+        } else {
+          q.w_off = 0;
+          q.nty = g.nty, q.ntx = g.ntx, q.dy0 = g.dy0, q.ddy = g.ddy, q.x0 = g.x0, q.ddx = g.ddx, q.Ktot = g.Ktot;
+          q.OH = g.OH, q.OW = g.OW, q.M = g.M;
+        }
+        recs.push_back({q, (int)c, std::string()});
+      }
+      keys += (c ? "|" : "") + n.tune_key(l);
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.q.Ktot != b.q.Ktot ? a.q.Ktot > b.q.Ktot : a.q.M > b.q.M; });
+    for (size_t r0 = 0, part = 0; r0 < recs.size(); r0 += kMaxProblems, ++part) {
+      GroupLaunch gl;
+      gl.multi = true;
+      gl.index = (int)i;
+      gl.nprob = (int)std::min<size_t>(kMaxProblems, recs.size() - r0);
+      gl.p = l0.cg;  // the layer's common fields: esize, klen, sy, sx, Cout, relu, sigmoid_ch
+      gl.p.ncls = 0;
+      gl.p.dbg = nullptr;
+      gl.p.x = nullptr, gl.p.y = nullptr, gl.p.resid = nullptr;
+      gl.p.w = l0.w->dev;
+      gl.p.scale = l0.scale ? l0.scale->dev : nullptr;
+      gl.p.shift = l0.shift ? l0.shift->dev : nullptr;
+      for (int k = 0; k < gl.nprob; ++k) {
+        gl.table.prob[k] = recs[r0 + k].q;
+        gl.prob_member.push_back(recs[r0 + k].member);
+        gl.flops += 2.0 * recs[r0 + k].q.M * (double)gl.p.Cout * recs[r0 + k].q.Ktot;
+      }
+      gl.key = "G" + std::to_string(gl.nprob) + (recs.size() > (size_t)kMaxProblems ? "p" + std::to_string(part) : "") + ":" + keys;
+      gl.label = l0.label + " x" + std::to_string(NM) + (gl.nprob != (int)NM ? " [" + std::to_string(gl.nprob) + " problems]" : "");
+      gl.table_slot = tables.size();
+      tables.emplace_back();
+      gp.launches.push_back(std::move(gl));
+    }
+  }
+  gp.ntables = tables.size();
+  if (gp.ntables) HIPCHECK(hipMalloc((void**)&gp.tables_dev, gp.ntables * sizeof(ConvMultiTable)));
+  // tile of every merged launch: the shared choice table, else (until the group is timed) the widest member's own tile
+  {
+    std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
+    for (auto& gl : gp.launches) {
+      if (!gl.multi) continue;
+      auto it = nets[0]->shared->tune_cache.find(gl.key);
+      int v = it != nets[0]->shared->tune_cache.end() ? it->second : -1;
+      const int forced = env_int("DC_CONV_VARIANT", -1);
+      if (forced >= 0 && forced < conv_num_variants() && conv_variant_multiproblem(forced) && gl.p.klen % conv_variant_bk(forced) == 0 &&
+          conv_variant_esize(forced) == gl.p.esize)
+        v = forced;
+      gl.variant = v;
+    }
+  }
+  for (auto& gl : gp.launches) {
+    if (!gl.multi) continue;
+    int v = gl.variant;
+    auto usable = [&](int cand) {
+      if (cand < 0 || cand >= conv_num_variants() || cand == kWinoVariant) return false;
+      ConvGemmParams p = gl.p;
+      ConvMultiTable t = gl.table;
+      return prepare_conv_multi(p, t, gl.nprob, cand) > 0;
+    };
+    if (!usable(v)) {
+      v = -1;
+      size_t big = 0;  // the member with the most pixels
+      for (size_t c = 1; c < NM; ++c)
+        if (nets[c]->plan[gl.index].cg.M > nets[big]->plan[gl.index].cg.M) big = c;
+      if (usable(nets[big]->plan[gl.index].variant)) v = nets[big]->plan[gl.index].variant;
+      for (int cand = 0; v < 0 && cand < conv_num_variants(); ++cand)
+        if (usable(cand)) v = cand;
+      if (v < 0) throw DcError(DC_EUNSUP, "group launch '" + gl.label + "': no multi-problem tile takes it");
+    }
+    apply_variant(gp, gl, v);
+  }
+}
+
+// prepare the launch for a tile and put its table into the plan's device array
+void NetGroup::apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant) {
+  ConvMultiTable t = gl.table;
+  ConvGemmParams p = gl.p;
+  const long grid = prepare_conv_multi(p, t, gl.nprob, variant);
+  if (grid <= 0) throw DcError(DC_EUNSUP, "group launch '" + gl.label + "': tile " + conv_variant(variant).name + " cannot take it");
+  ConvMultiTable* dst = gp.tables_dev + gl.table_slot;
+  HIPCHECK(hipMemcpy(dst, &t, sizeof t, hipMemcpyHostToDevice));
+  p.multi = dst;
+  gl.p = p;
+  gl.variant = variant;
+  gl.grid = grid;
+}
+
+// Tile of every merged launch by measurement, once per distinct signature (shared with every group of the model through
+// the model's choice table, persisted with DC_TUNE_CACHE like the single-problem choices).
+void NetGroup::autotune(GroupPlan& gp) {
+  gp.tuned = true;
+  if (env_int("DC_AUTOTUNE", 1) == 0 || env_int("DC_CONV_VARIANT", -1) >= 0) return;
+  Net& n0 = *nets[0];
+  std::lock_guard<std::mutex> lk(n0.shared->mu);
+  std::map<std::string, int>& cache = n0.shared->tune_cache;
+  bool timed_any = false;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct EvGuard {
+    hipEvent_t &a, &b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } guard{e0, e1};
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  if (!scratch_table_) HIPCHECK(hipMalloc((void**)&scratch_table_, sizeof(ConvMultiTable)));
+  void* s = stream();
+  for (auto& gl : gp.launches) {
+    if (!gl.multi || cache.count(gl.key)) continue;
+    timed_any = true;
+    std::vector<std::pair<float, int>> c;
+    for (int v = 0; v < conv_num_variants(); ++v) {
+      if (!conv_variant_multiproblem(v) || gl.p.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != gl.p.esize) continue;
+      ConvMultiTable t = gl.table;
+      ConvGemmParams p = gl.p;
+      const long grid = prepare_conv_multi(p, t, gl.nprob, v);
+      if (grid <= 0) continue;
+      HIPCHECK(hipMemcpy(scratch_table_, &t, sizeof t, hipMemcpyHostToDevice));
+      p.multi = scratch_table_;
+      KCHECK(launch_conv_multi(p, v, grid, s));  // warm
+      float ms = 1e30f;
+      for (int t2 = 0; t2 < 2; ++t2) {
+        HIPCHECK(hipEventRecord(e0, (hipStream_t)s));
+        for (int r = 0; r < 3; ++r) KCHECK(launch_conv_multi(p, v, grid, s));
+        HIPCHECK(hipEventRecord(e1, (hipStream_t)s));
+        HIPCHECK(hipEventSynchronize(e1));
+        float m2 = 0;
+        HIPCHECK(hipEventElapsedTime(&m2, e0, e1));
+        ms = std::min(ms, m2);
+      }
+      c.push_back({ms, v});
+    }
+    std::sort(c.begin(), c.end());
+    if (!c.empty()) {
+      cache[gl.key] = c.front().second;
+      for (auto& tm : c) tm.first *= 5.f / 3.f;  // the report prints "ms of a 5-launch burst"
+      n0.shared->tune_timings[gl.key] = c;
+    }
+  }
+  for (auto& gl : gp.launches) {
+    if (!gl.multi) continue;
+    auto it = cache.find(gl.key);
+    if (it != cache.end() && it->second != gl.variant) apply_variant(gp, gl, it->second);
+  }
+  if (timed_any) {
+    ++stats.autotune_runs;
+    write_tune_cache_locked(*n0.shared);
+  }
+  if (gp.graph_exec) {
+    (void)hipGraphExecDestroy((hipGraphExec_t)gp.graph_exec);
+    gp.graph_exec = nullptr;
+  }
+}
+
+void NetGroup::run(GroupPlan& gp, void* s) {
+  for (auto& gl : gp.launches) {
+    if (gl.multi) {
+      const int rc = launch_conv_multi(gl.p, gl.variant, gl.grid, s);
+      if (rc != 0) throw DcError(DC_EDEVICE, "group launch '" + gl.label + "' failed: " + hipGetErrorString((hipError_t)rc));
+    } else {
+      Net& n = *nets[gl.member];
+      n.run_launch(n.plan[gl.index], s);
+    }
+  }
+}
+
+void NetGroup::enqueue(void* s) {
+  GroupPlan& gp = ensure_plan();
+  cur_ = &gp;
+  if (!gp.tuned) {
+    HIPCHECK(hipStreamSynchronize((hipStream_t)s));  // the inputs are in place; the timing launches run on the group's own stream
+    autotune(gp);
+  }
+  bool use_graph = true;
+  for (Net* n : nets) use_graph = use_graph && n->use_graph;
+  if (use_graph) {
+    if (!gp.graph_exec) {
+      hipGraph_t graph;
+      void* cs = stream();
+      HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
+      try {
+        run(gp, cs);
+      } catch (...) {
+        hipGraph_t g2;
+        (void)hipStreamEndCapture((hipStream_t)cs, &g2);
+        throw;
+      }
+      HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
+      hipGraphExec_t ge;
+      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      gp.graph_exec = ge;
+      ++stats.graph_instantiations;
+    }
+    HIPCHECK(hipGraphLaunch((hipGraphExec_t)gp.graph_exec, (hipStream_t)s));
+  } else {
+    run(gp, s);
+  }
+  for (Net* n : nets) {
+    for (auto& l : n->plan) n->storages[l.out]->head = HEAD_AT_GPU;
+    for (int v : n->plan_views_) n->storages[v]->head = HEAD_AT_GPU;
+  }
+}
+
+void NetGroup::forward_batch(const float* const* inputs, const int* n, const int* h, const int* w, bool is_device, float* const* prob,
+                             float* const* loc, float* const* next, void* user_stream) {
+  if (!inputs || !n || !h || !w) throw DcError(DC_EINVAL, "group forward: null argument");
+  const bool own_async = user_stream == (void*)-1;
+  if (own_async) user_stream = nullptr;
+  std::vector<Storage*> ins;
+  for (size_t c = 0; c < nets.size(); ++c) ins.push_back(&nets[c]->begin_batch(n[c], h[c], w[c]));
+  void* s = user_stream ? user_stream : stream();
+  for (size_t c = 0; c < nets.size(); ++c) {
+    Storage& in = *ins[c];
+    const int C = in.dim(1);
+    if (is_device) {
+      KCHECK(launch_nchw_to_nhwc(inputs[c], in.dev, in.esize, n[c], C, h[c], w[c], in.cp(), s));
+    } else {
+      in.ensure_stage(in.count());
+      HIPCHECK(hipMemcpyAsync(in.stage, inputs[c], in.count() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s));
+      KCHECK(launch_nchw_to_nhwc(in.stage, in.dev, in.esize, n[c], C, h[c], w[c], in.cp(), s));
+    }
+    in.head = HEAD_AT_GPU;
+  }
+  enqueue(s);
+  for (size_t c = 0; c < nets.size(); ++c)
+    nets[c]->emit_maps(prob ? prob[c] : nullptr, loc ? loc[c] : nullptr, next ? next[c] : nullptr, is_device, s);
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+void NetGroup::forward_images(const unsigned char* const* bgr, const int* n, const int* h, const int* w, const double* scale, bool is_device,
+                              float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream) {
+  if (!bgr || !n || !h || !w || !scale) throw DcError(DC_EINVAL, "group forward_images: null argument");
+  if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "forward_images() in CPU mode: libdeepcut_hip provides the MI355X path only");
+  const bool own_async = user_stream == (void*)-1;
+  if (own_async) user_stream = nullptr;
+  nets[0]->ensure_device();
+  void* s = user_stream ? user_stream : stream();
+  for (size_t c = 0; c < nets.size(); ++c) nets[c]->prep_images(bgr[c], n[c], h[c], w[c], scale[c], is_device, s);
+  enqueue(s);
+  for (size_t c = 0; c < nets.size(); ++c) {
+    nets[c]->emit_maps(prob ? prob[c] : nullptr, loc ? loc[c] : nullptr, next ? next[c] : nullptr, is_device, s);
+    // decode on the group's stream; a host destination synchronises inside (the maps are complete there: same stream)
+    if (pose && pose[c]) nets[c]->decode_pose(scale[c], pose[c], is_device, s);
+  }
+  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+}
+
+int NetGroup::num_launches() { return cur_ ? (int)cur_->launches.size() : 0; }
+int NetGroup::num_multi_launches() {
+  int m = 0;
+  if (cur_)
+    for (auto& gl : cur_->launches) m += gl.multi ? 1 : 0;
+  return m;
+}
+double NetGroup::flops() { return cur_ ? cur_->flops : 0.0; }
+
+std::string NetGroup::plan_text() {
+  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
+  std::ostringstream os;
+  int multi = 0;
+  for (auto& gl : cur_->launches) multi += gl.multi ? 1 : 0;
+  os << "group of " << nets.size() << " executors: " << cur_->launches.size() << " launches (" << multi << " multi-problem), "
+     << cur_->flops / 1e9 << " GFLOP\n";
+  int i = 0;
+  for (auto& gl : cur_->launches) {
+    char buf[512];
+    if (gl.multi)
+      std::snprintf(buf, sizeof buf, "%4d  conv_gemm_mp<%s>  problems=%d grid=%ld  %s\n", i, conv_variant(gl.variant).name, gl.nprob, gl.grid, gl.label.c_str());
+    else
+      std::snprintf(buf, sizeof buf, "%4d  member %d: %s  %s\n", i, gl.member, nets[gl.member]->plan[gl.index].kernel.c_str(), gl.label.c_str());
+    os << buf;
+    ++i;
   }
   return os.str();
 }

@@ -266,6 +266,9 @@ struct Net {
   // multi-person consumers of the maps of the last forward (encoding: pose_data_layer.cpp:686-802)
   void detect_parts(double scale, float thr, int radius, int max_det, int* counts, double* dets);
   void decode_pairwise(double scale, int ndet, const int* det, const double* mean, const double* stdev, double* out);
+  // front half of forward_images: the uint8 pixels -> the network's NHWC input image, enqueued on s (the plan of the canvas
+  // shape is active afterwards); returns the canvas height / width
+  void prep_images(const unsigned char* bgr, int n, int h, int w, double scale, bool is_device, void* s);
   std::string plan_text();
   std::string profile_text(int iters);
   std::string tune_report_text();  // per GEMM signature of the current plan: tile in use, launches, the isolated timings of autotune
@@ -274,6 +277,7 @@ struct Net {
   int layer_index(const std::string& name) const;
 
  private:
+  friend struct NetGroup;
   void init_from(const TextMsg& root);
   void setup_layer(LayerRec& L);
   void reshape_layer(LayerRec& L);
@@ -304,6 +308,76 @@ struct Net {
   size_t img_cap_ = 0;
   unsigned char* tmp_dev_ = nullptr;  // horizontally resampled rows
   size_t tmp_cap_ = 0;
+};
+
+// ---- pyramid-grouped execution (round 4) ---------------------------------------------------------------------------------
+// The demo runs the scales of an image pyramid one forward after the other (python/pose/estimate_pose.py:81-128), the
+// reference one SGEMM per image and layer (base_conv_layer.cpp:326-341): four launches per layer over the SAME filters, each
+// starting on L2s that hold neither its filters nor its input, each with its own dispatch ramp and tail.  A NetGroup runs
+// several executors of ONE model (a net and its clones, each at its own input shape) as ONE launch sequence: launch i of
+// the group is launch i of every member's plan merged into a multi-problem gather-GEMM (kernels.h ConvProblem) — the
+// residue classes of the deconvolution heads become problems too —, so a 4-scale pyramid is 158 launches instead of 632.
+// Members keep their blobs, plans and tile choices: a member can still be run alone.  Launches that cannot merge (Winograd
+// form, max-pool, stand-alone element-wise layers) run member by member inside the same sequence.
+struct GroupLaunch {
+  bool multi = false;
+  int index = 0;              // index into every member's plan
+  int member = -1;            // !multi: the member whose launch `index` this is
+  ConvGemmParams p{};         // multi: the prepared common block (p.multi = device table)
+  ConvMultiTable table{};     // host copy (pointers filled, not yet prepared for a variant)
+  int nprob = 0;
+  int variant = -1;
+  long grid = 0;
+  std::string key, label;
+  double flops = 0;
+  size_t table_slot = 0;      // which ConvMultiTable of the plan's device array
+  std::vector<int> prob_member;  // per problem: the member it belongs to (diagnostics)
+};
+struct GroupPlan {
+  std::vector<std::vector<int>> shapes;   // per member: its input shape
+  std::vector<uint64_t> lowerings, buf_gens, weight_gens;  // per member, when the plan was merged
+  std::vector<GroupLaunch> launches;
+  ConvMultiTable* tables_dev = nullptr;   // one device array for all multi launches
+  size_t ntables = 0;
+  void* graph_exec = nullptr;
+  bool tuned = false;
+  uint64_t last_use = 0;
+  double flops = 0;
+};
+struct GroupStats {
+  long long merges = 0, graph_instantiations = 0, autotune_runs = 0, plan_hits = 0;
+};
+struct NetGroup {
+  std::vector<Net*> nets;  // borrowed: executors of one model (a net and its clones), alive as long as the group
+  GroupStats stats;
+  std::string text_buf;
+  ~NetGroup();
+  static NetGroup* create(const std::vector<Net*>& members);
+  // one batch per member (member c gets inputs[c] of n[c] x 3 x h[c] x w[c]); pointers as Net::forward_batch
+  void forward_batch(const float* const* inputs, const int* n, const int* h, const int* w, bool is_device, float* const* prob,
+                     float* const* loc, float* const* next, void* user_stream);
+  // image entry: member c pre-processes n[c] images of h[c] x w[c] at scale[c] (Net::forward_images), then ONE grouped
+  // forward, then per member the maps / the decoded pose
+  void forward_images(const unsigned char* const* bgr, const int* n, const int* h, const int* w, const double* scale, bool is_device,
+                      float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream);
+  std::string plan_text();
+  int num_launches();
+  int num_multi_launches();
+  double flops();
+
+ private:
+  std::vector<std::unique_ptr<GroupPlan>> plans_;
+  GroupPlan* cur_ = nullptr;
+  uint64_t use_clock_ = 0;
+  ConvMultiTable* scratch_table_ = nullptr;  // autotuning
+  GroupPlan& ensure_plan();   // after every member's begin_batch: the merged plan of the members' current shapes
+  void merge(GroupPlan& gp);
+  void autotune(GroupPlan& gp);
+  void apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant);
+  void run(GroupPlan& gp, void* s);
+  void enqueue(void* s);
+  void drop_plan(GroupPlan& gp);
+  void* stream();
 };
 
 }  // namespace dc

@@ -111,6 +111,16 @@ def _load():
         "dc_net_debug_info": (cp, [vp]),
         "dc_net_tune_report": (cp, [vp]),
         "dc_net_set_tile": (ci, [vp, cp, cp]),
+        "dc_group_create": (ci, [C.POINTER(vp), ci, C.POINTER(vp)]),
+        "dc_group_destroy": (ci, [vp]),
+        "dc_group_size": (ci, [vp]),
+        "dc_group_forward_batch": (ci, [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(vp), C.POINTER(vp),
+                                        C.POINTER(vp), vp]),
+        "dc_group_forward_images": (ci, [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_double), ci,
+                                         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
+        "dc_group_plan_text": (cp, [vp]),
+        "dc_group_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
+        "dc_group_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_conv_variant_count": (ci, []),
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
@@ -589,3 +599,138 @@ class Net(object):
         if t is None:
             raise DeepcutError(-1, (_lib.dc_last_error() or b"").decode())
         return t.decode()
+
+
+class NetGroup(object):
+    """Several executors of ONE model (a net and its clones), each at its own input shape, run as ONE launch sequence
+    (dc_group_*): launch i of the group is launch i of every member merged into a multi-problem gather-GEMM.  The scale
+    loop of the demo (python/pose/estimate_pose.py:81-128) as one forward: `NetGroup.for_shapes(net, [(8, 272, 368), ...])`.
+    Members stay usable on their own; after a grouped forward their blobs hold the results (decode_pose, detect_parts,
+    emit_maps_device on a member see them)."""
+
+    STAT_NAMES = ("merges", "graph_instantiations", "autotune_runs", "plan_hits", "launches", "multi_launches")
+
+    def __init__(self, nets):
+        self.nets = list(nets)
+        arr = (C.c_void_p * len(self.nets))(*[n._h for n in self.nets])
+        h = C.c_void_p()
+        _check(_lib.dc_group_create(arr, len(self.nets), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.dc_group_destroy(h)  # (the members are kept alive by self.nets until here)
+
+    @classmethod
+    def for_shapes(cls, net, shapes):
+        """`net` and len(shapes) - 1 clones, member c reserved at shapes[c] = (n, h, w)."""
+        nets = [net] + [net.clone() for _ in shapes[1:]]
+        for m, (n, h, w) in zip(nets, shapes):
+            m.reserve(n, h, w)
+        return cls(nets)
+
+    def __len__(self):
+        return len(self.nets)
+
+    @staticmethod
+    def _ptrs(ps, k):
+        if ps is None:
+            return None
+        return (C.c_void_p * k)(*[C.c_void_p(p or 0) for p in ps])
+
+    @staticmethod
+    def _ints(v):
+        return (C.c_int * len(v))(*[int(x) for x in v])
+
+    def forward_device(self, in_ptrs, shapes, prob_ptrs=None, loc_ptrs=None, next_ptrs=None, stream=None):
+        """Device-resident: member c forwards the NCHW float32 batch at in_ptrs[c] of shapes[c] = (n, h, w); output
+        pointer lists (or entries) may be None.  Asynchronous on `stream` when given ("own" = the first member's)."""
+        if stream == "own":
+            stream = C.c_void_p(-1).value
+        k = len(self.nets)
+        if len(in_ptrs) != k or len(shapes) != k:
+            raise ValueError("one input and one shape per group member")
+        _check(_lib.dc_group_forward_batch(self._h, self._ptrs(in_ptrs, k), self._ints([s[0] for s in shapes]), self._ints([s[1] for s in shapes]),
+                                           self._ints([s[2] for s in shapes]), 1, self._ptrs(prob_ptrs, k), self._ptrs(loc_ptrs, k),
+                                           self._ptrs(next_ptrs, k), C.c_void_p(stream or 0)))
+
+    def forward_batch(self, images, want=("prob", "loc_pred", "next_pred")):
+        """images: one float32 [n,3,H,W] host array per member -> one dict of NCHW host arrays per member."""
+        k = len(self.nets)
+        xs = [np.ascontiguousarray(x, dtype=np.float32) for x in images]
+        if len(xs) != k:
+            raise ValueError("one batch per group member")
+        outs = []
+        for m, x in zip(self.nets, xs):
+            n, c, h, w = x.shape
+            m.blobs["data"].reshape(n, c, h, w)
+            m.reshape()
+            outs.append({key: m._out_array(key, m.blobs[key].shape) for key in ("prob", "loc_pred", "next_pred") if key in want})
+
+        def col(key):
+            return self._ptrs([o[key].ctypes.data if key in o else None for o in outs], k)
+
+        _check(_lib.dc_group_forward_batch(self._h, self._ptrs([x.ctypes.data for x in xs], k), self._ints([x.shape[0] for x in xs]),
+                                           self._ints([x.shape[2] for x in xs]), self._ints([x.shape[3] for x in xs]), 0, col("prob"),
+                                           col("loc_pred"), col("next_pred"), None))
+        return outs
+
+    def forward_images(self, images, scales, want=("prob", "loc_pred"), pose=True):
+        """images: ONE uint8 [n,H,W,3] BGR host array (every member sees it, member c at scales[c] — the demo's pyramid), or a
+        list of one array per member.  -> one dict per member with the requested maps and "pose" [n,5,J]."""
+        k = len(self.nets)
+        if isinstance(images, np.ndarray):
+            images = [images] * k
+        xs = [np.ascontiguousarray(x, dtype=np.uint8) for x in images]
+        xs = [x[None] if x.ndim == 3 else x for x in xs]
+        if len(xs) != k or len(scales) != k:
+            raise ValueError("one image batch and one scale per group member")
+        outs = []
+        for m, x, sc in zip(self.nets, xs, scales):
+            n, h, w, _ = x.shape
+            ch, cw = canvas_size(h, w, sc)
+            m.blobs["data"].reshape(n, 3, ch, cw)
+            m.reshape()
+            o = {key: m._out_array(key, m.blobs[key].shape) for key in ("prob", "loc_pred", "next_pred") if key in want}
+            if pose:
+                o["pose"] = np.empty((n, 5, m.blobs["prob"].shape[1]), np.float64)
+            outs.append(o)
+
+        def col(key):
+            return self._ptrs([o[key].ctypes.data if key in o else None for o in outs], k)
+
+        _check(_lib.dc_group_forward_images(self._h, self._ptrs([x.ctypes.data for x in xs], k), self._ints([x.shape[0] for x in xs]),
+                                            self._ints([x.shape[1] for x in xs]), self._ints([x.shape[2] for x in xs]),
+                                            (C.c_double * k)(*[float(s) for s in scales]), 0, col("prob"), col("loc_pred"), col("next_pred"),
+                                            col("pose"), None))
+        return outs
+
+    def forward_images_device(self, img_ptrs, shapes, scales, prob_ptrs=None, loc_ptrs=None, next_ptrs=None, pose_ptrs=None, stream=None):
+        """Device-resident form: img_ptrs[c] -> uint8 [n,H,W,3] of shapes[c] = (n, H, W) at scales[c]."""
+        if stream == "own":
+            stream = C.c_void_p(-1).value
+        k = len(self.nets)
+        _check(_lib.dc_group_forward_images(self._h, self._ptrs(img_ptrs, k), self._ints([s[0] for s in shapes]), self._ints([s[1] for s in shapes]),
+                                            self._ints([s[2] for s in shapes]), (C.c_double * k)(*[float(s) for s in scales]), 1,
+                                            self._ptrs(prob_ptrs, k), self._ptrs(loc_ptrs, k), self._ptrs(next_ptrs, k), self._ptrs(pose_ptrs, k),
+                                            C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        self.nets[0].synchronize()
+
+    def plan_text(self):
+        t = _lib.dc_group_plan_text(self._h)
+        if t is None:
+            _check(-1)
+        return t.decode()
+
+    def stats(self):
+        v = (C.c_longlong * len(self.STAT_NAMES))()
+        _check(_lib.dc_group_stats(self._h, v, len(self.STAT_NAMES)))
+        return dict(zip(self.STAT_NAMES, [int(x) for x in v]))
+
+    def flops(self):
+        f = C.c_double()
+        _check(_lib.dc_group_flops(self._h, C.byref(f)))
+        return f.value

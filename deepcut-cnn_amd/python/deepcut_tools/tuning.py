@@ -18,6 +18,14 @@ def tune_in_flight(nets, run, top=6, margin=1.20, min_gain=0.01, reps=3, max_can
     run(): enqueue the representative load on the executors, synchronise, return the wall seconds.
     Returns {"before": s, "after": s, "changed": [(signature, old tile, new tile, seconds before, seconds after)], "runs": n,
              "skipped": signatures left alone because no isolated timings exist for them (tiles read from a DC_TUNE_CACHE file)}."""
+    runs = [0]
+
+    def measure():
+        run()  # re-captures the graphs a tile change dropped; not timed
+        runs[0] += reps + 1
+        return min(run() for _ in range(reps))
+
+    before = incumbent = measure()  # first: an executor that has not met the shape yet lowers it here (its report is empty before)
     report = nets[0].tune_report()
     have = [set(s["signature"] for s in n.tune_report()) for n in nets[1:]]
     ranked, skipped = [], 0
@@ -31,18 +39,10 @@ def tune_in_flight(nets, run, top=6, margin=1.20, min_gain=0.01, reps=3, max_can
         alone = dict(sig["timed"])
         ranked.append((alone.get(sig["tile"], sig["timed"][0][1]) * sig["launches"], sig))
     ranked.sort(key=lambda t: -t[0])
-    runs = [0]
-
-    def measure():
-        run()  # re-captures the graphs a tile change dropped; not timed
-        runs[0] += reps + 1
-        return min(run() for _ in range(reps))
-
     def put(signature, tile):
         for n in nets:
             n.set_tile(signature, tile)
 
-    before = incumbent = measure()
     changed = []
     for _share, sig in ranked[:top]:
         best_alone = sig["timed"][0][1]

@@ -280,6 +280,44 @@ int dc_conv_variant_count(void);
 const char* dc_conv_variant_name(int i);
 int dc_conv_variant_esize(int i);
 
+/* ---- pyramid-grouped execution: several executors of ONE model, each at its own input shape, as ONE launch sequence ----
+ * Replaces the scale loop of the demo (python/pose/estimate_pose.py:81-128: one net.forward() per scale, every shape change a
+ * full Reshape) and, per layer, the reference's one-SGEMM-per-image loop (src/caffe/layers/base_conv_layer.cpp:326-341,
+ * conv_layer.cpp:31): launch i of the group is launch i of EVERY member merged into one multi-problem gather-GEMM, so a layer's
+ * filters are pulled through the L2s once for all scales and the chip sees one dispatch ramp and one tail per layer
+ * (a 4-scale pyramid: 158 launches instead of 632).  Members are a net and its clones (dc_net_clone: shared parameters, own
+ * activations); they stay usable on their own, and their blobs hold the results of a grouped forward exactly as after their own
+ * (dc_net_blob / dc_net_decode_pose / dc_net_emit_maps / dc_net_detect_parts on a member see them).  Results equal the members'
+ * own forwards up to the fp32 summation order of the tile chosen (bit-identical for the same tile).  The group borrows the nets:
+ * destroy it before them.  Arrays below have one entry per member, in the order given at creation.                          */
+typedef struct dc_group dc_group;
+int dc_group_create(dc_net* const* nets, int n, dc_group** out);
+int dc_group_destroy(dc_group* group);
+int dc_group_size(dc_group* group);
+/* dc_net_forward_batch for every member at once: member c forwards inputs[c] = n[c] x 3 x h[c] x w[c]; output pointer arrays
+ * (or single entries) may be NULL.  stream as dc_net_forward_batch (NULL = the first member's own stream, synchronous).      */
+int dc_group_forward_batch(dc_group* group, const float* const* inputs, const int* n, const int* h, const int* w, int is_device,
+                           float* const* prob, float* const* loc_pred, float* const* next_pred, void* stream);
+/* dc_net_forward_images for every member at once (member c: n[c] images of height[c] x width[c] at scale[c]; the usual case is
+ * the SAME images at the scales of a pyramid): pre-processing per member, ONE grouped forward, then per member the maps and —
+ * pose[c] not NULL — the decoded pose.                                                                                       */
+int dc_group_forward_images(dc_group* group, const unsigned char* const* images, const int* n, const int* height, const int* width,
+                            const double* scale, int is_device, float* const* prob, float* const* loc_pred, float* const* next_pred,
+                            double* const* pose, void* stream);
+/* the merged plan of the last forward: one line per launch ("conv_gemm_mp<tile> problems=.. grid=.." or "member c: <kernel>");
+ * NULL + dc_last_error() before the first forward; pointer valid until the next call on this group                            */
+const char* dc_group_plan_text(dc_group* group);
+#define DC_GSTAT_MERGES 0               /* times the members' plans were merged into a group plan                  */
+#define DC_GSTAT_GRAPH_INSTANTIATIONS 1 /* hipGraph captures + instantiations of group plans                       */
+#define DC_GSTAT_AUTOTUNE_RUNS 2        /* group plans for which at least one merged signature had to be timed     */
+#define DC_GSTAT_PLAN_HITS 3            /* forwards served by a cached group plan                                  */
+#define DC_GSTAT_LAUNCHES 4             /* launches of the last forward's plan                                     */
+#define DC_GSTAT_MULTI_LAUNCHES 5       /* ... of which multi-problem                                              */
+#define DC_NUM_GSTATS 6
+int dc_group_stats(dc_group* group, long long* out, int n);
+/* algorithmic FLOPs of the last grouped forward (the members' dc_net_flops summed)                                          */
+int dc_group_flops(dc_group* group, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,205 @@
+"""-m gpu: pyramid-grouped execution (dc_group_*, caffe.NetGroup) — several executors of one model, each at its own input
+shape, as ONE launch sequence of multi-problem gather-GEMMs — against the CPU oracle, against the members' own forwards,
+with every tile variant forced in turn, in float32 and float16, through the host, device and image entries."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rand_image
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(2, 40, 56), (2, 64, 64), (2, 72, 104), (2, 104, 136)]  # a small 4-"scale" pyramid, batch 2 per scale
+MAX_VARIANTS = 64
+
+
+def _oracle(layers, n, h, w, seed):
+    from deepcut_tools import deepercut_prototxt
+
+    O.set_threads(min(16, os.cpu_count() or 1))
+    img = rand_image(seed, h, w, n=n)
+    return img, O.OracleNet(deepercut_prototxt(152, h, w, n), layers).forward(data=img)
+
+
+@pytest.fixture(scope="module")
+def refs(synth152):
+    _, layers = synth152
+    return [_oracle(layers, n, h, w, 40 + i) for i, (n, h, w) in enumerate(SHAPES)]
+
+
+def _group(caffe, path, shapes, **kw):
+    from deepcut_tools import deepercut_prototxt
+
+    n, h, w = shapes[0]
+    net = caffe.Net(deepercut_prototxt(152, h, w, n), path, caffe.TEST, from_text=True, **kw)
+    return caffe.NetGroup.for_shapes(net, shapes)
+
+
+def _check32(out, ref, tol=1e-3):
+    for k in ("prob", "loc_pred", "next_pred"):
+        assert out[k].shape == ref[k].shape
+        assert float(np.abs(out[k] - ref[k]).max()) <= tol, k
+
+
+def _check16(out, ref):
+    assert float(np.abs(out["prob"] - ref["prob"]).max()) <= 2.5e-3
+    for k in ("loc_pred", "next_pred"):
+        assert float(np.abs(out[k] - ref[k]).max()) <= 4e-3 * max(1.0, float(np.abs(ref[k]).max())), k
+
+
+@pytest.mark.parametrize("wino", ["0", None])
+def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synth152, refs, monkeypatch, wino):
+    """All four 'scales' in one plan vs the oracle (1e-3) and vs each member run on its own (same arithmetic: 1e-4)."""
+    path, _ = synth152
+    if wino is not None:
+        monkeypatch.setenv("DC_WINOGRAD", wino)  # 0: every convolution merges; default: the Winograd layers run member by member
+    grp = _group(gpu_caffe, path, SHAPES, hipgraph=1)
+    outs = grp.forward_batch([r[0] for r in refs])
+    for o, (_, ref) in zip(outs, refs):
+        _check32(o, ref)
+    st = grp.stats()
+    text = grp.plan_text()
+    assert st["multi_launches"] >= 100 and "conv_gemm_mp<" in text, text[:400]
+    if wino == "0":
+        # 158 launches per forward: 157 convolutions, all merged, + the max-pool member by member
+        assert st["multi_launches"] == 157 and st["launches"] == 157 + len(SHAPES), st
+    # the heads: 4 members x 4 residue classes = 16 problems in one launch
+    assert "problems=16" in text
+    keep = [{k: v.copy() for k, v in o.items()} for o in outs]
+    for m, (img, _), o in zip(grp.nets, refs, keep):
+        own = m.forward_batch(img)
+        for k in own:
+            assert float(np.abs(own[k] - o[k]).max()) <= 1e-4, k
+    # again, grouped: same plan, same graph, same values
+    before = grp.stats()
+    lows = [m.stats()["lowerings"] for m in grp.nets]
+    outs2 = grp.forward_batch([r[0] for r in refs])
+    for a, b in zip(outs2, keep):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    after = grp.stats()
+    assert after["merges"] == before["merges"] and after["graph_instantiations"] == before["graph_instantiations"]
+    assert after["plan_hits"] == before["plan_hits"] + 1
+    assert [m.stats()["lowerings"] for m in grp.nets] == lows
+
+
+def test_group_fp16_batch8_pyramid(gpu_caffe, synth152):
+    """BASELINE configs[2] in miniature: batch 8 at four scales of a 136x184 image, float16 operands, one grouped plan."""
+    path, layers = synth152
+    shapes = [(8, 72, 96), (8, 104, 144), (8, 136, 184), (8, 176, 232)]
+    grp = _group(gpu_caffe, path, shapes, dtype="f16", hipgraph=1)
+    data = [_oracle(layers, n, h, w, 60 + i) for i, (n, h, w) in enumerate(shapes)]
+    outs = grp.forward_batch([d[0] for d in data])
+    for o, (_, ref) in zip(outs, data):
+        _check16(o, ref)
+        assert float(np.abs(o["loc_pred"] - ref["loc_pred"]).max()) > 1e-6, "suspiciously exact: is the fp16 path running?"
+    text = grp.plan_text()
+    assert "conv_gemm_mp<d" in text or "conv_gemm_mp<h" in text, text[:300]
+    st = grp.stats()
+    assert st["multi_launches"] == 157, st
+    # the device pose decode of every member reads the grouped results
+    for m, sc in zip(grp.nets, (0.5, 0.75, 1.0, 1.25)):
+        pose = m.decode_pose(sc)
+        assert pose.shape == (8, 5, 14) and np.isfinite(pose).all()
+
+
+def test_group_unfused_graph_and_ab_switch(gpu_caffe, synth152, refs, monkeypatch):
+    """DC_OPT_FUSE 0 (every Caffe-visible blob materialised: stand-alone BatchNorm / Scale / ReLU / Eltwise / Crop launches run
+    member by member between the merged convolutions) and DC_GROUP=0 (nothing merged) give the same maps."""
+    path, _ = synth152
+    shapes = SHAPES[:2]
+    grp = _group(gpu_caffe, path, shapes, fuse=0)
+    outs = grp.forward_batch([r[0] for r in refs[:2]])
+    for o, (_, ref) in zip(outs, refs[:2]):
+        _check32(o, ref)
+    st = grp.stats()
+    assert st["multi_launches"] > 100 and st["launches"] > st["multi_launches"] + 100, st
+    for m, (_, ref) in zip(grp.nets, refs[:2]):  # intermediate blobs of a member after a grouped forward
+        for name in ("conv1", "pool1", "res2c", "res3b7", "res4b35", "res5c"):
+            assert float(np.abs(m.blobs[name].data - ref[name]).max()) <= 1e-3 * max(1.0, float(np.abs(ref[name]).max())), name
+    monkeypatch.setenv("DC_GROUP", "0")
+    grp0 = _group(gpu_caffe, path, shapes, fuse=2)
+    outs0 = grp0.forward_batch([r[0] for r in refs[:2]])
+    assert grp0.stats()["multi_launches"] == 0
+    for o, (_, ref) in zip(outs0, refs[:2]):
+        _check32(o, ref)
+
+
+def test_group_image_entry_equals_the_members_own(gpu_caffe, synth152):
+    """dc_group_forward_images: the same uint8 images at four scales, pre-processing + ONE grouped forward + pose decode,
+    against dc_net_forward_images of one net scale by scale (the demo's loop, estimate_pose.py:81-128)."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    scales = (0.5, 0.75, 1.0, 1.25)
+    img8 = np.random.RandomState(5).randint(0, 256, (2, 120, 152, 3)).astype(np.uint8)
+    single = gpu_caffe.Net(deepercut_prototxt(152, 120, 152, 2), path, gpu_caffe.TEST, from_text=True)
+    want = [dict((k, v.copy()) for k, v in single.forward_images(img8, s, want=("prob", "loc_pred", "next_pred"), pose=True).items()) for s in scales]
+    shapes = [(2,) + tuple(gpu_caffe.canvas_size(120, 152, s)) for s in scales]
+    grp = _group(gpu_caffe, path, shapes)
+    got = grp.forward_images(img8, scales, want=("prob", "loc_pred", "next_pred"), pose=True)
+    for g, w_ in zip(got, want):
+        for k in ("prob", "loc_pred", "next_pred"):
+            assert g[k].shape == w_[k].shape and float(np.abs(g[k] - w_[k]).max()) <= 1e-4, k
+    # the pose the device decoded for every member == pose_from_maps (pinned to the reference's _pose_from_mats by
+    # tests/test_pose.py) on the maps the SAME grouped forward returned
+    from pose import estimate_pose as ep
+
+    for g, sc in zip(got, scales):
+        for i in range(2):
+            assert np.allclose(g["pose"][i], ep.pose_from_maps(g["prob"][i], g["loc_pred"][i], sc), rtol=0, atol=1e-9)
+    assert grp.stats()["multi_launches"] >= 100
+
+
+def test_group_device_entry_and_async_stream(gpu_caffe, synth152, refs):
+    import torch
+
+    path, _ = synth152
+    shapes = SHAPES[1:3]
+    grp = _group(gpu_caffe, path, shapes, hipgraph=1)
+    xs = [torch.from_numpy(refs[i + 1][0]).cuda() for i in range(2)]
+    outs = [[torch.empty(refs[i + 1][1][k].shape, device="cuda") for k in ("prob", "loc_pred", "next_pred")] for i in range(2)]
+    st = torch.cuda.Stream()
+    for _ in range(3):
+        grp.forward_device([x.data_ptr() for x in xs], shapes, [o[0].data_ptr() for o in outs], [o[1].data_ptr() for o in outs],
+                           [o[2].data_ptr() for o in outs], stream=st.cuda_stream)
+    st.synchronize()
+    for o, (_, ref) in zip(outs, refs[1:3]):
+        _check32({"prob": o[0].cpu().numpy(), "loc_pred": o[1].cpu().numpy(), "next_pred": o[2].cpu().numpy()}, ref)
+
+
+def test_group_rejects_foreign_members(gpu_caffe, synth152):
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    a = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
+    b = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
+    with pytest.raises(gpu_caffe.DeepcutError):
+        gpu_caffe.NetGroup([a, b])  # two models: no shared filter images
+    with pytest.raises(gpu_caffe.DeepcutError):
+        gpu_caffe.NetGroup([a, a])
+    c = a.clone()
+    grp = gpu_caffe.NetGroup([a, c])
+    with pytest.raises(gpu_caffe.DeepcutError):
+        grp.plan_text()  # before the first forward
+
+
+@pytest.mark.parametrize("v", range(MAX_VARIANTS))
+def test_group_with_every_tile_forced(gpu_caffe, synth152, refs, monkeypatch, v):
+    """Every tile variant has a multi-problem instantiation; forced one at a time over a 2-member group (the whole graph:
+    dense 1x1, strided 1x1, 3x3, dilated 3x3, the stem's row taps, the 8-problem deconvolution heads), against the oracle."""
+    table = gpu_caffe.conv_variants()
+    if v >= len(table):
+        pytest.skip("the variant table has %d entries" % len(table))
+    name, esize = table[v]
+    path, _ = synth152
+    monkeypatch.setenv("DC_CONV_VARIANT", str(v))
+    shapes = [SHAPES[0], SHAPES[2]]
+    grp = _group(gpu_caffe, path, shapes, dtype="f16" if esize == 2 else "f32")
+    outs = grp.forward_batch([refs[0][0], refs[2][0]])
+    used = set(ln.split()[1] for ln in grp.plan_text().splitlines()[1:] if "conv_gemm_mp<" in ln)
+    assert "conv_gemm_mp<%s>" % name in used, (name, sorted(used))
+    for o, (_, ref) in zip(outs, (refs[0], refs[2])):
+        (_check16 if esize == 2 else _check32)(o, ref)
