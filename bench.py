@@ -122,8 +122,10 @@ def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
 
 def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=True, regions=5):
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
-    680x920), float16 operands with float32 accumulation, device-resident, one pyramid batch at a time.  A step = the
-    four batch-8 forwards of one pyramid batch (32 forwards = 8 images); shapes come from the per-shape plan cache."""
+    680x920), float16 operands with float32 accumulation, device-resident.  A step = one pyramid batch (32 forwards = 8
+    images).  Measured two ways in the same run: GROUPED (caffe.NetGroup: the four scales as ONE launch sequence of
+    multi-problem gather-GEMMs, 158 + 3 launches per pyramid batch instead of 632 — `value`) and, as in rounds 1-3, scale by
+    scale (four batch-8 forwards per step; reported as `scale_by_scale`).  Each: one step at a time, then `execs` in flight."""
     import torch
     from deepcut_tools import deepercut_prototxt
 
@@ -142,6 +144,17 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
         n.reserve(8, *shapes[-1])
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in nets[1:]]
     outs = [{s: [torch.empty(8, c, s[0] // 8, s[1] // 8, device=dev) for c in (14, 28, 364)] for s in shapes} for _ in nets]
+    # the grouped form: one group per step in flight, a member per scale (largest first: nothing grows afterwards)
+    groups = []
+    for e in range(execs):
+        members = [net.clone() for _ in shapes]
+        for m, s in zip(members, shapes):
+            m.reserve(8, *s)
+        groups.append(caffe.NetGroup(members))
+    gshapes = [(8, s[0], s[1]) for s in shapes]
+    # ... and the `execs` pyramid batches in flight COALESCED into one group (a net may sit in several groups as long as they do
+    # not run at the same time): every layer once over 4 x execs tensors — more rows per launch for the matrix-class layers
+    big = caffe.NetGroup([m for grp in groups for m in grp.nets]) if execs > 1 else None
 
     def pyramid(inflight, k0=0):
         for i, s in enumerate(shapes):
@@ -149,29 +162,54 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
             o = outs[e][s]
             nets[e].forward_device(xs[s].data_ptr(), 8, s[0], s[1], o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), streams[e].cuda_stream)
 
-    def timed(inflight):
+    def pyramid_grouped(inflight, k0=0):
+        e = k0 % inflight
+        o = outs[e]
+        groups[e].forward_device([xs[s].data_ptr() for s in shapes], gshapes, [o[s][0].data_ptr() for s in shapes],
+                                 [o[s][1].data_ptr() for s in shapes], [o[s][2].data_ptr() for s in shapes], stream=streams[e].cuda_stream)
+
+    def pyramid_coalesced(inflight, k0=0):
+        if k0 % execs:
+            return  # one call = `execs` steps
+        big.forward_device([xs[s].data_ptr() for _ in range(execs) for s in shapes], gshapes * execs,
+                           [outs[e][s][0].data_ptr() for e in range(execs) for s in shapes], [outs[e][s][1].data_ptr() for e in range(execs) for s in shapes],
+                           [outs[e][s][2].data_ptr() for e in range(execs) for s in shapes], stream=streams[0].cuda_stream)
+
+    def counters():
+        ns = [n.stats() for n in nets] + [m.stats() for grp in groups for m in grp.nets]
+        gs = [grp.stats() for grp in groups] + ([big.stats()] if big else [])
+        return (sum(x["lowerings"] for x in ns) + sum(x["merges"] for x in gs), sum(x["graph_instantiations"] for x in ns + gs))
+
+    def timed(fn, inflight):
         for k in range(4):  # lower, tune and capture every shape on every executor it will meet there
-            pyramid(inflight, k)
+            fn(inflight, k)
         torch.cuda.synchronize(dev)
-        before = [n.stats() for n in nets]
+        before = counters()
         dts = []
         for _ in range(regions):
             for st in streams[1:]:
                 st.wait_stream(streams[0])
             t0 = time.perf_counter()
             for k in range(steps):
-                pyramid(inflight, k)  # the scales rotate over the executors
+                fn(inflight, k)  # the scales (the groups) rotate over the executors
             torch.cuda.synchronize(dev)
             dts.append(time.perf_counter() - t0)
-        after = [n.stats() for n in nets]
-        return dts, sum(a["lowerings"] - b["lowerings"] for a, b in zip(after, before)), sum(
-            a["graph_instantiations"] - b["graph_instantiations"] for a, b in zip(after, before))
+        after = counters()
+        return dts, after[0] - before[0], after[1] - before[1]
 
     def med(v):
         return sorted(v)[len(v) // 2]
 
-    dts1, relow1, inst1 = timed(1)
-    dt1 = med(dts1)
+    def figures(dts):
+        dt = med(dts)
+        tf = steps * flops / dt / 1e12
+        return {"value": steps * 8 / dt, "value_min": steps * 8 / max(dts), "value_max": steps * 8 / min(dts), "unit": "image-pyramids/s",
+                "ms_per_pyramid_batch": dt / steps * 1e3, "tflops": tf, "roofline_frac_f16": tf / PEAK_FP16_MFMA_TFLOPS}
+
+    g1, relow_g1, inst_g1 = timed(pyramid_grouped, 1)
+    g2, relow_g2, inst_g2 = timed(pyramid_grouped, execs)
+    gc, relow_gc, inst_gc = timed(pyramid_coalesced, execs) if big and steps % execs == 0 else (None, 0, 0)
+    dts1, relow1, inst1 = timed(pyramid, 1)
     # between the regions: the tiles of every scale re-tuned for `execs` forwards in flight (untimed; deepcut_tools.tune_in_flight)
     retiled = None
     if execs > 1 and tune:
@@ -190,21 +228,25 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
 
             load()  # every executor at this scale: the report and the overrides address its current plan
             retiled += len(tune_in_flight(nets[:execs], load, top=4)["changed"])
-    dts2, relow2, inst2 = timed(execs)
-    dt2 = med(dts2)
-    tf1, tf2 = steps * flops / dt1 / 1e12, steps * flops / dt2 / 1e12
-    return {"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
-                        "accumulate (BASELINE configs[2]); value = %d batch-8 forwards in flight on %d executors (the scales rotate over them)" % (execs, execs),
-            "value": steps * 8 / dt2, "value_min": steps * 8 / max(dts2), "value_max": steps * 8 / min(dts2), "regions": regions,
-            "unit": "image-pyramids/s", "forwards_in_flight": execs,
-            "tile_tuning": "latency" if retiled is None else "in flight (%d signatures re-tiled over the four scales)" % retiled, "forwards_per_s": steps * 32 / dt2, "steps": steps,
-            "ms_per_pyramid_batch": dt2 / steps * 1e3, "gflop_per_image_pyramid": flops / 8 / 1e9, "tflops": tf2,
-            "roofline_frac_f16": tf2 / PEAK_FP16_MFMA_TFLOPS,
-            "one_forward_at_a_time": {"value": steps * 8 / dt1, "value_min": steps * 8 / max(dts1), "value_max": steps * 8 / min(dts1),
-                                      "unit": "image-pyramids/s", "ms_per_pyramid_batch": dt1 / steps * 1e3,
-                                      "tflops": tf1, "roofline_frac_f16": tf1 / PEAK_FP16_MFMA_TFLOPS},
-            "relowerings_in_timed_region": relow1 + relow2,
-            "graph_instantiations_in_timed_region": inst1 + inst2}
+    dts2, relow2, inst2 = timed(pyramid, execs)
+    f2, fc = figures(g2), (figures(gc) if gc else None)
+    coalesced = fc is not None and fc["value"] > f2["value"]
+    res = dict(fc if coalesced else f2)
+    res.update({"workload": "batch=8 x 4-scale pyramid (272x368, 408x552, 544x736, 680x920) of 736x544 images, fp16 MFMA with fp32 "
+                            "accumulate (BASELINE configs[2]); the four scales as ONE grouped launch sequence (caffe.NetGroup: %s); value = %d pyramid "
+                            "batches in flight, %s" % (groups[0].plan_text().splitlines()[0][2:], execs,
+                                                       "coalesced into one group of %d executors" % (4 * execs) if coalesced else "on %d groups / streams" % execs),
+                "regions": regions, "steps": steps, "forwards_in_flight": execs, "forwards_per_s": res["value"] * 4,
+                "gflop_per_image_pyramid": flops / 8 / 1e9, "tile_tuning": "latency (group signatures timed alone, then inside the group's own sequence)",
+                "one_forward_at_a_time": figures(g1), "in_flight_on_streams": f2, "in_flight_coalesced": fc})
+    sbs = figures(dts2)
+    sbs.update({"note": "rounds 1-3 form: four batch-8 forwards per pyramid batch, the scales rotating over %d executors" % execs,
+                "tile_tuning": "latency" if retiled is None else "in flight (%d signatures re-tiled over the four scales)" % retiled,
+                "one_forward_at_a_time": figures(dts1)})
+    res["scale_by_scale"] = sbs
+    res["relowerings_in_timed_region"] = relow1 + relow2 + relow_g1 + relow_g2 + relow_gc
+    res["graph_instantiations_in_timed_region"] = inst1 + inst2 + inst_g1 + inst_g2 + inst_gc
+    return res
 
 
 def main():

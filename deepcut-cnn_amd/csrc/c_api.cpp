@@ -565,6 +565,12 @@ const char* dc_group_plan_text(dc_group* group) {
   int rc = guard([&] { g->text_buf = g->plan_text(); });
   return rc == DC_OK ? g->text_buf.c_str() : nullptr;
 }
+const char* dc_group_profile_text(dc_group* group, int iters) {
+  if (!group) return nullptr;
+  NetGroup* g = G(group);
+  int rc = guard([&] { g->text_buf = g->profile_text(iters > 0 ? iters : 10); });
+  return rc == DC_OK ? g->text_buf.c_str() : nullptr;
+}
 int dc_group_stats(dc_group* group, long long* out, int n) {
   REQUIRE(group);
   REQUIRE(out);

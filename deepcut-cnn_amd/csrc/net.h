@@ -361,6 +361,7 @@ struct NetGroup {
   void forward_images(const unsigned char* const* bgr, const int* n, const int* h, const int* w, const double* scale, bool is_device,
                       float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream);
   std::string plan_text();
+  std::string profile_text(int iters);
   int num_launches();
   int num_multi_launches();
   double flops();

@@ -119,6 +119,7 @@ def _load():
         "dc_group_forward_images": (ci, [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_double), ci,
                                          C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "dc_group_plan_text": (cp, [vp]),
+        "dc_group_profile_text": (cp, [vp, ci]),
         "dc_group_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
         "dc_group_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_conv_variant_count": (ci, []),
@@ -721,6 +722,12 @@ class NetGroup(object):
 
     def plan_text(self):
         t = _lib.dc_group_plan_text(self._h)
+        if t is None:
+            _check(-1)
+        return t.decode()
+
+    def profile_text(self, iters=10):
+        t = _lib.dc_group_profile_text(self._h, int(iters))
         if t is None:
             _check(-1)
         return t.decode()

@@ -307,6 +307,8 @@ int dc_group_forward_images(dc_group* group, const unsigned char* const* images,
 /* the merged plan of the last forward: one line per launch ("conv_gemm_mp<tile> problems=.. grid=.." or "member c: <kernel>");
  * NULL + dc_last_error() before the first forward; pointer valid until the next call on this group                            */
 const char* dc_group_plan_text(dc_group* group);
+/* every launch of that plan timed with hipEvents (iters runs each), same table as dc_net_profile_text                        */
+const char* dc_group_profile_text(dc_group* group, int iters);
 #define DC_GSTAT_MERGES 0               /* times the members' plans were merged into a group plan                  */
 #define DC_GSTAT_GRAPH_INSTANTIATIONS 1 /* hipGraph captures + instantiations of group plans                       */
 #define DC_GSTAT_AUTOTUNE_RUNS 2        /* group plans for which at least one merged signature had to be timed     */
