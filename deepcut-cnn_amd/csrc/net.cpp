@@ -1168,6 +1168,45 @@ void Net::build_plan() {
     l.grid = wino_grid(l.cg);
   };
 
+  // Channel split of a wide-but-ragged GEMM (the merged heads: N = 406 = 3 x 128 + 22).  On 128-wide tiles a quarter of the
+  // fourth column block is padding (26 % of the launch's MFMA work and filter fetches for nothing); as two launches — the
+  // first floor(N / 128) * 128 channels, then the tail on a narrow tile — the padding is 22 -> 32/64 channels.  Host-side only:
+  // the second launch is the same kernel on offset filter rows / epilogue constants / output channels.
+  // DC_HEAD_SPLIT=1 switches it on.  OFF by default — measured (round 4, EXPERIMENTS.md): the tail launch re-reads all of res5c's
+  // 2048-deep rows for 22 channels (float16 grouped pyramid: 900 us -> 720 + 177 us; float32 batch 1: 457 -> 459 images/s in
+  // flight, 337 -> 333 alone): the padding it removes is paid back as operand traffic.  Kept as a switch with its parity test.
+  const int head_split = env_int("DC_HEAD_SPLIT", 0);
+  auto push_split = [&](Launch&& l, int kgcd) {
+    const int OC = l.cg.Cout;
+    const bool want = head_split == 1;
+    const int c0 = OC / 128 * 128;
+    if (!want || OC < 256 || c0 == OC || OC - c0 > 64 || force_variant >= 0) {
+      plan.push_back(std::move(l));
+      return;
+    }
+    Launch a = l, b = l;
+    const double fa = (double)c0 / OC;
+    a.cg.Cout = c0;
+    a.flops = l.flops * fa;
+    a.label += " [ch 0-" + std::to_string(c0 - 1) + "]";
+    a.cg.sigmoid_ch = std::min(l.cg.sigmoid_ch, c0);
+    b.cg.Cout = OC - c0;
+    b.flops = l.flops * (1.0 - fa);
+    b.label += " [ch " + std::to_string(c0) + "-" + std::to_string(OC - 1) + "]";
+    b.cg.sigmoid_ch = std::max(0, l.cg.sigmoid_ch - c0);
+    b.y_off = l.y_off + c0;
+    b.c_off = l.c_off + c0;
+    if (l.cg.ncls > 1) {
+      for (int q = 0; q < l.cg.ncls; ++q) b.cg.cls[q].w_off = l.cg.cls[q].w_off + (long)c0 * l.cg.cls[q].Ktot;
+    } else {
+      b.w_off = l.w_off + (long)c0 * l.cg.Ktot;
+    }
+    choose_variant(a, kgcd);
+    choose_variant(b, kgcd);
+    plan.push_back(std::move(a));
+    plan.push_back(std::move(b));
+  };
+
   for (auto& op : ops) {
     if (op.dead) continue;
     Launch base;
@@ -1289,7 +1328,8 @@ void Net::build_plan() {
         });
         if (wino_mode == 1 && (force_variant < 0 || force_variant == kWinoVariant)) use_wino(l);
       }
-      plan.push_back(std::move(l));
+      if (l.wino_w || rowtap) plan.push_back(std::move(l));
+      else push_split(std::move(l), kgcd);
     } else if (op.kind == LOp::DECONV) {
       // stride-s transposed convolution = s*s ordinary gather-GEMMs, one per output residue class
       // (Y mod s, X mod s): output pixel (s*i + r) receives tap k iff (r + p - k*d) % s == 0, from input
@@ -1427,7 +1467,7 @@ void Net::build_plan() {
           l.w->as_half = dtype == 1;
           half_row_scale(l, op, OC);
           choose_variant(l, CP);
-          plan.push_back(std::move(l));
+          push_split(std::move(l), CP);
           merged = true;
         }
       }
@@ -2061,9 +2101,9 @@ void Net::run_launch(const Launch& l, void* s) {
       g.x = X.dev;
       g.y = Y.dev_at(l.y_off);
       g.resid = l.in2 >= 0 ? storages[l.in2]->dev_at(l.y_off) : nullptr;
-      g.w = l.w->dev;
-      g.scale = l.scale ? l.scale->dev : nullptr;
-      g.shift = l.shift ? l.shift->dev : nullptr;
+      g.w = reinterpret_cast<const unsigned char*>(l.w->dev) + (size_t)l.w_off * (size_t)g.esize;
+      g.scale = l.scale ? l.scale->dev + l.c_off : nullptr;
+      g.shift = l.shift ? l.shift->dev + l.c_off : nullptr;
       const bool wino = l.variant == kWinoVariant;  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
       if (wino) {
         if (!l.wino_w) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
@@ -2869,7 +2909,8 @@ void NetGroup::merge(GroupPlan& gp) {
     for (size_t c = 0; c < NM && mergeable; ++c) {
       const Launch& l = nets[c]->plan[i];
       const ConvGemmParams &g = l.cg, &g0 = l0.cg;
-      if (l.kind != Launch::CONV || l.variant == kWinoVariant || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift ||
+      if (l.kind != Launch::CONV || l.variant == kWinoVariant || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift || l.c_off != l0.c_off ||
+          l.w_off != l0.w_off ||
           (l.in2 >= 0) != (l0.in2 >= 0) || g.esize != g0.esize || g.klen != g0.klen || g.sy != g0.sy || g.sx != g0.sx || g.Cout != g0.Cout ||
           g.relu != g0.relu || g.sigmoid_ch != g0.sigmoid_ch)
         mergeable = false;
@@ -2910,7 +2951,7 @@ void NetGroup::merge(GroupPlan& gp) {
       const int nc = g.ncls > 1 ? g.ncls : 1;
       for (int k = 0; k < nc; ++k) {
         ConvProblem q{};
-        const long yo = g.ncls > 1 ? g.cls[k].y_off : l.y_off;
+        const long yo = g.ncls > 1 ? l.y_off + g.cls[k].y_off : l.y_off;
         q.x = X.dev;
         q.y = Y.dev_at(yo);
         q.resid = l.in2 >= 0 ? n.storages[l.in2]->dev_at(yo) : nullptr;
@@ -2924,7 +2965,7 @@ void NetGroup::merge(GroupPlan& gp) {
           q.nty = cl.nty, q.ntx = cl.ntx, q.dy0 = cl.dy0, q.ddy = cl.ddy, q.x0 = cl.x0, q.ddx = cl.ddx, q.Ktot = cl.Ktot;
           q.OH = cl.OH, q.OW = cl.OW, q.M = cl.M;
         } else {
-          q.w_off = 0;
+          q.w_off = l.w_off;
           q.nty = g.nty, q.ntx = g.ntx, q.dy0 = g.dy0, q.ddy = g.ddy, q.x0 = g.x0, q.ddx = g.ddx, q.Ktot = g.Ktot;
           q.OH = g.OH, q.OW = g.OW, q.M = g.M;
         }
@@ -2943,8 +2984,8 @@ void NetGroup::merge(GroupPlan& gp) {
       gl.p.dbg = nullptr;
       gl.p.x = nullptr, gl.p.y = nullptr, gl.p.resid = nullptr;
       gl.p.w = l0.w->dev;
-      gl.p.scale = l0.scale ? l0.scale->dev : nullptr;
-      gl.p.shift = l0.shift ? l0.shift->dev : nullptr;
+      gl.p.scale = l0.scale ? l0.scale->dev + l0.c_off : nullptr;
+      gl.p.shift = l0.shift ? l0.shift->dev + l0.c_off : nullptr;
       for (int k = 0; k < gl.nprob; ++k) {
         gl.table.prob[k] = recs[r0 + k].q;
         gl.prob_member.push_back(recs[r0 + k].member);

@@ -163,7 +163,9 @@ struct Launch {
   int variant = 0;
   std::shared_ptr<DevVec> w, scale, shift;  // packed filters / folded affine (kept alive by the plan)
   std::shared_ptr<DevVec> wino_w;           // Winograd-transformed filters (eligible 3x3 layers), else null
-  long y_off = 0;                      // element offset of this launch's first output (deconvolution classes)
+  long y_off = 0;                      // element offset of this launch's first output (deconvolution classes, channel splits)
+  long w_off = 0;                      // element offset of this launch's first filter row inside `w` (channel splits)
+  int c_off = 0;                       // first output channel of this launch inside scale / shift (channel splits)
   double flops = 0;                    // algorithmic 2*MAC
   long grid = 0;
   // POOL

@@ -203,3 +203,18 @@ def test_group_with_every_tile_forced(gpu_caffe, synth152, refs, monkeypatch, v)
     assert "conv_gemm_mp<%s>" % name in used, (name, sorted(used))
     for o, (_, ref) in zip(outs, (refs[0], refs[2])):
         (_check16 if esize == 2 else _check32)(o, ref)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_head_channel_split_parity(gpu_caffe, synth152, refs, monkeypatch, dtype):
+    """DC_HEAD_SPLIT=1 (the 406-channel head GEMMs as two launches on offset filter rows / constants / output channels), alone
+    and grouped, against the oracle: `prob` (sigmoid prefix in the first part), `next_pred` (straddles the cut)."""
+    path, _ = synth152
+    monkeypatch.setenv("DC_HEAD_SPLIT", "1")
+    grp = _group(gpu_caffe, path, SHAPES[1:3], dtype=dtype)
+    outs = grp.forward_batch([refs[1][0], refs[2][0]])
+    assert "[ch 384-405]" in grp.plan_text() and "[ch 384-405]" in grp.nets[0].plan_text()
+    for o, (_, ref) in zip(outs, refs[1:3]):
+        (_check16 if dtype == "f16" else _check32)(o, ref)
+    own = grp.nets[1].forward_batch(refs[2][0])
+    (_check16 if dtype == "f16" else _check32)(own, refs[2][1])

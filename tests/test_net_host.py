@@ -368,3 +368,13 @@ def test_parameter_write_reaches_every_executor_and_survives_the_parent():
     assert c.stats()["lowerings"] == 3
     c2 = c.clone()
     assert (c2.params["conv1"][0].data == 0.5).all()
+
+
+def test_head_channel_split_switch(monkeypatch):
+    """DC_HEAD_SPLIT=1: the two 406-channel head GEMMs as [ch 0-383] + [ch 384-405] (measured: no gain, off by default)."""
+    monkeypatch.setenv("DC_HEAD_SPLIT", "1")
+    net = caffe.Net(deepercut_prototxt(152, 240, 320), caffe.TEST, from_text=True, dtype="f16")
+    lines = [l for l in net.plan_text().splitlines() if not l.startswith("#")]
+    assert len(lines) == 160
+    assert sum(1 for l in lines if "[ch 0-383]" in l) == 2 and sum(1 for l in lines if "[ch 384-405]" in l) == 2
+    assert "N=384" in [l for l in lines if "[ch 0-383]" in l][0] and "N=22" in [l for l in lines if "[ch 384-405]" in l][0]
