@@ -245,6 +245,7 @@ static int blob_host(dc_blob* b, float** out, bool mut) {
       else standalone_device(), storage_to_host(s, nullptr, nullptr);
     }
     *out = s.host_ptr();
+    s.host_touched = true;
     if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
     if (mut) {
       s.head = HEAD_AT_CPU;

@@ -1971,7 +1971,11 @@ void Net::release_graph() {
 
 // SyncedMemory::to_gpu (syncedmem.cpp:49-77): UNINITIALIZED -> a zeroed device image that is authoritative
 // (HEAD_AT_GPU); HEAD_AT_CPU -> upload, SYNCED.  The device image of a 4-D blob is channels-last.
-void storage_to_device(Storage& s, void* stream) {
+static void storage_to_device_impl(Storage& s, void* stream, bool wait);
+void storage_to_device(Storage& s, void* stream) { storage_to_device_impl(s, stream, true); }
+// wait = false: the upload is enqueued and the caller synchronises the stream before the host copy can change again
+// (Net::forward: its own final synchronisation covers the inputs it sent up — one round trip less per forward)
+static void storage_to_device_impl(Storage& s, void* stream, bool wait) {
   if (s.head == HEAD_AT_GPU || s.head == SYNCED) return;
   if (device_count() <= 0) throw DcError(DC_EDEVICE, "no HIP device visible");
   size_t n = s.count();
@@ -1990,7 +1994,7 @@ void storage_to_device(Storage& s, void* stream) {
     if (s.esize != 4) throw DcError(DC_EUNSUP, "only 4-D blobs have a half-precision device image");
     HIPCHECK(hipMemcpyAsync(s.dev, s.host_ptr(), n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   }
-  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (wait) HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
   s.head = SYNCED;
 }
 
@@ -2001,11 +2005,19 @@ void storage_mutable_device(Storage& s, void* stream) {  // syncedmem.cpp:130-13
 
 // SyncedMemory::to_cpu (syncedmem.cpp:25-47)
 void storage_to_host(Storage& s, void* stream, Storage* base) {
+  s.host_touched = true;
   if (s.head != HEAD_AT_GPU) {
     s.host_ptr();
     if (s.head == UNINITIALIZED) s.head = HEAD_AT_CPU;
     return;
   }
+  s.host_wanted = true;  // read on demand once: the next forwards deliver it (Net::forward)
+  storage_download_enqueue(s, stream, base);
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  s.head = SYNCED;
+}
+
+void storage_download_enqueue(Storage& s, void* stream, Storage* base) {
   size_t n = s.count();
   float* h = s.host_ptr();
   if (base) {  // channel slice of a concatenated tensor
@@ -2020,8 +2032,6 @@ void storage_to_host(Storage& s, void* stream, Storage* base) {
     if (s.esize != 4) throw DcError(DC_EUNSUP, "only 4-D blobs have a half-precision device image");
     HIPCHECK(hipMemcpyAsync(h, s.dev, n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   }
-  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
-  s.head = SYNCED;
 }
 
 void storage_copy(Storage& dst, Storage& src, Storage* src_base, void* stream) {
@@ -2246,7 +2256,12 @@ void Net::forward(int start, int end) {
             if (m.last_layer < start || m.first_layer > end) continue;
             if (m.out == sidx) produced_earlier = true;
           }
-          if (!produced_earlier) sync_to_device(s);
+          if (!produced_earlier) {
+            ensure_device();
+            // pinned host copy (non-parameter blobs): the copy engine reads it behind our back until the stream is drained —
+            // which forward() does before it returns; pageable memory is staged by the runtime at enqueue time
+            storage_to_device_impl(s, stream, false);
+          }
         }
       }
   }
@@ -2279,7 +2294,22 @@ void Net::forward(int start, int end) {
     storages[l.out]->head = HEAD_AT_GPU;
   }
   for (int v : plan_views_) storages[v]->head = HEAD_AT_GPU;
+  // the outputs the caller has been reading through host pointers travel now, behind the last launch (Storage::host_wanted)
+  std::vector<Storage*> delivered;
+  if (whole)
+    for (int bi : outputs) {
+      Storage& st = *blobs[bi]->st;
+      if (!st.host_wanted || st.head != HEAD_AT_GPU || st.elided) continue;
+      if (!st.host_touched) {  // not read since the last delivery: stop sending it
+        st.host_wanted = false;
+        continue;
+      }
+      st.host_touched = false;
+      storage_download_enqueue(st, stream, st.view_of >= 0 ? storages[st.view_of].get() : nullptr);
+      delivered.push_back(&st);
+    }
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  for (Storage* st : delivered) st->head = SYNCED;
 }
 
 // Common front half of the batched entries: shape the input blob, (re)build the plan, make the device state ready.

@@ -51,6 +51,12 @@ struct Storage {
   bool pad4 = false;   // channel pitch rounded up to one 16-byte vector (tensors read by the gather-GEMM)
   bool is_param = false;
   bool elided = false;  // absorbed by fusion in the current plan: never materialised
+  // net outputs the caller reads through host pointers after forward() (pycaffe: blobs['prob'].data): once an output was
+  // downloaded on demand, the following forwards send it to the (pinned) host copy right behind the head launch, inside the
+  // forward's own synchronisation — `.data` then finds it there (SYNCED) instead of paying a kernel, a copy and a stream
+  // round trip per map.  An output that was NOT touched between two forwards stops being sent (next_pred is 9.1 of the
+  // 10.2 MB and the demo never reads it, estimate_pose.py:104-112).
+  bool host_wanted = false, host_touched = false;
   int view_of = -1;     // >= 0: this blob is channels [view_c0, view_c0+C) of storage `view_of` (merged heads)
   int view_c0 = 0, view_cp = 0;
   Net* owner = nullptr;  // activations: the net whose stream moves this blob between host and device (null: stand-alone blob)
@@ -81,6 +87,7 @@ struct NetBlob {
 // owner's stream (null: the default stream), `base` the concatenated tensor a channel view lives in (else null)
 void storage_to_device(Storage& s, void* stream);
 void storage_to_host(Storage& s, void* stream, Storage* base);
+void storage_download_enqueue(Storage& s, void* stream, Storage* base);  // the device -> host part of it, no wait, head untouched
 void storage_mutable_device(Storage& s, void* stream);  // SyncedMemory::mutable_gpu_data: device image authoritative
 // Blob::CopyFrom (blob.cpp:435-474): wherever the source is authoritative; device copies re-pitch through an NCHW stage
 void storage_copy(Storage& dst, Storage& src, Storage* src_base, void* stream);

@@ -302,7 +302,11 @@ class Net(object):
 
     @property
     def _layer_names(self):
-        return [_lib.dc_net_layer_name(self._h, i).decode() for i in range(_lib.dc_net_num_layers(self._h))]
+        # fixed at construction (Net::Init); forward() looks names up on every call: 734 ctypes round trips otherwise
+        names = self.__dict__.get("_names_cache")
+        if names is None:
+            names = self.__dict__["_names_cache"] = [_lib.dc_net_layer_name(self._h, i).decode() for i in range(_lib.dc_net_num_layers(self._h))]
+        return list(names)
 
     @property
     def layer_types(self):
@@ -333,11 +337,17 @@ class Net(object):
 
     @property
     def inputs(self):
-        return [_lib.dc_net_input_name(self._h, i).decode() for i in range(_lib.dc_net_num_inputs(self._h))]
+        v = self.__dict__.get("_inputs_cache")
+        if v is None:
+            v = self.__dict__["_inputs_cache"] = [_lib.dc_net_input_name(self._h, i).decode() for i in range(_lib.dc_net_num_inputs(self._h))]
+        return list(v)
 
     @property
     def outputs(self):
-        return [_lib.dc_net_output_name(self._h, i).decode() for i in range(_lib.dc_net_num_outputs(self._h))]
+        v = self.__dict__.get("_outputs_cache")
+        if v is None:
+            v = self.__dict__["_outputs_cache"] = [_lib.dc_net_output_name(self._h, i).decode() for i in range(_lib.dc_net_num_outputs(self._h))]
+        return list(v)
 
     @property
     def name(self):
@@ -352,14 +362,18 @@ class Net(object):
     def forward(self, blobs=None, start=None, end=None, **kwargs):
         if blobs is None:
             blobs = []
-        names = self._layer_names
-        start_ind = names.index(start) if start is not None else 0
-        if end is not None:
-            end_ind = names.index(end)
-            outputs = set([end] + blobs)
-        else:
-            end_ind = len(names) - 1
+        if start is None and end is None:
+            start_ind, end_ind = 0, _lib.dc_net_num_layers(self._h) - 1
             outputs = set(self.outputs + blobs)
+        else:
+            names = self._layer_names
+            start_ind = names.index(start) if start is not None else 0
+            if end is not None:
+                end_ind = names.index(end)
+                outputs = set([end] + blobs)
+            else:
+                end_ind = len(names) - 1
+                outputs = set(self.outputs + blobs)
         if kwargs:
             if set(kwargs.keys()) != set(self.inputs):
                 raise Exception("Input blob arguments do not match net inputs.")

@@ -361,3 +361,46 @@ def test_debug_info_matches_the_oracles_blobs(gpu_caffe, synth152):
     net2.blobs["data"].data[...] = img
     net2.forward()
     assert "elided by fusion" in net2.debug_info()
+
+
+def test_outputs_read_through_host_pointers_are_delivered_by_the_next_forwards(gpu_caffe, synth152):
+    """The drop-in sequence `blobs['data'].data[...] = x; net.forward(); blobs['prob'].data` (estimate_pose.py:104-112): an
+    output downloaded on demand once travels inside the following forwards (head SYNCED when forward() returns: `.data` costs
+    no kernel, copy or stream round trip); an output nobody touches is not sent; values are the same either way and the
+    SyncedMemory head walk (syncedmem.cpp:25-77) stays what it was.  (pycaffe's own forward() reads every output blob into the
+    dict it returns, pycaffe.py:108, so the selective part is exercised through the C-level forward.)"""
+    from deepcut_tools import deepercut_prototxt
+
+    AT_GPU, SYNCED, AT_CPU = 2, 3, 1
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 104, 136), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    last = len(net._layer_names) - 1
+    x = rand_image(12, 104, 136)
+    net.blobs["data"].data[...] = x
+    net._forward(0, last)
+    assert net.blobs["prob"].head == AT_GPU and net.blobs["next_pred"].head == AT_GPU  # first forward: nothing was asked for yet
+    first = {k: net.blobs[k].data.copy() for k in ("prob", "loc_pred")}                 # on demand ...
+    assert net.blobs["prob"].head == AT_CPU                                              # ... and mutable_cpu_data marks the host copy
+    for _ in range(2):
+        net.blobs["data"].data[...] = x
+        net._forward(0, last)
+        assert net.blobs["prob"].head == SYNCED and net.blobs["loc_pred"].head == SYNCED  # delivered with the forward
+        assert net.blobs["next_pred"].head == AT_GPU                                       # never read: never sent
+        for k in first:
+            assert np.array_equal(net.blobs[k].data, first[k]), k
+    # stop reading loc_pred: one more delivery (it was touched after the last one), then none
+    net.blobs["data"].data[...] = x
+    net._forward(0, last)
+    _ = net.blobs["prob"].data
+    net.blobs["data"].data[...] = x
+    net._forward(0, last)
+    assert net.blobs["prob"].head == SYNCED and net.blobs["loc_pred"].head == AT_GPU
+    assert np.array_equal(net.blobs["loc_pred"].data, first["loc_pred"])  # on demand again
+    # pycaffe's forward(): all three maps come back in the dict, and from the second call on they were delivered
+    net.blobs["data"].data[...] = x
+    a = {k: v.copy() for k, v in net.forward().items()}
+    net.blobs["data"].data[...] = rand_image(13, 104, 136)
+    net._forward(0, last)
+    assert all(net.blobs[k].head == SYNCED for k in ("prob", "loc_pred", "next_pred"))
+    b = {k: net.blobs[k].data for k in a}
+    assert np.array_equal(a["prob"], first["prob"]) and float(np.abs(b["prob"] - a["prob"]).max()) > 1e-6  # no stale host copy
