@@ -263,7 +263,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 3],
                     help="BASELINE.json configs index: 1 = batch 1 per GPU (the headline), 3 = 8 images of 736x544 per GPU "
                          "(batch 64 sharded 8-way) with the gather of the maps to rank 0")
-    ap.add_argument("--coalesce", type=int, default=2, help="also measure cross-request batching: k batch-1 requests per batch forward (0/1: skip)")
+    ap.add_argument("--coalesce", type=int, default=4,
+                    help="also measure cross-request batching (deepcut_tools.Pipeline, opportunistic): at most k batch-1 requests per batch forward (0/1: skip)")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the configs[2] (fp16 pyramid) measurement printed beside the headline")
     ap.add_argument("--depth", type=int, default=152)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -567,31 +568,46 @@ def main():
                     "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
 
         def cross_request_batching():
-            # deepcut_tools.Pipeline(coalesce=k): the same independent batch-1 requests, merged k at a time into batch-k
-            # forwards on the executors; `value` stays batch-1 forwards in flight
+            # deepcut_tools.Pipeline, its default policy: independent batch-1 requests; one goes out alone while an executor is free,
+            # what queues up behind busy executors leaves as ONE batch forward of up to --coalesce requests (dc_net_forward_requests).
+            # Closed loop: `window` requests outstanding (queued + in flight), a new one submitted for every one that finishes —
+            # the service figure, with the latency a request sees under that load; `value` stays strict batch-1 forwards in flight.
             from deepcut_tools import Pipeline
 
-            pipe = Pipeline(net, depth=len(nets), coalesce=args.coalesce)
+            pipe = Pipeline(net, depth=len(nets), max_batch=args.coalesce)
             pipe.nets = nets  # reuse the executors (and their tuned plans)
-            nreq = args.steps * args.coalesce
+            window = pipe.max_queue + len(nets) * pipe.max_batch
+            nreq = max(args.steps, 10) * 8
             bufs = [(xs[i % S], [torch.empty(B, c, H // 8, W // 8, device=dev) for c in (shp["prob"][1], shp["loc_pred"][1], shp["next_pred"][1])])
-                    for i in range(2 * args.coalesce * len(nets))]
+                    for i in range(2 * window)]
 
-            def burst(count):
-                for i in range(count):
-                    xi, o = bufs[i % len(bufs)]
-                    pipe.submit(xi.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=i)
-                pipe.drain()
+            def closed_loop(count):
+                sent = done = 0
+                while done < count:
+                    while sent < count and sent - done < window:
+                        xi, o = bufs[sent % len(bufs)]
+                        pipe.submit(xi.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=sent)
+                        sent += 1
+                    pipe.wait_one()
+                    done += 1
 
-            burst(4 * args.coalesce * len(nets))
+            closed_loop(6 * window)  # every batch size it will form has been lowered, tuned and captured on every executor
             torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            burst(nreq)
-            torch.cuda.synchronize(dev)
-            dtc = time.perf_counter() - t1
-            return {"value": nreq / dtc, "unit": "images/s", "coalesce": args.coalesce, "executors": len(nets), "requests": nreq,
-                    "note": "independent batch-1 requests merged into batch-%d forwards (dc_net_forward_requests), %d executors"
-                            % (args.coalesce, len(nets))}
+            pipe.reset_stats()
+            dts = []
+            for _ in range(max(1, args.regions)):
+                t1 = time.perf_counter()
+                closed_loop(nreq)
+                torch.cuda.synchronize(dev)
+                dts.append(time.perf_counter() - t1)
+            dtc = sorted(dts)[len(dts) // 2]
+            pct = pipe.latency_percentiles((50, 90, 99))
+            return {"value": nreq / dtc, "value_min": nreq / max(dts), "value_max": nreq / min(dts), "unit": "images/s",
+                    "policy": "opportunistic (whatever is queued when an executor frees, up to %d requests per batch forward)" % pipe.max_batch,
+                    "executors": len(nets), "requests_outstanding": window, "requests_per_region": nreq, "regions": len(dts),
+                    "latency_ms": {"p50": pct.get(50), "p90": pct.get(90), "p99": pct.get(99)},
+                    "batch_sizes": {str(k): v for k, v in sorted(pipe.batch_sizes.items())},
+                    "note": "independent batch-1 requests through deepcut_tools.Pipeline (dc_net_forward_requests); latency = submit -> seen finished, closed loop"}
 
         n_pcie = max(3, min(20, args.steps))
         if world == 1:

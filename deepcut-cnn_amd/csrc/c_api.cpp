@@ -99,6 +99,19 @@ int dc_net_clone(dc_net* net, dc_net** out) {
   *out = nullptr;
   return guard([&] { *out = reinterpret_cast<dc_net*>(N(net)->clone()); });
 }
+int dc_net_busy(dc_net* net, int* busy) {
+  REQUIRE(net);
+  REQUIRE(busy);
+  *busy = 0;
+  if (!N(net)->stream) return DC_OK;
+  hipError_t e = hipStreamQuery((hipStream_t)N(net)->stream);
+  if (e == hipErrorNotReady) {
+    *busy = 1;
+    return DC_OK;
+  }
+  if (e != hipSuccess) return fail(DC_EDEVICE, std::string("hipStreamQuery failed: ") + hipGetErrorString(e));
+  return DC_OK;
+}
 int dc_net_synchronize(dc_net* net) {
   REQUIRE(net);
   return guard([&] { N(net)->synchronize(); });

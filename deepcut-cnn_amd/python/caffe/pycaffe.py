@@ -60,6 +60,7 @@ def _load():
         "dc_net_destroy": (ci, [vp]),
         "dc_net_clone": (ci, [vp, C.POINTER(vp)]),
         "dc_net_synchronize": (ci, [vp]),
+        "dc_net_busy": (ci, [vp, C.POINTER(ci)]),
         "dc_net_set_option": (ci, [vp, ci, ci]),
         "dc_net_get_option": (ci, [vp, ci, C.POINTER(ci)]),
         "dc_net_copy_from": (ci, [vp, cp]),
@@ -550,6 +551,12 @@ class Net(object):
 
     def synchronize(self):
         _check(_lib.dc_net_synchronize(self._h))
+
+    def busy(self):
+        """True while work enqueued on the net's own stream (stream="own") has not finished (non-blocking)."""
+        b = C.c_int()
+        _check(_lib.dc_net_busy(self._h, C.byref(b)))
+        return bool(b.value)
 
     STAT_NAMES = ("lowerings", "graph_instantiations", "plan_hits", "autotune_runs", "buffer_growths", "repacks",
                   "cached_plans")

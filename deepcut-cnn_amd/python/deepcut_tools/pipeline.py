@@ -1,51 +1,110 @@
-"""Several independent forwards in flight on one GPU, optionally coalesced into small batches.
+"""Several independent forwards in flight on one GPU, coalesced into small batches as they queue up.
 
 A batch-1 layer of the DeeperCut net is a 5-25 us problem that fills ~3/4 of the 256 CUs, a third of it fixed cost, so ONE
-forward at a time reaches ~48 % of the fp32-MFMA roof.  `Pipeline` keeps `depth` executors busy (a Net and its clones: own
-activations, own HIP stream, own hipGraph, SHARED parameters, packed weights and tile choices); requests go to them
-round-robin and the kernels of one fill the CUs and gaps another leaves idle (3 executors: x1.4).  With `coalesce` = k > 1,
-k consecutive same-shape requests are first merged into ONE batch-k forward (cross-request batching,
-dc_net_forward_requests): the launches fill the chip and pay their fixed cost once per k images.
+forward at a time reaches ~50 % of the fp32-MFMA roof.  `Pipeline` keeps `depth` executors busy (a Net and its clones: own
+activations, own HIP stream, own hipGraph, SHARED parameters, packed weights and tile choices).  Requests are single images
+(or whole batches with coalescing off); by default they are coalesced OPPORTUNISTICALLY: a request goes out at once, alone, if
+an executor is free; while all executors are busy requests queue up, and the executor that frees next takes whatever is queued
+— up to `max_batch` same-shape requests — as ONE batch forward (cross-request batching, dc_net_forward_requests: the launches
+fill the chip and pay their fixed cost once per batch).  Light load: batch-1 latency; heavy load: batch-`max_batch` throughput.
+`coalesce=k` (an int) is the fixed policy of rounds 2-3: hold requests until k are there.
 Device-resident interface: the caller owns NCHW float32 device buffers (e.g. torch CUDA tensors) and keeps them alive
 until the request's tag comes back from wait_one() / drain().  Three executors is the useful maximum: a HIP process has
 four hardware queues, and more concurrent kernels only evict each other's tiles from the 4 MB L2s.
+The reference forwards one image at a time (src/caffe/layers/conv_layer.cpp:31): nothing to mirror.
 """
 import collections
+import time
 
 
 class Pipeline(object):
-    def __init__(self, net, depth=3, coalesce=1):
+    def __init__(self, net, depth=3, coalesce=None, max_batch=4, max_queue=None):
         self.nets = [net] + [net.clone() for _ in range(max(1, depth) - 1)]
-        self.coalesce = max(1, int(coalesce))
+        self.opportunistic = coalesce is None
+        self.coalesce = 1 if coalesce is None else max(1, int(coalesce))
+        self.max_batch = max(1, int(max_batch)) if self.opportunistic else self.coalesce
+        # requests that may wait for an executor before submit() blocks: one full batch per executor
+        self.max_queue = int(max_queue) if max_queue is not None else self.max_batch * len(self.nets)
         self._next = 0
-        self._pending = collections.deque()  # (executor, [tags])
-        self._held = []                      # requests waiting for their batch to fill: (in, h, w, prob, loc, next, tag)
+        self._pending = collections.deque()  # (executor, [(tag, submit time)]) in launch order
+        self._held = collections.deque()     # queued requests: (in, h, w, prob, loc, next, tag, n, submit time)
         self._done = collections.deque()     # tags of finished requests not yet handed back
+        self.latencies = []                  # seconds from submit() to the moment the request was seen finished
+        self.batch_sizes = collections.Counter()
 
     @property
     def depth(self):
         return len(self.nets)
 
-    def _launch(self, reqs):
-        if len(self._pending) >= len(self.nets):
-            self._wait_group()
-        k = self._next
+    # ---- launching ---------------------------------------------------------------------------------------------------
+    def _free_executor(self):
+        busy = set(k for k, _ in self._pending)
+        for i in range(len(self.nets)):
+            k = (self._next + i) % len(self.nets)
+            if k not in busy:
+                return k
+        return None
+
+    def _launch(self, reqs, k=None):
+        if k is None:
+            if len(self._pending) >= len(self.nets):
+                self._wait_group()
+            k = self._free_executor()
         self._next = (k + 1) % len(self.nets)
         h, w = reqs[0][1], reqs[0][2]
-        if len(reqs) == 1 and self.coalesce == 1:
+        if len(reqs) == 1 and (reqs[0][7] != 1 or self.max_batch == 1):
             r = reqs[0]
             self.nets[k].forward_device(r[0], r[7], h, w, r[3], r[4], r[5], stream="own")
         else:
             self.nets[k].forward_requests([r[0] for r in reqs], h, w, [r[3] for r in reqs], [r[4] for r in reqs],
                                           [r[5] for r in reqs], stream="own")
-        self._pending.append((k, [r[6] for r in reqs]))
+        self.batch_sizes[len(reqs)] += 1
+        self._pending.append((k, [(r[6], r[8]) for r in reqs]))
         return k
 
+    def _reap(self):
+        """Collect every group that has finished, without blocking (the streams are independent: any of them may be first)."""
+        now = None
+        keep = collections.deque()
+        while self._pending:
+            k, tags = self._pending.popleft()
+            if self.nets[k].busy():
+                keep.append((k, tags))
+                continue
+            now = now or time.perf_counter()
+            for tag, t0 in tags:
+                self._done.append(tag)
+                self.latencies.append(now - t0)
+        self._pending = keep
+
+    def _take_batch(self):
+        first = self._held.popleft()
+        reqs = [first]
+        while self._held and len(reqs) < self.max_batch and first[7] == 1 and self._held[0][7] == 1 and \
+                (self._held[0][1], self._held[0][2]) == (first[1], first[2]):
+            reqs.append(self._held.popleft())
+        return reqs
+
+    def _pump(self):
+        self._reap()
+        while self._held:
+            k = self._free_executor() if len(self._pending) < len(self.nets) else None
+            if k is None:
+                if len(self._held) <= self.max_queue:
+                    return
+                self._wait_group()  # the queue is full: wait for the oldest group, then hand it more work
+                continue
+            self._launch(self._take_batch(), k)
+
     def submit(self, in_ptr, n, h, w, prob_ptr=None, loc_ptr=None, next_ptr=None, tag=None):
-        """Enqueue one forward (asynchronous).  If every executor is busy, waits for the oldest group first.  With
-        coalesce > 1 (single-image requests only) the request is held until `coalesce` same-shape requests are there (or
-        flush() / drain() is called)."""
-        req = (in_ptr, h, w, prob_ptr, loc_ptr, next_ptr, tag, n)
+        """Enqueue one forward (asynchronous).  Opportunistic mode: launched at once if an executor is free, else queued (and
+        coalesced with its neighbours when one frees); blocks only when `max_queue` requests are waiting.  Fixed mode
+        (coalesce=k, single-image requests only): held until k same-shape requests are there (or flush() / drain())."""
+        req = (in_ptr, h, w, prob_ptr, loc_ptr, next_ptr, tag, n, time.perf_counter())
+        if self.opportunistic:
+            self._held.append(req)
+            self._pump()
+            return None
         if self.coalesce == 1:
             return self._launch([req])
         if n != 1:
@@ -58,21 +117,31 @@ class Pipeline(object):
         return None
 
     def flush(self):
-        """Launch the held requests as they are (a partial batch)."""
-        if self._held:
-            held, self._held = self._held, []
-            self._launch(held)
+        """Launch whatever is queued as it is (partial batches included)."""
+        while self._held:
+            self._launch(self._take_batch())
 
     def _wait_group(self):
         k, tags = self._pending.popleft()
         self.nets[k].synchronize()
-        self._done.extend(tags)
+        now = time.perf_counter()
+        for tag, t0 in tags:
+            self._done.append(tag)
+            self.latencies.append(now - t0)
 
     def wait_one(self):
-        """Block until the oldest in-flight request has finished; returns its tag."""
+        """Block until a request has finished; returns its tag (requests of one executor finish in order)."""
         if not self._done:
-            self.flush()
-            self._wait_group()
+            if self.opportunistic:
+                self._pump()
+                if not self._done and not self._pending:
+                    self.flush()
+            else:
+                self.flush()
+            if not self._done:
+                self._wait_group()
+            if self.opportunistic:
+                self._pump()  # an executor is free now: give it the queued requests before returning to the caller
         return self._done.popleft()
 
     def drain(self):
@@ -83,24 +152,43 @@ class Pipeline(object):
         self._done.clear()
         return tags
 
+    def latency_percentiles(self, qs=(50, 99)):
+        """Request latency (submit -> seen finished) in milliseconds at the given percentiles, over everything since the last
+        reset_stats()."""
+        v = sorted(self.latencies)
+        if not v:
+            return {}
+        return {q: v[min(len(v) - 1, int(round(q / 100.0 * (len(v) - 1))))] * 1e3 for q in qs}
+
+    def reset_stats(self):
+        self.latencies = []
+        self.batch_sizes = collections.Counter()
+
     def tune(self, requests, rounds=4, **kw):
         """Re-tune the tiles of the requests' shape for THIS pipeline's load (depth executors, this coalescing): the
         autotuner chose them for one forward alone.  `requests`: a list of submit() argument tuples (in_ptr, n, h, w,
-        prob_ptr, loc_ptr, next_ptr) of one shape, at least depth * coalesce of them, whose buffers may be overwritten; the
-        burst is replayed `rounds` times per measurement.  Returns what deepcut_tools.tune_in_flight returns."""
-        import time
-
+        prob_ptr, loc_ptr, next_ptr) of one shape whose buffers may be overwritten — a multiple of the batch size times the
+        depth, so that every executor meets the same batch shape (a partial batch would put one executor on another plan);
+        the burst is replayed `rounds` times per measurement.  Returns what deepcut_tools.tune_in_flight returns."""
         from .tuning import tune_in_flight
 
         if self._pending or self._held:
             raise RuntimeError("tune() wants an idle pipeline")
+        per = self.max_batch * len(self.nets)
+        if len(requests) == 0 or len(requests) % per:
+            raise ValueError("tune() wants a multiple of batch size x depth = %d requests (got %d)" % (per, len(requests)))
+        fixed = Pipeline.__new__(Pipeline)  # the same executors under the fixed policy: every batch full, every run alike
+        fixed.__dict__.update(self.__dict__)
+        fixed.opportunistic, fixed.coalesce = False, self.max_batch
+        fixed._pending, fixed._held, fixed._done = collections.deque(), collections.deque(), collections.deque()
+        fixed.latencies, fixed.batch_sizes = [], collections.Counter()
 
         def load():
             t0 = time.perf_counter()
             for _ in range(rounds):
                 for r in requests:
-                    self.submit(*r)
-            self.drain()
+                    fixed.submit(*r)
+            fixed.drain()
             return time.perf_counter() - t0
 
         load()  # every executor has lowered (and tuned, for latency) the shape

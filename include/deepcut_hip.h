@@ -83,6 +83,9 @@ int dc_net_destroy(dc_net* net);
 int dc_net_clone(dc_net* net, dc_net** out);
 /* wait for everything enqueued on the net's own stream (see DC_STREAM_OWN)                                */
 int dc_net_synchronize(dc_net* net);
+/* non-blocking: *busy = 1 while work enqueued on the net's own stream (DC_STREAM_OWN) has not finished, else 0 — what a
+ * dispatcher polls to hand queued requests to whichever executor is free (deepcut_tools.Pipeline); no reference counterpart  */
+int dc_net_busy(dc_net* net, int* busy);
 int dc_net_set_option(dc_net* net, int key, int value);
 int dc_net_get_option(dc_net* net, int key, int* value);
 /* Net::CopyTrainedLayersFrom(file) (net.cpp:805-858): match by layer name, check blob

@@ -222,7 +222,8 @@ def test_pipeline_of_clones_matches_sequential(gpu_caffe, synth152):
     torch.cuda.synchronize()
     for i, im in enumerate(imgs):
         pipe.submit(im.data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
-    assert pipe.drain()[-1] == 6
+    assert sorted(pipe.drain()) == list(range(7))  # (opportunistic coalescing by default: groups finish in any order)
+    assert sum(k * v for k, v in pipe.batch_sizes.items()) == 7 and len(pipe.latencies) == 7
     for i in range(len(imgs)):
         for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
             assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)
@@ -404,3 +405,47 @@ def test_outputs_read_through_host_pointers_are_delivered_by_the_next_forwards(g
     assert all(net.blobs[k].head == SYNCED for k in ("prob", "loc_pred", "next_pred"))
     b = {k: net.blobs[k].data for k in a}
     assert np.array_equal(a["prob"], first["prob"]) and float(np.abs(b["prob"] - a["prob"]).max()) > 1e-6  # no stale host copy
+
+
+def test_pipeline_coalesces_what_queues_up_and_equals_the_batch_forward(gpu_caffe, synth152):
+    """Opportunistic cross-request batching (Pipeline's default): a request goes out alone while an executor is free; what
+    queues up behind busy executors leaves as ONE batch forward of up to max_batch requests.  (a) every request gets its own
+    maps whatever batch it travelled in; (b) two requests coalesced are BIT-identical to rows 0 / 1 of the batch-2 forward of
+    the same two images (same plan, same tiles: dc_net_forward_requests only gathers / scatters); (c) latencies are recorded."""
+    import torch
+    from deepcut_tools import Pipeline, deepercut_prototxt
+
+    path, _ = synth152
+    h, w = 104, 136
+    net = gpu_caffe.Net(deepercut_prototxt(152, h, w), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    dev = torch.device("cuda", 0)
+    imgs = [torch.from_numpy(rand_image(50 + i, h, w)).to(dev) for i in range(12)]
+    ref = [net.forward_batch(im.cpu().numpy()) for im in imgs]
+    outs = [[torch.empty(1, c, h // 8, w // 8, device=dev) for c in (14, 28, 364)] for _ in imgs]
+    pipe = Pipeline(net, depth=2, max_batch=4)
+    assert pipe.opportunistic and pipe.max_queue == 8
+    for rep in range(2):  # second round: every batch shape has been lowered and captured, the host floods the queue
+        for o in outs:
+            for t in o:
+                t.zero_()
+        pipe.reset_stats()
+        for i, im in enumerate(imgs):
+            pipe.submit(im.data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
+        got = [pipe.wait_one() for _ in range(4)] + pipe.drain()
+        assert sorted(got) == list(range(12))
+        for i in range(len(imgs)):
+            for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
+                assert np.abs(t.cpu().numpy() - ref[i][k]).max() <= 1e-5, (i, k)
+    assert sum(k * v for k, v in pipe.batch_sizes.items()) == 12 and max(pipe.batch_sizes) > 1, dict(pipe.batch_sizes)
+    pct = pipe.latency_percentiles((50, 99))
+    assert len(pipe.latencies) == 12 and 0 < pct[50] <= pct[99]
+    # (b) bit-identical to the batch forward they became
+    two = Pipeline(net, depth=1, coalesce=2)
+    two.nets = pipe.nets[:1]
+    for i in (3, 8):
+        two.submit(imgs[i].data_ptr(), 1, h, w, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), tag=i)
+    assert sorted(two.drain()) == [3, 8]
+    both = net.forward_batch(np.concatenate([imgs[3].cpu().numpy(), imgs[8].cpu().numpy()]))
+    for row, i in enumerate((3, 8)):
+        for k, t in zip(("prob", "loc_pred", "next_pred"), outs[i]):
+            assert np.array_equal(t.cpu().numpy()[0], both[k][row]), (i, k)

@@ -108,7 +108,9 @@ def test_pipeline_tune_runs_its_own_load(gpu_caffe, synth152, monkeypatch):
     dev = torch.device("cuda", 0)
     x = torch.from_numpy(rand_image(11, H, W)).to(dev)
     ref = net.blobs["prob"].data.copy()
-    pipe = Pipeline(net, depth=2)
+    pipe = Pipeline(net, depth=2, max_batch=2)
+    with pytest.raises(ValueError):
+        pipe.tune([(x.data_ptr(), 1, H, W, None, None, None)] * 3)  # not a multiple of batch size x depth
     outs = [[torch.empty(1, c, H // 8, W // 8, device=dev) for c in (14, 28, 364)] for _ in range(4)]
     reqs = [(x.data_ptr(), 1, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr()) for o in outs]
     res = pipe.tune(reqs, rounds=2, top=3, reps=1)
