@@ -249,6 +249,122 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
     return res
 
 
+def rank_identity(backend, dev):
+    """What THIS rank runs on — gathered from every rank into config.distributed so that the N>1 line verifies itself: under
+    `nccl` (= RCCL) every rank must sit on a GPU of its own (uuid / PCI bus id), and the line shows what RCCL saw."""
+    import socket
+
+    import torch
+
+    ident = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "host": socket.gethostname(),
+             "pid": os.getpid(), "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}
+    if dev is not None and dev.type == "cuda":
+        p = torch.cuda.get_device_properties(dev)
+        ident.update({"device_index": dev.index, "device_name": p.name, "uuid": str(getattr(p, "uuid", "")),
+                      "pci": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+                      "hbm_gb": round(p.total_memory / 2 ** 30, 1)})
+    else:
+        ident.update({"device_index": None, "device_name": "none (dry run: no forwards)", "uuid": "", "pci": ""})
+    return ident
+
+
+def one_gpu_per_rank(ids, backend):
+    """Under nccl (= RCCL) two ranks on one GPU would make every scaling number meaningless: refuse."""
+    if backend != "nccl" or len(ids) < 2:
+        return
+    seen = {}
+    for i in ids:
+        key = (i["host"], i["uuid"] or i["pci"])
+        if key in seen:
+            raise SystemExit("bench.py: ranks %d and %d both run on GPU %s of %s under nccl: one process per GPU is the contract"
+                             % (seen[key], i["rank"], key[1], key[0]))
+        seen[key] = i["rank"]
+
+
+def distributed_report(backend, dev, world, payload_bytes, gather_gbps):
+    """All-gather the rank identities, refuse two ranks on one GPU under nccl, and describe the exchange."""
+    import torch
+    import torch.distributed as dist
+
+    me = rank_identity(backend, dev)
+    ids = [None] * world
+    if world > 1:
+        dist.all_gather_object(ids, me)
+    else:
+        ids = [me]
+    one_gpu_per_rank(ids, backend)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:  # noqa: BLE001
+        rccl = None
+    return {"backend": backend, "ranks_seen": dist.get_world_size() if world > 1 else 1, "rccl_version": rccl,
+            "ranks": ids, "distinct_devices": len(set((i["host"], i["uuid"] or i["pci"] or i["rank"]) for i in ids)),
+            "gather": {"pattern": "grouped isend/irecv of prob|loc_pred|next_pred to rank 0 (no ring, no reduction): every peer sends over its own "
+                                  "xGMI link into the root",
+                       "payload_bytes_per_rank_per_step": payload_bytes, "bytes_into_rank0_per_step": payload_bytes * (world - 1),
+                       "expected_per_link_bytes_per_step": payload_bytes,
+                       "measured_gather_gbps_into_rank0": gather_gbps}}
+
+
+def dry_run(args):
+    """`--dry-run`: the N>1 control path WITHOUT forwards, for a box with no GPU (the CPU test suite runs it at world size 8 over
+    gloo): process group, rank identities, the gather of payloads of exactly the size the real run sends (shapes from the
+    prototxt, host only), barriers and the max-over-ranks timing, one JSON line marked `dry_run`.  `value` is null: nothing
+    was forwarded."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    import caffe
+    from deepcut_tools import deepercut_prototxt, gather_maps_known
+
+    H, W, B = args.height, args.width, args.batch
+    net = caffe.Net(deepercut_prototxt(args.depth, H, W, B), caffe.TEST, from_text=True, dtype=args.dtype)  # host only: shapes
+    nel = sum(int(np.prod(net.blobs[k].shape)) for k in ("prob", "loc_pred", "next_pred"))
+    dt_t = torch.float16 if args.dtype == "f16" else torch.float32
+    out = torch.full((nel,), float(rank), dtype=dt_t)
+    sizes = [nel] * world
+    recvs = [torch.empty_like(out) for _ in range(world)] if rank == 0 and world > 1 else None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        gather_maps_known(out, sizes, 0, None, out=recvs)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gather_maps_known(out, sizes, 0, None, out=recvs)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0 and world > 1:
+        for r in range(1, world):
+            assert float(recvs[r][0]) == float(r) and float(recvs[r][-1]) == float(r), "rank %d's payload did not arrive" % r
+    payload = nel * out.element_size()
+    rep = distributed_report("gloo", None, world, payload, payload * (world - 1) * args.steps / float(tt.item()) / 1e9 if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN: control path of `bench.py --gpus %d` without forwards (no GPU needed)" % world, "dry_run": True,
+                          "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": float(tt.item()) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": args.dtype, "data": "synthetic payloads of the real run's size",
+                          "config": {"workload": "gather of batch=%d x %dx%d maps per rank (BASELINE configs[%d]), %s payload" % (B, W, H, args.config, args.dtype),
+                                     "per_gpu_batch": B, "global_batch": B * world, "distributed": rep}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,9 +396,13 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("DC_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real thing) or gloo (lets two ranks share one "
                          "GPU to smoke-test the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N>1 control path only (process group, rank identities, gather of real-size payloads over gloo), no forwards, no GPU")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = 8 if args.config == 3 else 1
+    if args.dry_run:
+        return dry_run(args)
     if args.streams <= 0:  # forwards kept in flight: 3 at batch 1, 2 at batch 8
         args.streams = 3 if args.batch < 4 else 2
 
@@ -447,6 +567,25 @@ def main():
         dt, ev_ms, dt_all = lat_dt, lat_ev_ms, lat_all
     x = xs[0]
 
+    # N > 1: the exchange alone (no forwards): what rank 0's seven receives reach, and who the ranks are
+    gather_gbps = None
+    payload_bytes = outs[0].numel() * outs[0].element_size()
+    if world > 1:
+        fence()
+        g0 = time.perf_counter()
+        for _ in range(10):
+            if args.backend == "nccl":
+                _b, reqs = gather_maps_known(outs[0], sizes, 0, None, out=recvs[0], async_op=True)
+                for q in reqs:
+                    q.wait()
+            else:
+                gather_maps_known(outs[0].cpu(), sizes, 0, None, out=recvs[0])
+        fence()
+        gt = torch.tensor([time.perf_counter() - g0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_gbps = payload_bytes * (world - 1) * 10 / float(gt.item()) / 1e9
+    dist_report = distributed_report(args.backend if world > 1 else "none", dev, world, payload_bytes, gather_gbps)
+
     if rank == 0:
         total_images = args.steps * B * world
         launches = net.num_launches()
@@ -490,6 +629,7 @@ def main():
                                 % (len(tuning["changed"]), tuning.get("skipped", 0), tuning["before"] * 1e3, tuning["after"] * 1e3, 6 * S, tuning["runs"])
                                 if tuning and "error" not in tuning else ("latency" if not tuning else tuning["error"])),
                 "parallelism": "dp%d (images sharded, maps gathered to rank 0 by RCCL send/recv)" % world if world > 1 else "single GPU",
+                "distributed": dist_report,
             },
             "tflops": total_images * flops_img / dt / 1e12,
             "one_forward_at_a_time": {"value": total_images / lat_dt, "value_min": total_images / max(lat_all),
