@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
   constexpr int SPC = Elem<T>::SPC;
   constexpr int NW = WR * WC * WK;       // waves per workgroup (4 or 8)
   constexpr int NT = NW * 64;
-  static_assert(NW == 4 || NW == 8 || (NW == 16 && DMA), "4 or 8 waves per workgroup (16 compiles for the LDS-DMA tiles: measured, no gain — DESIGN 8b)");
+  static_assert(NW == 4 || NW == 8 || (NW == 16 && DMA), "4 or 8 waves per workgroup (16 compiles for the LDS-DMA tiles: measured, no gain — EXPERIMENTS.md A)");
   constexpr int LDB = DMA ? BK * ES : BK * ES + 16;  // LDS row, bytes: padded (16-B aligned, bank-spread), or 128 swizzled (DMA)
   static_assert(!DMA || BK * ES == 128 || BK * ES == 256, "the LDS-DMA image has 128- or 256-byte rows (8 / 16 chunks of 16 bytes, XOR-swizzled)");
   static_assert(DMA == 0 || (DMA >= 2 && DMA <= 4), "ring of 2..4 LDS stages");
@@ -1201,7 +1201,7 @@ const VariantEntry kVariants[] = {
     DC_VARIANT_HD_T(128, 128, 2, 2, 1, 2),    // 45: LDS-transposed epilogue instead of the swapped-operand one
     DC_VARIANT_HD_T(64, 128, 2, 2, 1, 2),     // 46
     // float32 through LDS-DMA: the fp32 matrix pipe is 16x slower than the fp16 one, staging is not its limiter — these
-    // tie with the register-ring tiles (+-3 % at batch 1, up to -5 % at batch 8: DESIGN 8b); the autotuner takes the wins
+    // tie with the register-ring tiles (+-3 % at batch 1, up to -5 % at batch 8: EXPERIMENTS.md A); the autotuner takes the wins
     DC_VARIANT_FD(32, 64, 64, 1, 2, 4, 3),    // 47: the res4/res5 batch-1 tile (8 waves, split-K 4)
     DC_VARIANT_FD(64, 128, 32, 2, 2, 2, 3),   // 48
     DC_VARIANT_FD(64, 64, 32, 2, 2, 2, 4),    // 49

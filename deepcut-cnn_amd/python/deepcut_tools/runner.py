@@ -73,18 +73,24 @@ class ShardedPoseRunner(object):
     decode_pose(scale)->[n,5,J]).  `preprocess(image, scale) -> HxWx3 float32` defaults to pose.estimate_pose's."""
 
     def __init__(self, net, preprocess=None, group=None, max_batch=16, device=None, device_preprocess=True, depth=1,
-                 half_maps=None):
+                 half_maps=None, group_size=4):
         """depth > 1 (device pipeline): that many batches are kept in flight on this GPU, each on its own executor
         (`net.clone()`: shared weights, shared tile choices) and stream — upload, pre-processing, forward and decode of
         one batch overlap the others'; results equal depth 1 up to the batch composition (same kernels, same order).
-        half_maps: send float16 maps (default: whenever the net computes in float16)."""
+        group_size > 1 (device pipeline, default 4): up to that many consecutive batches of this rank — the scales of a
+        pyramid, the crop sizes of a crowd image — run as ONE grouped launch sequence (caffe.NetGroup: every layer once over
+        all of them, dc_group_forward_images) instead of one forward each; results equal the ungrouped run up to the fp32
+        summation order of the tiles chosen.  half_maps: send float16 maps (default: whenever the net computes in float16)."""
         self.net = net
         self.group = group
         self.max_batch = max_batch
         self.device = device
         self.depth = max(1, int(depth))
         self.half_maps = half_maps
+        self.group_size = max(1, int(group_size))
         self._execs = None
+        self._members = None   # grouped: per executor slot, the member nets (a net and its clones)
+        self._groups = None    # grouped: per executor slot, {members used: caffe.NetGroup}
         self._seen = set()
         self.image_entry = bool(device_preprocess and preprocess is None and hasattr(net, "forward_images"))
         if preprocess is None:
@@ -123,11 +129,22 @@ class ShardedPoseRunner(object):
 
         dev = self._torch_device()
         comm_dev = self._comm_device(dist, dev) if world > 1 else None
+        G = self.group_size
+        try:
+            import caffe
+
+            grouped = G > 1 and hasattr(caffe, "NetGroup") and isinstance(self.net, caffe.Net)
+        except Exception:  # noqa: BLE001
+            grouped = False
         with torch.cuda.device(dev):
             if self._execs is None:
                 self._execs = [self.net] + [self.net.clone() for _ in range(self.depth - 1)]
                 self._streams = [torch.cuda.Stream(dev) for _ in self._execs]
                 self._comm_stream = torch.cuda.Stream(dev)
+            if grouped and self._members is None:
+                # slot e: executor e itself + G - 1 clones of it (member j of a unit runs batch j of the unit)
+                self._members = [[ex] + [ex.clone() for _ in range(G - 1)] for ex in self._execs]
+                self._groups = [dict() for _ in self._execs]
         chans = [self.net.blobs[n].shape[1] for n in MAP_NAMES]
         nj, ctot = chans[0], sum(chans)
         half = self.half_maps if self.half_maps is not None else getattr(self.net, "dtype", "f32") == "f16"
@@ -149,11 +166,11 @@ class ShardedPoseRunner(object):
         def finish(e):
             if busy[e] is None:
                 return
-            chunk, pose_t, _img_t = busy[e]
             self._streams[e].synchronize()
-            host = pose_t.cpu().numpy()
-            for j, k in enumerate(chunk):
-                poses[k] = host[j]
+            for chunk, pose_t, _img_t in busy[e]:
+                host = pose_t.cpu().numpy()
+                for j, k in enumerate(chunk):
+                    poses[k] = host[j]
             busy[e] = None
 
         def exchange_round(k, done_event):
@@ -187,57 +204,78 @@ class ShardedPoseRunner(object):
                     sent.remove((rq0, kk))
 
         rounds = max([len(b) for b in batches_of]) if want_maps and world > 1 else 0
-        for bi, (src_hw, s, in_hw, chunk) in enumerate(mine):
-            e = bi % self.depth
+        # a unit = the batches that run as one launch sequence: G consecutive batches grouped, else one batch
+        step = G if grouped else 1
+        units = [list(range(u0, min(u0 + step, len(mine)))) for u0 in range(0, len(mine), step)]
+        for ui, unit in enumerate(units):
+            e = ui % self.depth
             finish(e)
-            key = (len(chunk), in_hw)
+            key = tuple((len(mine[bi][3]), mine[bi][2]) for bi in unit)
             if key not in self._seen:
-                # first meeting of a shape: its tiles are timed on the device inside this call — with the GPU to itself
+                # first meeting of a shape (set): its tiles are timed on the device inside this call — with the GPU to itself
                 # (timings taken under the other executors' kernels are noise, and every executor shares the choice)
                 for q in range(self.depth):
                     finish(q)
                 self._seen.add(key)
             st = self._streams[e]
-            ids = tuple(items[k][0] for k in chunk)
-            with torch.cuda.device(dev), torch.cuda.stream(st):
-                # the scales of a pyramid forward the SAME images: their uint8 pixels are stacked and uploaded once
-                if ids not in uploaded:
-                    up = torch.from_numpy(np.stack([images[i] for i in ids])).to(dev, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    uploaded[ids] = (up, ev)
-                img_t, up_ev = uploaded[ids]
-                st.wait_event(up_ev)  # the upload may have been enqueued on another executor's stream
-                uses_left[ids] -= 1
-                if uses_left[ids] == 0:
-                    del uploaded[ids]  # last scale of these images: busy[e] keeps the tensor alive until its forward is done
-                pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device=dev)
-                mbuf = torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None
-            assert img_t.device == dev and pose_t.device == dev
-            ex = self._execs[e]
-            ex.forward_images_device(img_t.data_ptr(), len(chunk), src_hw[0], src_hw[1], s, pose_ptr=pose_t.data_ptr(),
-                                     stream=st.cuda_stream)
+            held = []  # per batch of the unit: (chunk, pose tensor, image stack) — alive until the unit has finished
+            mbufs = []
+            for bi in unit:
+                src_hw, s, in_hw, chunk = mine[bi]
+                ids = tuple(items[k][0] for k in chunk)
+                with torch.cuda.device(dev), torch.cuda.stream(st):
+                    # the scales of a pyramid forward the SAME images: their uint8 pixels are stacked and uploaded once
+                    if ids not in uploaded:
+                        up = torch.from_numpy(np.stack([images[i] for i in ids])).to(dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        uploaded[ids] = (up, ev)
+                    img_t, up_ev = uploaded[ids]
+                    st.wait_event(up_ev)  # the upload may have been enqueued on another executor's stream
+                    uses_left[ids] -= 1
+                    if uses_left[ids] == 0:
+                        del uploaded[ids]  # last scale of these images: `held` keeps the tensor alive until its forward is done
+                    pose_t = torch.empty((len(chunk), 5, nj), dtype=torch.float64, device=dev)
+                    mbufs.append(torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None)
+                assert img_t.device == dev and pose_t.device == dev
+                held.append((chunk, pose_t, img_t))
+            if grouped:
+                members = self._members[e][:len(unit)]
+                grp = self._groups[e].get(len(unit))
+                if grp is None:
+                    grp = self._groups[e][len(unit)] = caffe.NetGroup(members)
+                grp.forward_images_device([h[2].data_ptr() for h in held], [(len(mine[bi][3]),) + tuple(mine[bi][0]) for bi in unit],
+                                          [mine[bi][1] for bi in unit], pose_ptrs=[h[1].data_ptr() for h in held], stream=st.cuda_stream)
+            else:
+                members = [self._execs[e]]
+                src_hw, s, _in_hw, chunk = mine[unit[0]]
+                members[0].forward_images_device(held[0][2].data_ptr(), len(chunk), src_hw[0], src_hw[1], s, pose_ptr=held[0][1].data_ptr(),
+                                                 stream=st.cuda_stream)
             done = None
             if want_maps:
-                if key not in checked_shapes:
-                    # the payload layout assumes stride-8 maps (msize): check it against the net once per shape instead of
-                    # letting emit_maps write past the buffer for a model with another stride
-                    checked_shapes.add(key)
-                    for name, c in zip(MAP_NAMES, chans):
-                        got = tuple(ex.blobs[name].shape)
-                        want = (len(chunk), c, in_hw[0] // 8, in_hw[1] // 8)
-                        if got != want:
-                            raise ValueError("map %r has shape %s, the exchange expects %s (stride-8 maps)" % (name, got, want))
-                hw8 = (in_hw[0] // 8) * (in_hw[1] // 8) * len(chunk)
-                o1, o2 = chans[0] * hw8, (chans[0] + chans[1]) * hw8
-                ex.emit_maps_device(mbuf[:o1].data_ptr(), mbuf[o1:o2].data_ptr(), mbuf[o2:].data_ptr(), half=half,
-                                    stream=st.cuda_stream)
-                payload[bi] = mbuf
+                for ex, bi, mbuf in zip(members, unit, mbufs):
+                    _src, _s, in_hw, chunk = mine[bi]
+                    skey = (len(chunk), in_hw)
+                    if skey not in checked_shapes:
+                        # the payload layout assumes stride-8 maps (msize): check it against the net once per shape instead of
+                        # letting emit_maps write past the buffer for a model with another stride
+                        checked_shapes.add(skey)
+                        for name, c in zip(MAP_NAMES, chans):
+                            got = tuple(ex.blobs[name].shape)
+                            want = (len(chunk), c, in_hw[0] // 8, in_hw[1] // 8)
+                            if got != want:
+                                raise ValueError("map %r has shape %s, the exchange expects %s (stride-8 maps)" % (name, got, want))
+                    hw8 = (in_hw[0] // 8) * (in_hw[1] // 8) * len(chunk)
+                    o1, o2 = chans[0] * hw8, (chans[0] + chans[1]) * hw8
+                    ex.emit_maps_device(mbuf[:o1].data_ptr(), mbuf[o1:o2].data_ptr(), mbuf[o2:].data_ptr(), half=half,
+                                        stream=st.cuda_stream)
+                    payload[bi] = mbuf
                 done = torch.cuda.Event()
                 done.record(st)
-            busy[e] = (chunk, pose_t, img_t)
-            if bi < rounds:
-                exchange_round(bi, done)
+            busy[e] = held
+            for bi in unit:
+                if bi < rounds:
+                    exchange_round(bi, done)
         for e in range(self.depth):
             finish(e)
         for k in range(len(mine), rounds):  # rounds in which this rank has nothing to send (rank 0 may still receive)

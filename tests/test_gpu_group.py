@@ -218,3 +218,33 @@ def test_head_channel_split_parity(gpu_caffe, synth152, refs, monkeypatch, dtype
         (_check16 if dtype == "f16" else _check32)(o, ref)
     own = grp.nets[1].forward_batch(refs[2][0])
     (_check16 if dtype == "f16" else _check32)(own, refs[2][1])
+
+
+@pytest.mark.parametrize("dtype,depth", [("f32", 1), ("f16", 2)])
+def test_sharded_runner_groups_the_scales_of_a_pyramid(gpu_caffe, synth152, dtype, depth):
+    """deepcut_tools.ShardedPoseRunner (the product form of BASELINE configs 3-5): by default the batches of a rank run in
+    groups of four — the four scales of the pyramid as one launch sequence; poses and maps equal the batch-by-batch run."""
+    from deepcut_tools import ShardedPoseRunner, deepercut_prototxt
+
+    path, _ = synth152
+    net = gpu_caffe.Net(deepercut_prototxt(152, 96, 128, 3), path, gpu_caffe.TEST, from_text=True, dtype=dtype, hipgraph=1)
+    rs = np.random.RandomState(8)
+    imgs = [rs.randint(0, 256, (96, 128, 3)).astype(np.uint8) for _ in range(5)] + [rs.randint(0, 256, (80, 112, 3)).astype(np.uint8)]
+    scales = [0.5, 0.75, 1.0, 1.25]
+    plain = ShardedPoseRunner(net, max_batch=3, depth=depth, group_size=1).run(imgs, scales, want_maps=True)
+    runner = ShardedPoseRunner(net, max_batch=3, depth=depth)
+    assert runner.group_size == 4
+    res = runner.run(imgs, scales, want_maps=True)
+    assert runner._groups and any(g for g in runner._groups), "the grouped path did not run"
+    multi = [g.stats()["multi_launches"] for slot in runner._groups for g in slot.values()]
+    assert multi and min(multi) >= 100, multi
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert sorted(res["maps"]) == sorted(plain["maps"]) == list(range(len(imgs) * len(scales)))
+    for k in res["maps"]:
+        for name in ("prob", "loc_pred", "next_pred"):
+            a, b = res["maps"][k][name], plain["maps"][k][name]
+            assert a.shape == b.shape and float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max())), (k, name)
+    assert np.allclose(res["item_poses"][:, 2], plain["item_poses"][:, 2], atol=tol)  # confidences of every item
+    assert res["best_scale"] == plain["best_scale"] or dtype == "f16"
+    again = runner.run(imgs, scales)  # second run: plans, graphs and group plans are there
+    assert np.array_equal(again["item_poses"], res["item_poses"])
