@@ -35,9 +35,8 @@ struct ConvClass {
 // (python/pose/estimate_pose.py:81-128 runs them as four forwards; base_conv_layer.cpp:326-341 as one SGEMM per image), the
 // crops of a crowd image, and, inside each of them, the residue classes of a strided deconvolution.  Filters, epilogue
 // constants, klen, sy/sx, Cout are the layer's and stay in ConvGemmParams; everything that depends on a tensor's shape or
-// address is per problem.  The table lives in device memory (ConvGemmParams::multi), read with scalar loads like the
-// argument block itself: filters are pulled through the L2s once per layer instead of once per scale, one dispatch
-// ramp and one tail per layer instead of four.
+// address is per problem.  The table travels in the kernel arguments (ConvMultiArgs): filters are pulled through the L2s once
+// per layer instead of once per scale, one dispatch ramp and one tail per layer instead of four.
 constexpr int kMaxProblems = 16;
 struct ConvProblem {
   const void* x;
@@ -116,10 +115,20 @@ struct ConvGemmParams {
   int ncls;
   int mc_lgx;  // multi-class tile map: the 8 XCDs form a (1 << mc_lgx) x (8 >> mc_lgx) grid over (n tiles) x (m tiles of every class)
   ConvClass cls[kMaxClasses];
-  // --- multi-problem launches: nprob > 0 and multi[0] (device memory) replace every per-tensor field above
+  // --- multi-problem launches: nprob > 0 and the ConvMultiTable that follows the block in the kernel arguments
+  //     (ConvMultiArgs) replace every per-tensor field above
   int nprob;
-  const ConvMultiTable* multi;
+  int pad2_;
 };
+// kernel arguments of a multi-problem launch: the table travels IN the argument block (3.6 KB of the 4 KB a HIP kernel may
+// take), so a workgroup finds its problem with scalar loads from the same segment as everything else — with the table behind
+// a pointer in device memory every workgroup paid one more dependent round trip (argument block -> table row -> problem)
+// before its first useful instruction, ~5 % of a batch-8 float16 forward
+struct ConvMultiArgs {
+  ConvGemmParams p;
+  ConvMultiTable t;
+};
+static_assert(sizeof(ConvMultiArgs) <= 4096, "HIP kernel arguments are limited to 4 KB");
 
 // Tile variants of conv_gemm.  BM x BN output tile per 256-thread workgroup, 4 waves arranged
 // WR x WC x WK (WK = waves splitting the K range of the same output tile, reduced through LDS).
@@ -138,11 +147,11 @@ long conv_grid(const ConvGemmParams& p, int variant);
 int launch_conv_gemm(const ConvGemmParams& p, int variant, void* stream);
 // Multi-problem launch, prepared once (host side): `p` carries the layer's common fields (esize, klen, sy, sx, w, Cout, scale,
 // shift, relu, sigmoid_ch), `table.prob[0..nprob)` the per-tensor ones (pointers included).  Fills the derived fields of both
-// (x_bias, magic numbers, tiles, dense / vector-epilogue flags, the XCD arrangement and table.cum) and returns the grid, or
-// -1 if this variant cannot take the launch.  The caller uploads `table` and sets p.multi to the device copy.
+// (x_bias, magic numbers, tiles, dense / vector-epilogue flags, the XCD arrangement and table.end) and returns the grid, or
+// -1 if this variant cannot take the launch.
 long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& table, int nprob, int variant);
 bool conv_variant_multiproblem(int i);
-int launch_conv_multi(const ConvGemmParams& p, int variant, long grid, void* stream);
+int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stream);
 
 // ---- Winograd F(2x2, 3x3) for the stride-1, dilation-1, pad-1 3x3 convolutions (float32) -------------------------
 // Same ConvGemmParams as the gather-GEMM (x/y/resid/scale/shift/relu, NB, OH, OW, Cout, strides; klen = input channels,

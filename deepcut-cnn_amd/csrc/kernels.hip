@@ -162,7 +162,11 @@ template <typename T, int BM, int BN, int BK, int WR, int WC, int WK, int PF, bo
 // (second launch bound = waves per SIMD the register budget must allow: the 4-wave LDS-DMA tiles are meant to run two
 //  workgroups per CU, so their allocation has to stay within 256 registers — with it the compiler also keeps the
 //  accumulators in VGPRs instead of AGPRs: no v_accvgpr_read pass in front of the epilogue, 169 instead of 200 registers)
-__global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1) void conv_gemm_kernel(const std::conditional_t<MP, ConvMultiArgs, ConvGemmParams> ka) {
+  const ConvGemmParams& p = [&]() -> const ConvGemmParams& {
+    if constexpr (MP) return ka.p;
+    else return ka;
+  }();
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();  // before the first kernel-argument load (DC_DEBUG_TIMING)
   DC_KARG_TOUCH(ka0, ka1, ka2, ka3, ka4);
   constexpr int ES = sizeof(T);          // bytes per element
@@ -252,8 +256,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
     // XCD (qx, qy) owns the n tiles [tn*qx/gx, tn*(qx+1)/gx) and walks, problem after problem, the m tiles
     // [tm_k*qy/gy, tm_k*(qy+1)/gy) of every problem k, n fastest: the layer's filters (shared by all problems) are fetched
     // once per L2 that needs them.  The grid is 8 x the longest XCD list; surplus workgroups exit.
-    typedef const __attribute__((address_space(4))) ConvMultiTable* tab_t;  // constant address space: scalar loads
-    tab_t tb = (tab_t)p.multi;
+    const ConvMultiTable* tb = &ka.t;  // in the argument block: scalar loads
     const int xq = blockIdx.x & 7, lgx = p.mc_lgx, lgy = 3 - lgx;
     const int qx = xq & ((1 << lgx) - 1), qy = xq >> lgx;
     const int n_lo = (p.tiles_n * qx) >> lgx, n_cnt = ((p.tiles_n * (qx + 1)) >> lgx) - n_lo;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(WR* WC* WK * 64, (DMA && WR * WC * WK == 4) ? 2 : 1
       start = (e & ge) | (start & ~ge);
     }
     if (k >= p.nprob) return;
-    const __attribute__((address_space(4))) ConvProblem& q = tb->prob[k];
+    const ConvProblem& q = tb->prob[k];
     c_Ktot = q.Ktot, c_nty = q.nty, c_ntx = q.ntx, c_dy0 = q.dy0, c_ddy = q.ddy, c_x0 = q.x0, c_ddx = q.ddx, c_xbias = q.x_bias;
     c_OH = q.OH, c_OW = q.OW, c_M = q.M;
     c_dohw[0] = q.div_ohw[0], c_dohw[1] = q.div_ohw[1], c_dow[0] = q.div_ow[0], c_dow[1] = q.div_ow[1];
@@ -1119,7 +1122,7 @@ struct VariantEntry {
   int BK;
   int esize;
   void (*kernel_mc)(const ConvGemmParams);  // multi-class instantiation (the deconvolution heads), or null
-  void (*kernel_mp)(const ConvGemmParams);  // multi-problem instantiation (pyramid-grouped launches)
+  void (*kernel_mp)(const ConvMultiArgs);   // multi-problem instantiation (pyramid-grouped launches)
 };
 // the three instantiations of one tile: single problem, multi-class (or null), multi-problem
 #define DC_K3(T, BM, BN, BK, WR, WC, WK, PF, DMA, SWP, ES, WITH_MC)                                            \
@@ -1474,11 +1477,11 @@ long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& tb, int nprob, int va
   return blk;
 }
 
-int launch_conv_multi(const ConvGemmParams& p, int variant, long grid, void* stream) {
-  if (variant < 0 || variant >= kNumVariants || !kVariants[variant].kernel_mp || !p.multi || p.nprob < 1 || grid <= 0) return (int)hipErrorInvalidValue;
+int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stream) {
+  if (variant < 0 || variant >= kNumVariants || !kVariants[variant].kernel_mp || a.p.nprob < 1 || grid <= 0) return (int)hipErrorInvalidValue;
   const VariantEntry& e = kVariants[variant];
   const int nt = e.v.WR * e.v.WC * e.v.WK * 64;
-  hipLaunchKernelGGL(e.kernel_mp, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(e.kernel_mp, dim3((unsigned)grid), dim3(nt), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

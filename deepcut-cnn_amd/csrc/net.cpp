@@ -2866,13 +2866,10 @@ void NetGroup::drop_plan(GroupPlan& gp) {
   (void)hipDeviceSynchronize();
   if (gp.graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)gp.graph_exec);
   gp.graph_exec = nullptr;
-  if (gp.tables_dev) (void)hipFree(gp.tables_dev);
-  gp.tables_dev = nullptr;
 }
 
 NetGroup::~NetGroup() {
   for (auto& gp : plans_) drop_plan(*gp);
-  if (scratch_table_) (void)hipFree(scratch_table_);
 }
 
 // The merged plan of the members' CURRENT shapes (every member has been through begin_batch: its plan is active, its
@@ -2932,7 +2929,6 @@ void NetGroup::merge(GroupPlan& gp) {
   for (Net* n : nets)
     if (n->plan.size() != NL) throw DcError(DC_EINVAL, "group: the members' plans differ in length (different fusion options or graphs?)");
   const bool grouping = env_int("DC_GROUP", 1) != 0;  // 0: every launch member by member (A/B of the merge itself)
-  std::vector<ConvMultiTable> tables;
   for (size_t i = 0; i < NL; ++i) {
     const Launch& l0 = nets[0]->plan[i];
     bool mergeable = grouping && l0.kind == Launch::CONV && NM >= 1;
@@ -3027,13 +3023,9 @@ void NetGroup::merge(GroupPlan& gp) {
       }
       gl.key = "G" + std::to_string(gl.nprob) + (recs.size() > (size_t)kMaxProblems ? "p" + std::to_string(part) : "") + ":" + keys;
       gl.label = l0.label + " x" + std::to_string(NM) + (gl.nprob != (int)NM ? " [" + std::to_string(gl.nprob) + " problems]" : "");
-      gl.table_slot = tables.size();
-      tables.emplace_back();
       gp.launches.push_back(std::move(gl));
     }
   }
-  gp.ntables = tables.size();
-  if (gp.ntables) HIPCHECK(hipMalloc((void**)&gp.tables_dev, gp.ntables * sizeof(ConvMultiTable)));
   // tile of every merged launch: the shared choice table, else (until the group is timed) the widest member's own tile
   {
     std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
@@ -3071,16 +3063,14 @@ void NetGroup::merge(GroupPlan& gp) {
   }
 }
 
-// prepare the launch for a tile and put its table into the plan's device array
-void NetGroup::apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant) {
-  ConvMultiTable t = gl.table;
-  ConvGemmParams p = gl.p;
-  const long grid = prepare_conv_multi(p, t, gl.nprob, variant);
+// prepare the launch (common block + problem table = its kernel arguments) for a tile
+void NetGroup::apply_variant(GroupPlan&, GroupLaunch& gl, int variant) {
+  ConvMultiArgs a;
+  a.p = gl.p;
+  a.t = gl.table;
+  const long grid = prepare_conv_multi(a.p, a.t, gl.nprob, variant);
   if (grid <= 0) throw DcError(DC_EUNSUP, "group launch '" + gl.label + "': tile " + conv_variant(variant).name + " cannot take it");
-  ConvMultiTable* dst = gp.tables_dev + gl.table_slot;
-  HIPCHECK(hipMemcpy(dst, &t, sizeof t, hipMemcpyHostToDevice));
-  p.multi = dst;
-  gl.p = p;
+  gl.args = a;
   gl.variant = variant;
   gl.grid = grid;
 }
@@ -3104,7 +3094,6 @@ void NetGroup::autotune(GroupPlan& gp) {
   } guard{e0, e1};
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
-  if (!scratch_table_) HIPCHECK(hipMalloc((void**)&scratch_table_, sizeof(ConvMultiTable)));
   void* s = stream();
   for (auto& gl : gp.launches) {
     if (!gl.multi || cache.count(gl.key)) continue;
@@ -3112,12 +3101,11 @@ void NetGroup::autotune(GroupPlan& gp) {
     std::vector<std::pair<float, int>> c;
     for (int v = 0; v < conv_num_variants(); ++v) {
       if (!conv_variant_multiproblem(v) || gl.p.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != gl.p.esize) continue;
-      ConvMultiTable t = gl.table;
-      ConvGemmParams p = gl.p;
-      const long grid = prepare_conv_multi(p, t, gl.nprob, v);
+      ConvMultiArgs p;
+      p.p = gl.p;
+      p.t = gl.table;
+      const long grid = prepare_conv_multi(p.p, p.t, gl.nprob, v);
       if (grid <= 0) continue;
-      HIPCHECK(hipMemcpy(scratch_table_, &t, sizeof t, hipMemcpyHostToDevice));
-      p.multi = scratch_table_;
       KCHECK(launch_conv_multi(p, v, grid, s));  // warm
       float ms = 1e30f;
       for (int t2 = 0; t2 < 2; ++t2) {
@@ -3181,7 +3169,7 @@ void NetGroup::autotune(GroupPlan& gp) {
             const GroupLaunch& gl = gp.launches[i];
             const bool watched = j < idx.size() && idx[j] == i;
             if (watched) HIPCHECK(hipEventRecord(ev[2 * j], (hipStream_t)s));
-            if (gl.multi) KCHECK(launch_conv_multi(gl.p, gl.variant, gl.grid, s));
+            if (gl.multi) KCHECK(launch_conv_multi(gl.args, gl.variant, gl.grid, s));
             else nets[gl.member]->run_launch(nets[gl.member]->plan[gl.index], s);
             if (watched) {
               HIPCHECK(hipEventRecord(ev[2 * j + 1], (hipStream_t)s));
@@ -3227,7 +3215,7 @@ void NetGroup::autotune(GroupPlan& gp) {
 void NetGroup::run(GroupPlan& gp, void* s) {
   for (auto& gl : gp.launches) {
     if (gl.multi) {
-      const int rc = launch_conv_multi(gl.p, gl.variant, gl.grid, s);
+      const int rc = launch_conv_multi(gl.args, gl.variant, gl.grid, s);
       if (rc != 0) throw DcError(DC_EDEVICE, "group launch '" + gl.label + "' failed: " + hipGetErrorString((hipError_t)rc));
     } else {
       Net& n = *nets[gl.member];
@@ -3368,7 +3356,7 @@ std::string NetGroup::profile_text(int iters) {
   os << "idx\tkernel\tus\tGFLOP\tTFLOP/s\tgrid\tlabel\n";
   double total_us = 0;
   auto one = [&](const GroupLaunch& gl) {
-    if (gl.multi) KCHECK(launch_conv_multi(gl.p, gl.variant, gl.grid, s));
+    if (gl.multi) KCHECK(launch_conv_multi(gl.args, gl.variant, gl.grid, s));
     else nets[gl.member]->run_launch(nets[gl.member]->plan[gl.index], s);
   };
   for (size_t i = 0; i < gp.launches.size(); ++i) {

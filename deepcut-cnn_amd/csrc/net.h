@@ -332,22 +332,20 @@ struct GroupLaunch {
   bool multi = false;
   int index = 0;              // index into every member's plan
   int member = -1;            // !multi: the member whose launch `index` this is
-  ConvGemmParams p{};         // multi: the prepared common block (p.multi = device table)
-  ConvMultiTable table{};     // host copy (pointers filled, not yet prepared for a variant)
+  ConvGemmParams p{};         // multi: the layer's common block (not yet prepared for a variant)
+  ConvMultiTable table{};     // ... and the problems (pointers filled, not yet prepared)
+  ConvMultiArgs args{};       // both, prepared for `variant`: the kernel arguments
   int nprob = 0;
   int variant = -1;
   long grid = 0;
   std::string key, label;
   double flops = 0;
-  size_t table_slot = 0;      // which ConvMultiTable of the plan's device array
   std::vector<int> prob_member;  // per problem: the member it belongs to (diagnostics)
 };
 struct GroupPlan {
   std::vector<std::vector<int>> shapes;   // per member: its input shape
   std::vector<uint64_t> lowerings, buf_gens, weight_gens;  // per member, when the plan was merged
   std::vector<GroupLaunch> launches;
-  ConvMultiTable* tables_dev = nullptr;   // one device array for all multi launches
-  size_t ntables = 0;
   void* graph_exec = nullptr;
   bool tuned = false;
   uint64_t last_use = 0;
@@ -379,7 +377,6 @@ struct NetGroup {
   std::vector<std::unique_ptr<GroupPlan>> plans_;
   GroupPlan* cur_ = nullptr;
   uint64_t use_clock_ = 0;
-  ConvMultiTable* scratch_table_ = nullptr;  // autotuning
   GroupPlan& ensure_plan();   // after every member's begin_batch: the merged plan of the members' current shapes
   void merge(GroupPlan& gp);
   void autotune(GroupPlan& gp);

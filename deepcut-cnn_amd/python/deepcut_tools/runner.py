@@ -52,20 +52,44 @@ def plan_work(image_shapes, scales, world):
     return items, lpt_shards(costs, world)
 
 
-def rank_batches(image_shapes, items, shard, max_batch):
+def rank_batches(image_shapes, items, shard, max_batch, interleave=False):
     """Batches of one rank, in execution order: [(source (h, w), scale, net input (H, W), [item indices])].  A pure
-    function of the schedule, so every rank knows every other rank's batches (and the size of every payload)."""
+    function of the schedule, so every rank knows every other rank's batches (and the size of every payload).
+    interleave: round-robin over the (source size, scale) classes instead of class after class — the r-th batch of every
+    class, largest net input first, then the (r+1)-th of every class —, so that consecutive batches have DIFFERENT shapes
+    and can run as one grouped launch sequence (`group_units`)."""
     groups = {}
     for k in shard:
         groups.setdefault((tuple(image_shapes[items[k][0]]), items[k][1]), []).append(k)
-    out = []
+    per_class = []
     # largest net input first: its buffers are allocated before the smaller shapes are met, so nothing grows later
     # (a reallocated buffer makes the captured graphs of the other shapes stale)
     for key in sorted(groups, key=lambda g: (-items[groups[g][0]][2][0] * items[groups[g][0]][2][1], g)):
         ks = groups[key]
-        for b0 in range(0, len(ks), max_batch):
-            out.append((key[0], key[1], items[ks[0]][2], ks[b0:b0 + max_batch]))
+        per_class.append([(key[0], key[1], items[ks[0]][2], ks[b0:b0 + max_batch]) for b0 in range(0, len(ks), max_batch)])
+    if not interleave:
+        return [b for c in per_class for b in c]
+    out = []
+    for r in range(max([len(c) for c in per_class]) if per_class else 0):
+        out.extend(c[r] for c in per_class if r < len(c))
     return out
+
+
+def group_units(batches, group_size):
+    """Consecutive batches that run as ONE launch sequence: up to `group_size` batches of pairwise different (batch size, net
+    input) shapes (two batches of one shape gain nothing from sharing a launch — they could have been one bigger batch — and
+    lose the overlap of running on two executors).  -> [[batch indices]]."""
+    units, cur, seen = [], [], set()
+    for bi, b in enumerate(batches):
+        key = (len(b[3]), tuple(b[2]))
+        if cur and (key in seen or len(cur) >= group_size):
+            units.append(cur)
+            cur, seen = [], set()
+        cur.append(bi)
+        seen.add(key)
+    if cur:
+        units.append(cur)
+    return units
 
 
 class ShardedPoseRunner(object):
@@ -205,8 +229,7 @@ class ShardedPoseRunner(object):
 
         rounds = max([len(b) for b in batches_of]) if want_maps and world > 1 else 0
         # a unit = the batches that run as one launch sequence: G consecutive batches grouped, else one batch
-        step = G if grouped else 1
-        units = [list(range(u0, min(u0 + step, len(mine)))) for u0 in range(0, len(mine), step)]
+        units = group_units(mine, G if grouped else 1)
         for ui, unit in enumerate(units):
             e = ui % self.depth
             finish(e)
@@ -239,7 +262,7 @@ class ShardedPoseRunner(object):
                     mbufs.append(torch.empty(msize(mine[bi]), dtype=mdtype, device=dev) if want_maps else None)
                 assert img_t.device == dev and pose_t.device == dev
                 held.append((chunk, pose_t, img_t))
-            if grouped:
+            if grouped and len(unit) > 1:
                 members = self._members[e][:len(unit)]
                 grp = self._groups[e].get(len(unit))
                 if grp is None:
@@ -364,7 +387,7 @@ class ShardedPoseRunner(object):
         mine = shards[rank]
         on_device = self._use_device_pipeline()
         if on_device:
-            batches_of = [rank_batches(shapes, items, shards[r], self.max_batch) for r in range(world)]
+            batches_of = [rank_batches(shapes, items, shards[r], self.max_batch, interleave=self.group_size > 1) for r in range(world)]
             poses, maps = self._run_device(images, items, batches_of, rank, world, want_maps, dist)
         else:
             poses, maps = self._run_host(images, items, mine, want_maps)

@@ -201,3 +201,29 @@ def test_world8_gloo_with_idle_ranks():
     single = ShardedPoseRunner(FakeNet()).run(_images64(3), [1.0], want_maps=True)
     item_poses, have, map_keys, _c = _run_world(8, 3, [1.0])
     assert np.allclose(item_poses, single["item_poses"], atol=1e-12) and map_keys == [0, 1, 2] and have == [True] * 3
+
+
+def test_interleaved_batches_and_group_units():
+    """The grouped device pipeline's schedule is a pure function of the work list (every rank computes every rank's): batches
+    round-robin over the (source size, scale) classes, units = runs of pairwise different shapes of at most group_size."""
+    from deepcut_tools import group_units, plan_work, rank_batches
+
+    shapes = [(336, 256)] * 32  # BASELINE configs[4]: 32 crops x 4 scales on one rank
+    scales = [0.5, 0.75, 1.0, 1.25]
+    items, shards = plan_work(shapes, scales, 1)
+    plain = rank_batches(shapes, items, shards[0], 16)
+    inter = rank_batches(shapes, items, shards[0], 16, interleave=True)
+    assert sorted(tuple(b[3]) for b in plain) == sorted(tuple(b[3]) for b in inter)  # the same batches, another order
+    assert [b[1] for b in plain] == [1.25, 1.25, 1.0, 1.0, 0.75, 0.75, 0.5, 0.5]
+    assert [b[1] for b in inter] == [1.25, 1.0, 0.75, 0.5, 1.25, 1.0, 0.75, 0.5]     # largest first inside every round
+    assert group_units(inter, 4) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert group_units(plain, 4) == [[0], [1, 2], [3, 4], [5, 6], [7]]               # equal shapes never share a unit
+    assert group_units(inter, 1) == [[i] for i in range(8)] and group_units(inter, 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    # one scale only (configs[3]'s share): nothing to group, the plain path runs
+    items1, shards1 = plan_work([(544, 736)] * 8, [1.0], 1)
+    b1 = rank_batches([(544, 736)] * 8, items1, shards1[0], 4, interleave=True)
+    assert group_units(b1, 4) == [[0], [1]]
+    # a ragged last batch differs in batch size: it may join a unit with the full batches of other scales
+    items2, shards2 = plan_work([(544, 736)] * 5, [1.0, 0.5], 1)
+    b2 = rank_batches([(544, 736)] * 5, items2, shards2[0], 4, interleave=True)
+    assert [(len(b[3]), b[1]) for b in b2] == [(4, 1.0), (4, 0.5), (1, 1.0), (1, 0.5)] and group_units(b2, 4) == [[0, 1, 2, 3]]

@@ -21,6 +21,7 @@ import numpy as np  # noqa: E402
 
 
 def main():
+    gs = int(os.environ.get("DC_RUN_GROUP_SIZE", "4"))  # batches of a rank that run as one grouped launch sequence (1: none)
     import caffe
     from deepcut_tools import ShardedPoseRunner, deepercut_prototxt, synth_weights
 
@@ -44,29 +45,29 @@ def main():
         return (time.perf_counter() - t) / reps
 
     scales = [0.5, 0.75, 1.0, 1.25]
-    out = {"device": "1 x MI355X", "data": "synthetic uint8 images (RandomState seeds as in SURVEY 8d), conditioned synthetic weights seed 0",
+    out = {"device": "1 x MI355X", "group_size": gs, "data": "synthetic uint8 images (RandomState seeds as in SURVEY 8d), conditioned synthetic weights seed 0",
            "path": "ShardedPoseRunner: host uint8 -> dc_net_forward_images (pre-processing, forward, pose decode on the device)"}
     imgs8 = [np.random.RandomState(10 + i).randint(0, 256, (544, 736, 3)).astype(np.uint8) for i in range(8)]
     crops = [np.random.RandomState(200 + i).randint(0, 256, (336, 256, 3)).astype(np.uint8) for i in range(32)]
 
     half = make_net("f16")
-    r = ShardedPoseRunner(half, max_batch=8)
+    r = ShardedPoseRunner(half, max_batch=8, group_size=gs)
     dt = timed(lambda: r.run(imgs8, scales), 5)
     out["config3_pyramid_fp16_batch8"] = {"seconds_per_batch_of_8_pyramids": dt, "images_per_s": 8 / dt, "forwards_per_s": 32 / dt,
                                           "tflops": 8 * 823.8e9 / dt / 1e12}
     dt = timed(lambda: r.run(imgs8, [1.0]), 10)
     out["config4_share_8_images_fp16"] = {"seconds": dt, "images_per_s": 8 / dt}
-    r2 = ShardedPoseRunner(half, max_batch=8, depth=2)
+    r2 = ShardedPoseRunner(half, max_batch=8, depth=2, group_size=gs)
     dt = timed(lambda: r2.run(imgs8, scales), 5)
     out["config3_pyramid_fp16_batch8_2_batches_in_flight"] = {"seconds_per_batch_of_8_pyramids": dt, "images_per_s": 8 / dt,
                                                               "forwards_per_s": 32 / dt, "tflops": 8 * 823.8e9 / dt / 1e12}
     del r, r2, half
 
     full = make_net("f32")
-    r = ShardedPoseRunner(full, max_batch=8)
+    r = ShardedPoseRunner(full, max_batch=8, group_size=gs)
     dt = timed(lambda: r.run(imgs8, [1.0]), 10)
     out["config4_share_8_images_fp32"] = {"seconds": dt, "images_per_s": 8 / dt}
-    r = ShardedPoseRunner(full, max_batch=16)
+    r = ShardedPoseRunner(full, max_batch=16, group_size=gs)
     dt = timed(lambda: r.run(crops, scales, want_maps=True), 3)
     out["config5_32_crops_4_scales_fp32_with_maps"] = {"seconds": dt, "crops_per_s": 32 / dt, "forwards_per_s": 128 / dt,
                                                        "tflops": 32 * 177.8e9 / dt / 1e12,
@@ -74,11 +75,11 @@ def main():
     dt = timed(lambda: r.run(crops, scales), 3)
     out["config5_32_crops_4_scales_fp32_poses_only"] = {"seconds": dt, "crops_per_s": 32 / dt, "forwards_per_s": 128 / dt,
                                                         "tflops": 32 * 177.8e9 / dt / 1e12}
-    r3 = ShardedPoseRunner(full, max_batch=16, depth=3)
+    r3 = ShardedPoseRunner(full, max_batch=16, depth=3, group_size=gs)
     dt = timed(lambda: r3.run(crops, scales), 3)
     out["config5_32_crops_4_scales_fp32_poses_only_3_batches_in_flight"] = {"seconds": dt, "crops_per_s": 32 / dt, "forwards_per_s": 128 / dt,
                                                                             "tflops": 32 * 177.8e9 / dt / 1e12}
-    r3 = ShardedPoseRunner(full, max_batch=4, depth=3)
+    r3 = ShardedPoseRunner(full, max_batch=4, depth=3, group_size=gs)
     dt = timed(lambda: r3.run(imgs8, [1.0]), 10)
     out["config4_share_8_images_fp32_3_batches_of_4_in_flight"] = {"seconds": dt, "images_per_s": 8 / dt}
     print(json.dumps(out, indent=1))
