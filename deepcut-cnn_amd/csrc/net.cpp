@@ -1706,12 +1706,25 @@ void Net::autotune() {
   if (cache_path && !shared->tune_file_loaded) {
     shared->tune_file_loaded = true;
     if (FILE* f = std::fopen(cache_path, "r")) {
-      char key[200], vname[64];
-      while (std::fscanf(f, "%199s %63s", key, vname) == 2) {
-        if (std::string(vname) == "wino_f23") tune_cache_[key] = kWinoVariant;
-        for (int v = 0; v < conv_num_variants(); ++v)
-          if (std::string(conv_variant(v).name) == vname) tune_cache_[key] = v;
+      // one "<signature> <tile>" per line; group signatures (NetGroup) concatenate their members' and run to several hundred
+      // characters, so lines are read whole and cut at the LAST blank
+      std::string line;
+      int ch;
+      auto take = [&]() {
+        const size_t sp = line.find_last_of(' ');
+        if (sp != std::string::npos && sp > 0 && sp + 1 < line.size()) {
+          const std::string key = line.substr(0, sp), vname = line.substr(sp + 1);
+          if (vname == "wino_f23") tune_cache_[key] = kWinoVariant;
+          for (int v = 0; v < conv_num_variants(); ++v)
+            if (vname == conv_variant(v).name) tune_cache_[key] = v;
+        }
+        line.clear();
+      };
+      while ((ch = std::fgetc(f)) != EOF) {
+        if (ch == '\n' || ch == '\r') take();
+        else line.push_back((char)ch);
       }
+      take();
       std::fclose(f);
     }
   }

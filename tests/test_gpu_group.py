@@ -248,3 +248,26 @@ def test_sharded_runner_groups_the_scales_of_a_pyramid(gpu_caffe, synth152, dtyp
     assert res["best_scale"] == plain["best_scale"] or dtype == "f16"
     again = runner.run(imgs, scales)  # second run: plans, graphs and group plans are there
     assert np.array_equal(again["item_poses"], res["item_poses"])
+
+
+def test_group_tile_choices_persist_in_the_tune_cache_file(gpu_caffe, synth152, refs, monkeypatch, tmp_path):
+    """DC_TUNE_CACHE: the group signatures (their members' signatures joined: 150 characters for two members, several hundred
+    for the 16-problem heads of a 4-scale pyramid) are written next to the single-problem ones and read back whole — a second
+    model instance times nothing."""
+    path, _ = synth152
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("DC_TUNE_CACHE", str(cache))
+    shapes = SHAPES[1:3]
+    g1 = _group(gpu_caffe, path, shapes)
+    out1 = g1.forward_batch([refs[1][0], refs[2][0]])
+    assert g1.stats()["autotune_runs"] == 1
+    lines = cache.read_text().splitlines()
+    long_keys = [ln for ln in lines if ln.startswith("G")]
+    assert long_keys and max(len(ln) for ln in long_keys) > 120 and all(len(ln.rsplit(" ", 1)) == 2 for ln in lines)
+    g2 = _group(gpu_caffe, path, shapes)  # a new model (own ModelShared): everything comes from the file
+    out2 = g2.forward_batch([refs[1][0], refs[2][0]])
+    assert g2.stats()["autotune_runs"] == 0 and all(m.stats()["autotune_runs"] == 0 for m in g2.nets)
+    assert g2.plan_text() == g1.plan_text()
+    for a, b in zip(out1, out2):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k

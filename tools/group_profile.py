@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-members", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of a hipGraph (counter collection)")
+    ap.add_argument("--pmc-run", type=int, default=0, help="only this many grouped forwards, nothing else (the command rocprofv3 --pmc wraps; "
+                                                           "seed DC_TUNE_CACHE from a plain run so that no timing launches are profiled)")
     ap.add_argument("--pyramids", type=int, default=1, help="pyramid batches coalesced into ONE group (members = 4 x this)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -34,7 +37,7 @@ def main():
     B = args.batch
     shapes = [(272, 368), (408, 552), (544, 736), (680, 920)] * args.pyramids
     layers = synth_weights(152, seed=0)
-    net = caffe.Net(deepercut_prototxt(152, 544, 736, B), caffe.TEST, from_text=True, hipgraph=1, dtype=args.dtype)
+    net = caffe.Net(deepercut_prototxt(152, 544, 736, B), caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1, dtype=args.dtype)
     for name, _t, blobs in layers:
         for p, b in zip(net.params[name], blobs):
             p.data[...] = b
@@ -53,6 +56,11 @@ def main():
         for m, x, s in zip(grp.nets, xs, gshapes):
             m.forward_device(x.data_ptr(), *s)
 
+    if args.pmc_run:
+        for _ in range(args.pmc_run):
+            grouped()
+        torch.cuda.synchronize()
+        return
     for name, fn in (("grouped", grouped), ("scale by scale (same executors)", by_scale)):
         for _ in range(3):
             fn()

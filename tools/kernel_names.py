@@ -37,7 +37,8 @@ def variant_name(name):
             s += "_t"
     else:
         s = "%s%sx%sx%s_w%s%s%s_p%s" % ("h" if ty == "_Float16" else "", bm, bn, bk, wr, wc, wk, pf)
-    return s + (" [multi-class]" if mc == "true" else "")
+    mp = a[11] if len(a) > 11 else "false"
+    return s + (" [multi-class]" if mc == "true" else "") + (" [multi-problem]" if mp == "true" else "")
 
 
 def label(name):
