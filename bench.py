@@ -142,7 +142,9 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
     nets = [net] + [net.clone() for _ in range(execs - 1)]  # executors (shared weights and tile choices): `execs` batch-8 forwards in flight
     for n in nets[1:]:
         n.reserve(8, *shapes[-1])
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in nets[1:]]
+    # every executor on a stream of its own (never the default stream: its handle is 0, which the C entries read as "no stream
+    # given: the net's own, synchronous" — rounds 1-3 measured "in flight" with executor 0 blocking the host after each forward)
+    streams = [torch.cuda.Stream(dev) for _ in nets]
     outs = [{s: [torch.empty(8, c, s[0] // 8, s[1] // 8, device=dev) for c in (14, 28, 364)] for s in shapes} for _ in nets]
     # the grouped form: one group per step in flight, a member per scale (largest first: nothing grows afterwards)
     groups = []
@@ -455,8 +457,11 @@ def main():
     nel = {k: int(np.prod(s)) for k, s in shp.items()}
 
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
-    main = torch.cuda.current_stream(dev)
-    streams = [main] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    # every executor on a stream of its own — never the default stream: its handle is 0, which dc_net_forward_batch reads as
+    # "no stream given: the net's own stream, synchronous" (rounds 1-3 ran executor 0 that way: the host blocked on it after
+    # every one of its forwards while the other executors ran ahead)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    main = streams[0]
     xs = [(torch.randn(B, 3, H, W, generator=g) * 50).to(dev) for _ in range(S)]
     # the maps leave the net in its own element type: float16 payloads from a float16 net (half the gather bytes)
     half = args.dtype == "f16"

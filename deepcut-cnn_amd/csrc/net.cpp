@@ -3012,7 +3012,20 @@ void NetGroup::merge(GroupPlan& gp) {
       }
       keys += (c ? "|" : "") + n.tune_key(l);
     }
-    std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.q.Ktot != b.q.Ktot ? a.q.Ktot > b.q.Ktot : a.q.M > b.q.M; });
+    // order of the problems = order in which every XCD walks them.  Default: tensor after tensor (the residue classes of ONE
+    // member's deconvolution next to each other: they read the same 2048-deep input rows through different taps, which the
+    // memory-side cache then still holds), biggest tensor first, inside a tensor the heaviest class first.
+    // DC_GROUP_ORDER=1: heaviest K first across all members (class-major).
+    if (env_int("DC_GROUP_ORDER", 0) == 1)
+      std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.q.Ktot != b.q.Ktot ? a.q.Ktot > b.q.Ktot : a.q.M > b.q.M; });
+    else {
+      std::vector<long> msum(NM, 0);
+      for (auto& r : recs) msum[r.member] += r.q.M;
+      std::stable_sort(recs.begin(), recs.end(), [&](const Rec& a, const Rec& b) {
+        if (a.member != b.member) return msum[a.member] != msum[b.member] ? msum[a.member] > msum[b.member] : a.member < b.member;
+        return a.q.Ktot > b.q.Ktot;
+      });
+    }
     for (size_t r0 = 0, part = 0; r0 < recs.size(); r0 += kMaxProblems, ++part) {
       GroupLaunch gl;
       gl.multi = true;

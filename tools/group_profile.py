@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of a hipGraph (counter collection)")
     ap.add_argument("--pmc-run", type=int, default=0, help="only this many grouped forwards, nothing else (the command rocprofv3 --pmc wraps; "
                                                            "seed DC_TUNE_CACHE from a plain run so that no timing launches are profiled)")
+    ap.add_argument("--inflight", type=int, default=1, help="also measure this many groups in flight, each on its own stream")
     ap.add_argument("--pyramids", type=int, default=1, help="pyramid batches coalesced into ONE group (members = 4 x this)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -73,6 +74,29 @@ def main():
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) / 10 * 1e3)
         print("%-36s %.3f ms per pyramid batch (min %.3f max %.3f) = %.1f image-pyramids/s" % (name, sorted(ts)[2], min(ts), max(ts), B * args.pyramids / sorted(ts)[2] * 1e3), flush=True)
+    if args.inflight > 1:
+        grps = [grp] + [caffe.NetGroup.for_shapes(net.clone(), gshapes[::-1]) for _ in range(args.inflight - 1)]
+        for g2 in grps[1:]:
+            g2.nets.reverse()
+        grps = [grp] + [caffe.NetGroup(g2.nets) for g2 in grps[1:]]
+        streams = [torch.cuda.Stream(dev) for _ in grps]
+
+        def inflight(k):
+            g2, st = grps[k % len(grps)], streams[k % len(grps)]
+            g2.forward_device([x.data_ptr() for x in xs], gshapes, stream=st.cuda_stream)
+
+        for k in range(2 * len(grps)):
+            inflight(k)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for k in range(10):
+                inflight(k)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 10 * 1e3)
+        print("%-36s %.3f ms per pyramid batch (min %.3f max %.3f) = %.1f image-pyramids/s" % ("%d groups in flight" % len(grps), sorted(ts)[2], min(ts), max(ts),
+                                                                                                   B * args.pyramids / sorted(ts)[2] * 1e3), flush=True)
     grouped()
     torch.cuda.synchronize()
     with open(os.path.join(args.out, "group_per_launch.txt"), "w") as f:
