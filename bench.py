@@ -209,6 +209,23 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
                 "ms_per_pyramid_batch": dt / steps * 1e3, "tflops": tf, "roofline_frac_f16": tf / PEAK_FP16_MFMA_TFLOPS}
 
     g1, relow_g1, inst_g1 = timed(pyramid_grouped, 1)
+    gretiled = None
+    if execs > 1 and tune:
+        # the group's tiles were chosen for ONE grouped forward at a time; with `execs` in flight on their own streams the descent
+        # of deepcut_tools.tune_in_flight runs over the groups (same report / override interface as a net), untimed
+        from deepcut_tools import tune_in_flight
+
+        def gload():
+            t0 = time.perf_counter()
+            for r in range(3 * execs):
+                pyramid_grouped(execs, r)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        try:
+            gretiled = len(tune_in_flight(groups, gload, top=4)["changed"])
+        except Exception as e:  # noqa: BLE001
+            gretiled = "failed: %s" % e
     g2, relow_g2, inst_g2 = timed(pyramid_grouped, execs)
     gc, relow_gc, inst_gc = timed(pyramid_coalesced, execs) if big and steps % execs == 0 else (None, 0, 0)
     dts1, relow1, inst1 = timed(pyramid, 1)
@@ -239,7 +256,8 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
                             "batches in flight, %s" % (groups[0].plan_text().splitlines()[0][2:], execs,
                                                        "coalesced into one group of %d executors" % (4 * execs) if coalesced else "on %d groups / streams" % execs),
                 "regions": regions, "steps": steps, "forwards_in_flight": execs, "forwards_per_s": res["value"] * 4,
-                "gflop_per_image_pyramid": flops / 8 / 1e9, "tile_tuning": "latency (group signatures timed alone, then inside the group's own sequence)",
+                "gflop_per_image_pyramid": flops / 8 / 1e9, "tile_tuning": "latency (group signatures timed alone, then inside the group's own sequence)" + (
+                    "" if gretiled is None else "; in flight: %s signatures re-tiled under %d groups in flight" % (gretiled, execs)),
                 "one_forward_at_a_time": figures(g1), "in_flight_on_streams": f2, "in_flight_coalesced": fc})
     sbs = figures(dts2)
     sbs.update({"note": "rounds 1-3 form: four batch-8 forwards per pyramid batch, the scales rotating over %d executors" % execs,

@@ -585,6 +585,18 @@ const char* dc_group_profile_text(dc_group* group, int iters) {
   int rc = guard([&] { g->text_buf = g->profile_text(iters > 0 ? iters : 10); });
   return rc == DC_OK ? g->text_buf.c_str() : nullptr;
 }
+const char* dc_group_tune_report(dc_group* group) {
+  if (!group) return nullptr;
+  NetGroup* g = G(group);
+  int rc = guard([&] { g->text_buf = g->tune_report_text(); });
+  return rc == DC_OK ? g->text_buf.c_str() : nullptr;
+}
+int dc_group_set_tile(dc_group* group, const char* signature, const char* tile) {
+  REQUIRE(group);
+  REQUIRE(signature);
+  REQUIRE(tile);
+  return guard([&] { G(group)->set_tile(signature, tile); });
+}
 int dc_group_stats(dc_group* group, long long* out, int n) {
   REQUIRE(group);
   REQUIRE(out);

@@ -3364,6 +3364,68 @@ std::string NetGroup::plan_text() {
   return os.str();
 }
 
+std::string NetGroup::tune_report_text() {
+  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
+  std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<int, int>> seen;
+  for (auto& gl : cur_->launches) {
+    if (!gl.multi) continue;
+    auto it = seen.find(gl.key);
+    if (it == seen.end()) order.push_back(gl.key), seen[gl.key] = {gl.variant, 1};
+    else ++it->second.second;
+  }
+  std::string out;
+  for (auto& k : order) {
+    out += k + "\t" + conv_variant(seen[k].first).name + "\t" + std::to_string(seen[k].second) + "\t";
+    auto t = nets[0]->shared->tune_timings.find(k);
+    if (t != nets[0]->shared->tune_timings.end())
+      for (size_t i = 0; i < t->second.size(); ++i) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "%s%s:%.2f", i ? " " : "", conv_variant(t->second[i].second).name, t->second[i].first * 1000.f / 5.f);
+        out += buf;
+      }
+    out += "\n";
+  }
+  return out;
+}
+
+void NetGroup::set_tile(const std::string& key, const std::string& tile) {
+  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
+  int v = -1;
+  for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
+    if (tile == conv_variant(i).name) v = i;
+  if (v < 0) throw DcError(DC_EINVAL, "no tile variant named '" + tile + "'");
+  bool any = false;
+  for (auto& gl : cur_->launches) {
+    if (!gl.multi || gl.key != key) continue;
+    ConvMultiArgs a;
+    a.p = gl.p;
+    a.t = gl.table;
+    if (!conv_variant_multiproblem(v) || prepare_conv_multi(a.p, a.t, gl.nprob, v) <= 0)
+      throw DcError(DC_EUNSUP, "tile '" + tile + "' cannot take group launch '" + gl.label + "'");
+    any = true;
+  }
+  if (!any) throw DcError(DC_EINVAL, "the group's current plan has no launch with signature '" + key + "'");
+  // nothing of this plan may be in flight while its launches change
+  for (Net* n : nets)
+    if (n->stream) (void)hipStreamSynchronize((hipStream_t)n->stream);
+  for (auto& gl : cur_->launches)
+    if (gl.multi && gl.key == key) apply_variant(*cur_, gl, v);
+  {
+    std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
+    auto it = nets[0]->shared->tune_cache.find(key);
+    if (it == nets[0]->shared->tune_cache.end() || it->second != v) {
+      nets[0]->shared->tune_cache[key] = v;
+      write_tune_cache_locked(*nets[0]->shared);
+    }
+  }
+  if (cur_->graph_exec) {
+    (void)hipGraphExecDestroy((hipGraphExec_t)cur_->graph_exec);
+    cur_->graph_exec = nullptr;
+  }
+}
+
 std::string NetGroup::profile_text(int iters) {
   if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
   GroupPlan& gp = *cur_;

@@ -369,6 +369,10 @@ struct NetGroup {
                       float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream);
   std::string plan_text();
   std::string profile_text(int iters);
+  // as Net::tune_report_text / Net::set_tile, for the merged launches of the last forward's plan (signature = "G<problems>:" + the
+  // members' signatures): what deepcut_tools.tune_in_flight walks when the load is groups in flight
+  std::string tune_report_text();
+  void set_tile(const std::string& key, const std::string& tile);
   int num_launches();
   int num_multi_launches();
   double flops();

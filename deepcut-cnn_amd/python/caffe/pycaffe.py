@@ -121,6 +121,8 @@ def _load():
                                          C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]),
         "dc_group_plan_text": (cp, [vp]),
         "dc_group_profile_text": (cp, [vp, ci]),
+        "dc_group_tune_report": (cp, [vp]),
+        "dc_group_set_tile": (ci, [vp, cp, cp]),
         "dc_group_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
         "dc_group_flops": (ci, [vp, C.POINTER(C.c_double)]),
         "dc_conv_variant_count": (ci, []),
@@ -746,6 +748,23 @@ class NetGroup(object):
         if t is None:
             _check(-1)
         return t.decode()
+
+    def tune_report(self):
+        """As Net.tune_report, for the merged launches of the last forward's plan."""
+        t = _lib.dc_group_tune_report(self._h)
+        if t is None:
+            _check(-1)
+        out = []
+        for ln in t.decode().splitlines():
+            f = ln.split("\t")
+            if len(f) < 3:
+                continue
+            timed = [(c.rsplit(":", 1)[0], float(c.rsplit(":", 1)[1])) for c in (f[3].split() if len(f) > 3 else [])]
+            out.append({"signature": f[0], "tile": f[1], "launches": int(f[2]), "timed": timed})
+        return out
+
+    def set_tile(self, signature, tile):
+        _check(_lib.dc_group_set_tile(self._h, signature.encode(), tile.encode()))
 
     def profile_text(self, iters=10):
         t = _lib.dc_group_profile_text(self._h, int(iters))

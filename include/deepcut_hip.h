@@ -312,6 +312,11 @@ int dc_group_forward_images(dc_group* group, const unsigned char* const* images,
 const char* dc_group_plan_text(dc_group* group);
 /* every launch of that plan timed with hipEvents (iters runs each), same table as dc_net_profile_text                        */
 const char* dc_group_profile_text(dc_group* group, int iters);
+/* dc_net_tune_report / dc_net_set_tile for the merged launches of the last forward's plan: signature = "G<problems>:" + the members'
+ * signatures joined by '|' (the key DC_TUNE_CACHE files carry for them); set_tile wants the group idle (it synchronises the members'
+ * own streams; work enqueued on a caller's stream is the caller's to wait for)                                              */
+const char* dc_group_tune_report(dc_group* group);
+int dc_group_set_tile(dc_group* group, const char* signature, const char* tile);
 #define DC_GSTAT_MERGES 0               /* times the members' plans were merged into a group plan                  */
 #define DC_GSTAT_GRAPH_INSTANTIATIONS 1 /* hipGraph captures + instantiations of group plans                       */
 #define DC_GSTAT_AUTOTUNE_RUNS 2        /* group plans for which at least one merged signature had to be timed     */

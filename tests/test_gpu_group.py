@@ -271,3 +271,49 @@ def test_group_tile_choices_persist_in_the_tune_cache_file(gpu_caffe, synth152, 
     for a, b in zip(out1, out2):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_group_tune_report_and_set_tile(gpu_caffe, synth152, refs, monkeypatch):
+    """dc_group_tune_report / dc_group_set_tile (what deepcut_tools.tune_in_flight drives when the load is groups in flight): every
+    merged signature with its isolated timings; an override shows in the plan, leaves the maps where they were (1e-4: another tile
+    may sum in another order) and reaches a second group of the same model through the shared choice table."""
+    from deepcut_tools import tune_in_flight
+
+    monkeypatch.delenv("DC_TUNE_CACHE", raising=False)
+    path, _ = synth152
+    shapes = SHAPES[1:3]
+    grp = _group(gpu_caffe, path, shapes, hipgraph=1)
+    imgs = [refs[1][0], refs[2][0]]
+    base = [{k: v.copy() for k, v in o.items()} for o in grp.forward_batch(imgs)]
+    rep = grp.tune_report()
+    assert len(rep) >= 20 and all(r["signature"].startswith("G") and r["timed"] for r in rep)
+    assert sum(r["launches"] for r in rep) == grp.stats()["multi_launches"]
+    busiest = max(rep, key=lambda r: r["launches"])
+    other = [t for t, _ in busiest["timed"] if t != busiest["tile"]][0]
+    grp.set_tile(busiest["signature"], other)
+    assert [r["tile"] for r in grp.tune_report() if r["signature"] == busiest["signature"]] == [other]
+    assert "conv_gemm_mp<%s>" % other in grp.plan_text()
+    for o, b in zip(grp.forward_batch(imgs), base):
+        for k in o:
+            assert float(np.abs(o[k] - b[k]).max()) <= 1e-4, k
+    with pytest.raises(gpu_caffe.DeepcutError):
+        grp.set_tile(busiest["signature"], "no_such_tile")
+    with pytest.raises(gpu_caffe.DeepcutError):
+        grp.set_tile("G2:1/2/3", other)
+    # the descent itself, over two groups of the model (the second one picks the override up from the shared table)
+    grp2 = gpu_caffe.NetGroup.for_shapes(grp.nets[0].clone(), shapes)
+    grp2.forward_batch(imgs)
+    assert [r["tile"] for r in grp2.tune_report() if r["signature"] == busiest["signature"]] == [other]
+    import time
+
+    def load():
+        t0 = time.perf_counter()
+        for g in (grp, grp2):
+            g.forward_batch(imgs)
+        return time.perf_counter() - t0
+
+    res = tune_in_flight([grp, grp2], load, top=2, reps=1)
+    assert res["runs"] >= 2 and [r["tile"] for r in grp.tune_report()] == [r["tile"] for r in grp2.tune_report()]
+    for o, b in zip(grp2.forward_batch(imgs), base):
+        for k in o:
+            assert float(np.abs(o[k] - b[k]).max()) <= 1e-4, k

@@ -51,13 +51,18 @@ python tools/pmc_mfma_util.py $(db pmc_mfma16) "the same counters over \`bench.p
 python tools/pmc_hbm_traffic.py $(db pmc_fetch16) $(db pmc_write16) "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over \`bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --dtype f16 --batch 8 --streams 1 --no-graph --steps 2 --warmup 1\`, $TAG" 8.4115e9 > $OUT/pmc_hbm_traffic_f16_b8.json 2>> $OUT/post.err
 python tools/pmc_per_shape.py $(db pmc_fetch16) $(db pmc_write16) > $OUT/pmc_hbm_traffic_per_shape_f16_b8.txt 2>> $OUT/post.err
 timeout 600 python tools/run_configs.py > $OUT/configs.json 2> $OUT/configs.err
-# 6. the stand-alone probes: every tile variant on the layer shapes (float16 batch 8 with phase stamps, float32 batch 1),
-#    L2 -> LDS and HBM bandwidth, the RCCL process group with one rank
-timeout 300 tools/probes/bin/conv_probe --stamps > $OUT/conv_probe_f16_b8.txt 2>&1
-timeout 300 tools/probes/bin/conv_probe --dtype f --batch 1 --reps 50 > $OUT/conv_probe_f32_b1.txt 2>&1
-timeout 120 tools/probes/bin/l2_lds_probe > $OUT/l2_lds_probe.txt 2>&1
-timeout 120 tools/probes/bin/bw_probe > $OUT/bw_probe.txt 2>&1
+# 6. the RCCL process group with one rank; the stand-alone probes only with PROBES=1 (the single-problem kernels they time did not
+#    change in round 4: profiles/r03_conv_probe_*.txt, r03_l2_lds_probe.txt, r03_bw_probe.txt stand)
+if [ "${PROBES:-0}" = 1 ]; then
+  timeout 300 tools/probes/bin/conv_probe --stamps > $OUT/conv_probe_f16_b8.txt 2>&1
+  timeout 300 tools/probes/bin/conv_probe --dtype f --batch 1 --reps 50 > $OUT/conv_probe_f32_b1.txt 2>&1
+  timeout 120 tools/probes/bin/l2_lds_probe > $OUT/l2_lds_probe.txt 2>&1
+  timeout 120 tools/probes/bin/bw_probe > $OUT/bw_probe.txt 2>&1
+fi
 timeout 120 python tools/rccl_world1_check.py > $OUT/rccl_world1_check.txt 2>&1
+# 7. the grouped float16 pyramid (round 4): per-launch table, MFMA counters, HBM traffic, kernel stats and gaps
+unset DC_TUNE_CACHE
+bash tools/gpu_group_pmc.sh $TAG > $OUT/group_pmc.log 2>&1
 rm -rf $OUT/stats $OUT/pmc_mfma $OUT/pmc_mfma_b2 $OUT/pmc_mfma_b8 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_mfma16
-ls -la $OUT | head -40
+ls -la $OUT | head -60
 tail -c 400 $OUT/bench.json; tail -5 $OUT/post.err
