@@ -214,6 +214,18 @@ def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=Non
     if net is None:
         net = _get_model(model_def, model_bin)
     poses = []
+    if tiling is None and on_device and len(scales) > 1 and hasattr(net, "clone") and _np.asarray(image).dtype == _np.uint8:
+        # the scale loop of the reference (:81-128) as ONE grouped forward: a member per scale (the net and clones of it, kept
+        # with the net), every layer a single launch over all the scales (caffe.NetGroup / dc_group_forward_images)
+        import caffe as _caffe
+
+        if hasattr(_caffe, "NetGroup"):
+            groups = net.__dict__.setdefault("_scale_groups", {})
+            grp = groups.get(len(scales))
+            if grp is None:
+                grp = groups[len(scales)] = _caffe.NetGroup([net] + [net.clone() for _ in scales[1:]])
+            outs = grp.forward_images(_np.asarray(image), list(scales), want=(), pose=True)
+            return select_best([o["pose"][0] for o in outs])
     for s in scales:
         if tiling is None and on_device and hasattr(net, "forward_images") and _np.asarray(image).dtype == _np.uint8:
             poses.append(net.forward_images(_np.asarray(image), s, want=(), pose=True)["pose"][0])
