@@ -1886,6 +1886,7 @@ void Net::autotune() {
   }
   if (timed_any) ++stats.autotune_runs;
   if (cache_path && (tune_cache_.size() != cached_before || timed_any)) write_tune_cache_locked(*shared);
+  ++tile_gen_;
   release_graph();
 }
 
@@ -1972,6 +1973,7 @@ void Net::set_tile(const std::string& key, const std::string& tile) {
       write_tune_cache_locked(*shared);  // an override changes a value, not the size of the table: persist it too
     }
   }
+  ++tile_gen_;
   release_graph();
 }
 
@@ -2897,14 +2899,14 @@ GroupPlan& NetGroup::ensure_plan() {
     bool stale = false;
     for (size_t c = 0; c < nets.size(); ++c)
       if (hit->lowerings[c] != (uint64_t)nets[c]->stats.lowerings || hit->buf_gens[c] != nets[c]->buf_gen_ ||
-          hit->weight_gens[c] != nets[c]->seen_weights_gen)
+          hit->weight_gens[c] != nets[c]->seen_weights_gen || hit->tile_gens[c] != nets[c]->tile_gen_)
         stale = true;
     if (!stale) {
       hit->last_use = ++use_clock_;
       ++stats.plan_hits;
       return *hit;
     }
-    drop_plan(*hit);  // a member re-lowered (weights, options) or reallocated a buffer: merge again (tile choices are cached)
+    drop_plan(*hit);  // a member re-lowered (weights, options), reallocated a buffer or changed a tile: merge again (choices are cached)
     hit->launches.clear();
     hit->tuned = false;
     merge(*hit);
@@ -2929,8 +2931,9 @@ GroupPlan& NetGroup::ensure_plan() {
 
 void NetGroup::merge(GroupPlan& gp) {
   const size_t NM = nets.size();
-  gp.lowerings.resize(NM), gp.buf_gens.resize(NM), gp.weight_gens.resize(NM);
+  gp.lowerings.resize(NM), gp.buf_gens.resize(NM), gp.weight_gens.resize(NM), gp.tile_gens.resize(NM);
   for (size_t c = 0; c < NM; ++c) {
+    gp.tile_gens[c] = nets[c]->tile_gen_;
     gp.lowerings[c] = (uint64_t)nets[c]->stats.lowerings;
     gp.buf_gens[c] = nets[c]->buf_gen_;
     gp.weight_gens[c] = nets[c]->seen_weights_gen;

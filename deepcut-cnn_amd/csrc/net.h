@@ -234,6 +234,8 @@ struct Net {
   std::vector<std::unique_ptr<PlanState>> parked_;  // plans of the other shapes met so far (LRU, DC_PLAN_CACHE entries)
   uint64_t use_clock_ = 0, cur_last_use_ = 0;
   uint64_t buf_gen_ = 1;                 // bumped whenever a device buffer of this net is reallocated
+  uint64_t tile_gen_ = 1;                // bumped whenever a launch of the active plan changes its tile (autotune, set_tile): a
+                                         // NetGroup that captured this member's launches in ITS graph re-merges
   NetStats stats;
   std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
   void* stream = nullptr;
@@ -344,7 +346,7 @@ struct GroupLaunch {
 };
 struct GroupPlan {
   std::vector<std::vector<int>> shapes;   // per member: its input shape
-  std::vector<uint64_t> lowerings, buf_gens, weight_gens;  // per member, when the plan was merged
+  std::vector<uint64_t> lowerings, buf_gens, weight_gens, tile_gens;  // per member, when the plan was merged
   std::vector<GroupLaunch> launches;
   void* graph_exec = nullptr;
   bool tuned = false;

@@ -317,3 +317,46 @@ def test_group_tune_report_and_set_tile(gpu_caffe, synth152, refs, monkeypatch):
     for o, b in zip(grp2.forward_batch(imgs), base):
         for k in o:
             assert float(np.abs(o[k] - b[k]).max()) <= 1e-4, k
+
+
+def test_group_follows_its_members_weights_and_tiles(gpu_caffe, synth152, refs):
+    """A member is an ordinary net: new weights through one executor (CopyTrainedLayersFrom semantics: every executor of the model
+    re-packs) and a tile override on a member reach the next grouped forward — the group re-merges instead of replaying a graph that
+    captured the old filter images / kernels."""
+    from deepcut_tools import synth_weights, write_caffemodel
+
+    path, _ = synth152
+    shapes = SHAPES[:2]
+    grp = _group(gpu_caffe, path, shapes, hipgraph=1)
+    imgs = [refs[0][0], refs[1][0]]
+    a = [{k: v.copy() for k, v in o.items()} for o in grp.forward_batch(imgs)]
+    for o, (_, ref) in zip(a, refs[:2]):
+        _check32(o, ref)
+    merges = grp.stats()["merges"]
+    # a member's own tile changes: the group's graph holds that member's (non-merged) launches too
+    rep = grp.nets[1].tune_report()
+    sig = max(rep, key=lambda r: r["launches"])
+    other = [t for t, _ in sig["timed"] if t != sig["tile"]]
+    if other:
+        grp.nets[1].set_tile(sig["signature"], other[0])
+        b = grp.forward_batch(imgs)
+        assert grp.stats()["merges"] == merges + 1
+        for o, x in zip(b, a):
+            for k in o:
+                assert float(np.abs(o[k] - x[k]).max()) <= 1e-4, k
+    # new weights (another seed) through member 0: both members' maps change and match the oracle of the new weights
+    import os
+    import tempfile
+
+    layers2 = synth_weights(152, seed=5)
+    with tempfile.TemporaryDirectory() as d:
+        p2 = os.path.join(d, "w2.caffemodel")
+        write_caffemodel(p2, "ResNet-152", layers2)
+        grp.nets[0].copy_from(p2)
+    c = grp.forward_batch(imgs)
+    from deepcut_tools import deepercut_prototxt
+
+    for o, x, (n, h, w), img in zip(c, a, shapes, imgs):
+        assert float(np.abs(o["loc_pred"] - x["loc_pred"]).max()) > 1e-3  # really other weights
+        ref = O.OracleNet(deepercut_prototxt(152, h, w, n), layers2).forward(data=img)
+        _check32(o, ref)
