@@ -545,6 +545,10 @@ int dc_group_destroy(dc_group* group) {
   return DC_OK;
 }
 int dc_group_size(dc_group* group) { return group ? (int)G(group)->nets.size() : 0; }
+int dc_group_set_lanes(dc_group* group, int lanes) {
+  REQUIRE(group);
+  return guard([&] { G(group)->set_lanes(lanes); });
+}
 int dc_group_forward_batch(dc_group* group, const float* const* inputs, const int* n, const int* h, const int* w, int is_device,
                            float* const* prob, float* const* loc_pred, float* const* next_pred, void* stream) {
   REQUIRE(group);
@@ -602,7 +606,7 @@ int dc_group_stats(dc_group* group, long long* out, int n) {
   REQUIRE(out);
   NetGroup* g = G(group);
   const long long v[DC_NUM_GSTATS] = {g->stats.merges, g->stats.graph_instantiations, g->stats.autotune_runs, g->stats.plan_hits,
-                                      (long long)g->num_launches(), (long long)g->num_multi_launches()};
+                                      (long long)g->num_launches(), (long long)g->num_multi_launches(), (long long)g->lanes()};
   for (int i = 0; i < n && i < DC_NUM_GSTATS; ++i) out[i] = v[i];
   return DC_OK;
 }

@@ -2878,13 +2878,30 @@ void NetGroup::drop_plan(GroupPlan& gp) {
   // nothing enqueued may still read the tables or replay the graph
   for (Net* n : nets)
     if (n->stream) (void)hipStreamSynchronize((hipStream_t)n->stream);
+  for (void* st : lane_streams_) (void)hipStreamSynchronize((hipStream_t)st);
   (void)hipDeviceSynchronize();
-  if (gp.graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)gp.graph_exec);
-  gp.graph_exec = nullptr;
+  gp.drop_graphs();
 }
 
 NetGroup::~NetGroup() {
   for (auto& gp : plans_) drop_plan(*gp);
+  for (void* e : lane_events_) (void)hipEventDestroy((hipEvent_t)e);
+  if (fork_event_) (void)hipEventDestroy((hipEvent_t)fork_event_);
+  for (void* st : lane_streams_) (void)hipStreamDestroy((hipStream_t)st);
+}
+
+void GroupPlan::drop_graphs() {
+  for (void*& g : lane_graphs)
+    if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g), g = nullptr;
+}
+
+void NetGroup::set_lanes(int n) {
+  if (n < 0) throw DcError(DC_EINVAL, "lanes must be 0 (automatic) or positive");
+  if (n == lanes_opt_) return;
+  lanes_opt_ = n;
+  for (auto& gp : plans_) drop_plan(*gp);  // every merged plan was cut for the old lane count
+  plans_.clear();
+  cur_ = nullptr;
 }
 
 // The merged plan of the members' CURRENT shapes (every member has been through begin_batch: its plan is active, its
@@ -2945,10 +2962,39 @@ void NetGroup::merge(GroupPlan& gp) {
   for (Net* n : nets)
     if (n->plan.size() != NL) throw DcError(DC_EINVAL, "group: the members' plans differ in length (different fusion options or graphs?)");
   const bool grouping = env_int("DC_GROUP", 1) != 0;  // 0: every launch member by member (A/B of the merge itself)
+  // LANES.  The members are dealt to `nlanes` lanes — snake order over their sizes: largest with smallest — and every lane is
+  // merged on its own and runs on a stream of its own, concurrently with the others: the launches of one lane fill the
+  // dispatch ramps and the tails of the other's (a grouped 4-scale float16 pyramid batch: 12.06 ms as one lane, 10.61 ms as two
+  // lanes of two scales — what two independent groups in flight reach, for ONE request), at the price of fetching a layer's
+  // filters once per lane.  Default: two lanes from four members up; dc_group_set_lanes / DC_GROUP_LANES override.
+  int nl = lanes_opt_ > 0 ? lanes_opt_ : env_int("DC_GROUP_LANES", 0);
+  if (nl <= 0) nl = NM >= 4 ? 2 : 1;
+  nl = std::max(1, std::min<int>(nl, (int)NM));
+  gp.nlanes = nl;
+  gp.lane_members.assign(nl, {});
+  {
+    std::vector<size_t> order(NM);
+    for (size_t c = 0; c < NM; ++c) order[c] = c;
+    auto rows = [&](size_t c) {
+      long r = 1;
+      for (int d : nets[c]->plan_input_shape) r *= d;
+      return r;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return rows(x) > rows(y); });
+    for (size_t j = 0; j < NM; ++j) {
+      const size_t r = j / nl, c = j % nl;
+      gp.lane_members[r % 2 == 0 ? c : nl - 1 - c].push_back((int)order[j]);
+    }
+    for (auto& lm : gp.lane_members) std::sort(lm.begin(), lm.end());
+  }
+  for (int lane = 0; lane < nl; ++lane) {
+  const std::vector<int>& mem = gp.lane_members[lane];
+  const size_t NMl = mem.size();
   for (size_t i = 0; i < NL; ++i) {
-    const Launch& l0 = nets[0]->plan[i];
-    bool mergeable = grouping && l0.kind == Launch::CONV && NM >= 1;
-    for (size_t c = 0; c < NM && mergeable; ++c) {
+    const Launch& l0 = nets[mem[0]]->plan[i];
+    bool mergeable = grouping && l0.kind == Launch::CONV && NMl >= 1;
+    for (size_t cc = 0; cc < NMl && mergeable; ++cc) {
+      const size_t c = (size_t)mem[cc];
       const Launch& l = nets[c]->plan[i];
       const ConvGemmParams &g = l.cg, &g0 = l0.cg;
       if (l.kind != Launch::CONV || l.variant == kWinoVariant || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift || l.c_off != l0.c_off ||
@@ -2965,9 +3011,11 @@ void NetGroup::merge(GroupPlan& gp) {
       mergeable = have;
     }
     if (!mergeable) {
-      for (size_t c = 0; c < NM; ++c) {
+      for (size_t cc = 0; cc < NMl; ++cc) {
+        const size_t c = (size_t)mem[cc];
         if (nets[c]->plan[i].kind != l0.kind) throw DcError(DC_EINVAL, "group: the members' plans differ at launch " + std::to_string(i));
         GroupLaunch gl;
+        gl.lane = lane;
         gl.multi = false;
         gl.index = (int)i;
         gl.member = (int)c;
@@ -2984,7 +3032,8 @@ void NetGroup::merge(GroupPlan& gp) {
     };
     std::vector<Rec> recs;
     std::string keys;
-    for (size_t c = 0; c < NM; ++c) {
+    for (size_t cc = 0; cc < NMl; ++cc) {
+      const size_t c = (size_t)mem[cc];
       Net& n = *nets[c];
       const Launch& l = n.plan[i];
       const ConvGemmParams& g = l.cg;
@@ -3013,7 +3062,7 @@ void NetGroup::merge(GroupPlan& gp) {
         }
         recs.push_back({q, (int)c, std::string()});
       }
-      keys += (c ? "|" : "") + n.tune_key(l);
+      keys += (cc ? "|" : "") + n.tune_key(l);
     }
     // order of the problems = order in which every XCD walks them.  Default: tensor after tensor (the residue classes of ONE
     // member's deconvolution next to each other: they read the same 2048-deep input rows through different taps, which the
@@ -3031,6 +3080,7 @@ void NetGroup::merge(GroupPlan& gp) {
     }
     for (size_t r0 = 0, part = 0; r0 < recs.size(); r0 += kMaxProblems, ++part) {
       GroupLaunch gl;
+      gl.lane = lane;
       gl.multi = true;
       gl.index = (int)i;
       gl.nprob = (int)std::min<size_t>(kMaxProblems, recs.size() - r0);
@@ -3047,14 +3097,15 @@ void NetGroup::merge(GroupPlan& gp) {
       }
       {
         double fl = 0;
-        for (size_t c = 0; c < NM; ++c) fl += nets[c]->plan[i].flops;
+        for (int c : mem) fl += nets[c]->plan[i].flops;
         gl.flops = fl * gl.nprob / (double)recs.size();
       }
       gl.key = "G" + std::to_string(gl.nprob) + (recs.size() > (size_t)kMaxProblems ? "p" + std::to_string(part) : "") + ":" + keys;
-      gl.label = l0.label + " x" + std::to_string(NM) + (gl.nprob != (int)NM ? " [" + std::to_string(gl.nprob) + " problems]" : "");
+      gl.label = l0.label + " x" + std::to_string(NMl) + (gl.nprob != (int)NMl ? " [" + std::to_string(gl.nprob) + " problems]" : "");
       gp.launches.push_back(std::move(gl));
     }
   }
+  }  // lane
   // tile of every merged launch: the shared choice table, else (until the group is timed) the widest member's own tile
   {
     std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
@@ -3080,9 +3131,9 @@ void NetGroup::merge(GroupPlan& gp) {
     };
     if (!usable(v)) {
       v = -1;
-      size_t big = 0;  // the member with the most pixels
-      for (size_t c = 1; c < NM; ++c)
-        if (nets[c]->plan[gl.index].cg.M > nets[big]->plan[gl.index].cg.M) big = c;
+      size_t big = (size_t)gp.lane_members[gl.lane][0];  // the lane's member with the most pixels
+      for (int c : gp.lane_members[gl.lane])
+        if (nets[c]->plan[gl.index].cg.M > nets[big]->plan[gl.index].cg.M) big = (size_t)c;
       if (usable(nets[big]->plan[gl.index].variant)) v = nets[big]->plan[gl.index].variant;
       for (int cand = 0; v < 0 && cand < conv_num_variants(); ++cand)
         if (usable(cand)) v = cand;
@@ -3235,14 +3286,12 @@ void NetGroup::autotune(GroupPlan& gp) {
     ++stats.autotune_runs;
     write_tune_cache_locked(*n0.shared);
   }
-  if (gp.graph_exec) {
-    (void)hipGraphExecDestroy((hipGraphExec_t)gp.graph_exec);
-    gp.graph_exec = nullptr;
-  }
+  gp.drop_graphs();
 }
 
-void NetGroup::run(GroupPlan& gp, void* s) {
+void NetGroup::run(GroupPlan& gp, int lane, void* s) {
   for (auto& gl : gp.launches) {
+    if (lane >= 0 && gl.lane != lane) continue;
     if (gl.multi) {
       const int rc = launch_conv_multi(gl.args, gl.variant, gl.grid, s);
       if (rc != 0) throw DcError(DC_EDEVICE, "group launch '" + gl.label + "' failed: " + hipGetErrorString((hipError_t)rc));
@@ -3262,28 +3311,55 @@ void NetGroup::enqueue(void* s) {
   }
   bool use_graph = true;
   for (Net* n : nets) use_graph = use_graph && n->use_graph;
-  if (use_graph) {
-    if (!gp.graph_exec) {
-      hipGraph_t graph;
-      void* cs = stream();
-      HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
-      try {
-        run(gp, cs);
-      } catch (...) {
-        hipGraph_t g2;
-        (void)hipStreamEndCapture((hipStream_t)cs, &g2);
-        throw;
-      }
-      HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
-      hipGraphExec_t ge;
-      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      gp.graph_exec = ge;
-      ++stats.graph_instantiations;
+  const int nl = gp.nlanes;
+  if (use_graph && (int)gp.lane_graphs.size() != nl) gp.lane_graphs.assign(nl, nullptr);
+  // lanes beyond the first run on streams of the group's own, forked from and joined back into the caller's stream by events
+  while ((int)lane_streams_.size() < nl - 1) {
+    hipStream_t st;
+    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    lane_streams_.push_back(st);
+    hipEvent_t ev;
+    HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    lane_events_.push_back(ev);
+  }
+  if (nl > 1) {
+    if (!fork_event_) {
+      hipEvent_t ev;
+      HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      fork_event_ = ev;
     }
-    HIPCHECK(hipGraphLaunch((hipGraphExec_t)gp.graph_exec, (hipStream_t)s));
-  } else {
-    run(gp, s);
+    HIPCHECK(hipEventRecord((hipEvent_t)fork_event_, (hipStream_t)s));
+  }
+  for (int lane = 0; lane < nl; ++lane) {
+    void* ls = lane == 0 ? s : lane_streams_[lane - 1];
+    if (lane > 0) HIPCHECK(hipStreamWaitEvent((hipStream_t)ls, (hipEvent_t)fork_event_, 0));
+    if (use_graph) {
+      if (!gp.lane_graphs[lane]) {
+        hipGraph_t graph;
+        void* cs = stream();
+        HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
+        try {
+          run(gp, lane, cs);
+        } catch (...) {
+          hipGraph_t g2;
+          (void)hipStreamEndCapture((hipStream_t)cs, &g2);
+          throw;
+        }
+        HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
+        hipGraphExec_t ge;
+        HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        gp.lane_graphs[lane] = ge;
+        ++stats.graph_instantiations;
+      }
+      HIPCHECK(hipGraphLaunch((hipGraphExec_t)gp.lane_graphs[lane], (hipStream_t)ls));
+    } else {
+      run(gp, lane, ls);
+    }
+    if (lane > 0) {
+      HIPCHECK(hipEventRecord((hipEvent_t)lane_events_[lane - 1], (hipStream_t)ls));
+      HIPCHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)lane_events_[lane - 1], 0));
+    }
   }
   for (Net* n : nets) {
     for (auto& l : n->plan) n->storages[l.out]->head = HEAD_AT_GPU;
@@ -3348,7 +3424,7 @@ double NetGroup::flops() { return cur_ ? cur_->flops : 0.0; }
 std::string NetGroup::plan_text() {
   if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
   std::ostringstream os;
-  os << "# group of " << nets.size() << " executors: " << cur_->launches.size() << " launches (" << num_multi_launches() << " multi-problem), "
+  os << "# group of " << nets.size() << " executors in " << cur_->nlanes << " lane" << (cur_->nlanes > 1 ? "s" : "") << ": " << cur_->launches.size() << " launches (" << num_multi_launches() << " multi-problem), "
      << cur_->flops / 1e9 << " GFLOP algorithmic" << (nets[0]->dtype == 1 ? ", dtype=f16" : ", dtype=f32") << "\n";
   for (size_t i = 0; i < cur_->launches.size(); ++i) {
     const GroupLaunch& gl = cur_->launches[i];
@@ -3358,7 +3434,8 @@ std::string NetGroup::plan_text() {
       int kmax = 0;
       for (int k = 0; k < gl.nprob; ++k) M += gl.table.prob[k].M, kmax = std::max(kmax, gl.table.prob[k].Ktot);
       os << "conv_gemm_mp<" << conv_variant(gl.variant).name << ">\tM=" << M << " N=" << gl.p.Cout << " K=" << kmax << " problems=" << gl.nprob
-         << " grid=" << gl.grid << (gl.table.prob[0].resid ? " +resid" : "") << (gl.p.relu ? " +relu" : "") << (gl.p.sigmoid_ch ? " +sigmoid" : "");
+         << " grid=" << gl.grid << (cur_->nlanes > 1 ? " lane=" + std::to_string(gl.lane) : std::string()) << (gl.table.prob[0].resid ? " +resid" : "")
+         << (gl.p.relu ? " +relu" : "") << (gl.p.sigmoid_ch ? " +sigmoid" : "");
     } else {
       os << nets[gl.member]->plan[gl.index].kernel << "\tmember " << gl.member;
     }
@@ -3423,10 +3500,7 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
       write_tune_cache_locked(*nets[0]->shared);
     }
   }
-  if (cur_->graph_exec) {
-    (void)hipGraphExecDestroy((hipGraphExec_t)cur_->graph_exec);
-    cur_->graph_exec = nullptr;
-  }
+  cur_->drop_graphs();
 }
 
 std::string NetGroup::profile_text(int iters) {

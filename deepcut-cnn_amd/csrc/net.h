@@ -332,6 +332,7 @@ struct Net {
 // form, max-pool, stand-alone element-wise layers) run member by member inside the same sequence.
 struct GroupLaunch {
   bool multi = false;
+  int lane = 0;               // which lane of the plan runs it (GroupPlan::lane_members)
   int index = 0;              // index into every member's plan
   int member = -1;            // !multi: the member whose launch `index` this is
   ConvGemmParams p{};         // multi: the layer's common block (not yet prepared for a variant)
@@ -348,10 +349,13 @@ struct GroupPlan {
   std::vector<std::vector<int>> shapes;   // per member: its input shape
   std::vector<uint64_t> lowerings, buf_gens, weight_gens, tile_gens;  // per member, when the plan was merged
   std::vector<GroupLaunch> launches;
-  void* graph_exec = nullptr;
+  int nlanes = 1;
+  std::vector<std::vector<int>> lane_members;  // per lane: member indices (ascending)
+  std::vector<void*> lane_graphs;              // per lane: the captured hipGraphExec, or null
   bool tuned = false;
   uint64_t last_use = 0;
   double flops = 0;
+  void drop_graphs();
 };
 struct GroupStats {
   long long merges = 0, graph_instantiations = 0, autotune_runs = 0, plan_hits = 0;
@@ -369,6 +373,9 @@ struct NetGroup {
   // forward, then per member the maps / the decoded pose
   void forward_images(const unsigned char* const* bgr, const int* n, const int* h, const int* w, const double* scale, bool is_device,
                       float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream);
+  // lanes: 0 = automatic (two from four members up), else that many (at most one per member); every merged plan is dropped
+  void set_lanes(int n);
+  int lanes() const { return cur_ ? cur_->nlanes : lanes_opt_; }
   std::string plan_text();
   std::string profile_text(int iters);
   // as Net::tune_report_text / Net::set_tile, for the merged launches of the last forward's plan (signature = "G<problems>:" + the
@@ -383,11 +390,14 @@ struct NetGroup {
   std::vector<std::unique_ptr<GroupPlan>> plans_;
   GroupPlan* cur_ = nullptr;
   uint64_t use_clock_ = 0;
+  int lanes_opt_ = 0;
+  std::vector<void*> lane_streams_, lane_events_;  // lanes 1.. : own stream + join event
+  void* fork_event_ = nullptr;
   GroupPlan& ensure_plan();   // after every member's begin_batch: the merged plan of the members' current shapes
   void merge(GroupPlan& gp);
   void autotune(GroupPlan& gp);
   void apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant);
-  void run(GroupPlan& gp, void* s);
+  void run(GroupPlan& gp, int lane, void* s);  // lane < 0: every launch
   void enqueue(void* s);
   void drop_plan(GroupPlan& gp);
   void* stream();

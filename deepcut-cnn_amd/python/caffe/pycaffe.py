@@ -115,6 +115,7 @@ def _load():
         "dc_group_create": (ci, [C.POINTER(vp), ci, C.POINTER(vp)]),
         "dc_group_destroy": (ci, [vp]),
         "dc_group_size": (ci, [vp]),
+        "dc_group_set_lanes": (ci, [vp, ci]),
         "dc_group_forward_batch": (ci, [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), ci, C.POINTER(vp), C.POINTER(vp),
                                         C.POINTER(vp), vp]),
         "dc_group_forward_images": (ci, [vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_double), ci,
@@ -632,14 +633,21 @@ class NetGroup(object):
     Members stay usable on their own; after a grouped forward their blobs hold the results (decode_pose, detect_parts,
     emit_maps_device on a member see them)."""
 
-    STAT_NAMES = ("merges", "graph_instantiations", "autotune_runs", "plan_hits", "launches", "multi_launches")
+    STAT_NAMES = ("merges", "graph_instantiations", "autotune_runs", "plan_hits", "launches", "multi_launches", "lanes")
 
-    def __init__(self, nets):
+    def __init__(self, nets, lanes=None):
+        """lanes: None / 0 = automatic (two lanes from four members up: the members are dealt largest-with-smallest to lanes that
+        run concurrently on their own streams), n = that many."""
         self.nets = list(nets)
         arr = (C.c_void_p * len(self.nets))(*[n._h for n in self.nets])
         h = C.c_void_p()
         _check(_lib.dc_group_create(arr, len(self.nets), C.byref(h)))
         self._h = h
+        if lanes:
+            self.set_lanes(lanes)
+
+    def set_lanes(self, lanes):
+        _check(_lib.dc_group_set_lanes(self._h, int(lanes or 0)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -647,12 +655,12 @@ class NetGroup(object):
             _lib.dc_group_destroy(h)  # (the members are kept alive by self.nets until here)
 
     @classmethod
-    def for_shapes(cls, net, shapes):
+    def for_shapes(cls, net, shapes, lanes=None):
         """`net` and len(shapes) - 1 clones, member c reserved at shapes[c] = (n, h, w)."""
         nets = [net] + [net.clone() for _ in shapes[1:]]
         for m, (n, h, w) in zip(nets, shapes):
             m.reserve(n, h, w)
-        return cls(nets)
+        return cls(nets, lanes=lanes)
 
     def __len__(self):
         return len(self.nets)

@@ -29,12 +29,12 @@ def refs(synth152):
     return [_oracle(layers, n, h, w, 40 + i) for i, (n, h, w) in enumerate(SHAPES)]
 
 
-def _group(caffe, path, shapes, **kw):
+def _group(caffe, path, shapes, lanes=None, **kw):
     from deepcut_tools import deepercut_prototxt
 
     n, h, w = shapes[0]
     net = caffe.Net(deepercut_prototxt(152, h, w, n), path, caffe.TEST, from_text=True, **kw)
-    return caffe.NetGroup.for_shapes(net, shapes)
+    return caffe.NetGroup.for_shapes(net, shapes, lanes=lanes)
 
 
 def _check32(out, ref, tol=1e-3):
@@ -49,24 +49,29 @@ def _check16(out, ref):
         assert float(np.abs(out[k] - ref[k]).max()) <= 4e-3 * max(1.0, float(np.abs(ref[k]).max())), k
 
 
-@pytest.mark.parametrize("wino", ["0", None])
-def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synth152, refs, monkeypatch, wino):
-    """All four 'scales' in one plan vs the oracle (1e-3) and vs each member run on its own (same arithmetic: 1e-4)."""
+@pytest.mark.parametrize("wino,lanes", [("0", 1), (None, 1), ("0", None), (None, 4)])
+def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synth152, refs, monkeypatch, wino, lanes):
+    """All four 'scales' in one plan vs the oracle (1e-3) and vs each member run on its own (same arithmetic: 1e-4) — as one
+    lane (every layer ONE launch over the four tensors), as the default two lanes (largest + smallest scale | the middle two,
+    concurrently on two streams) and as four lanes (nothing merged across members: four streams)."""
     path, _ = synth152
     if wino is not None:
         monkeypatch.setenv("DC_WINOGRAD", wino)  # 0: every convolution merges; default: the Winograd layers run member by member
-    grp = _group(gpu_caffe, path, SHAPES, hipgraph=1)
+    grp = _group(gpu_caffe, path, SHAPES, lanes=lanes, hipgraph=1)
     outs = grp.forward_batch([r[0] for r in refs])
     for o, (_, ref) in zip(outs, refs):
         _check32(o, ref)
     st = grp.stats()
     text = grp.plan_text()
+    assert st["lanes"] == (lanes or 2)
     assert st["multi_launches"] >= 100 and "conv_gemm_mp<" in text, text[:400]
     if wino == "0":
-        # 158 launches per forward: 157 convolutions, all merged, + the max-pool member by member
-        assert st["multi_launches"] == 157 and st["launches"] == 157 + len(SHAPES), st
-    # the heads: 4 members x 4 residue classes = 16 problems in one launch
-    assert "problems=16" in text
+        # 158 launches per forward: 157 convolutions, all merged per lane, + the max-pool member by member
+        assert st["multi_launches"] == 157 * st["lanes"] and st["launches"] == 157 * st["lanes"] + len(SHAPES), st
+    # the heads: (members of a lane) x 4 residue classes problems in one launch
+    assert "problems=%d" % (16 // st["lanes"]) in text
+    if st["lanes"] == 2:
+        assert "lane=0" in text and "lane=1" in text
     keep = [{k: v.copy() for k, v in o.items()} for o in outs]
     for m, (img, _), o in zip(grp.nets, refs, keep):
         own = m.forward_batch(img)
@@ -98,7 +103,7 @@ def test_group_fp16_batch8_pyramid(gpu_caffe, synth152):
     text = grp.plan_text()
     assert "conv_gemm_mp<d" in text or "conv_gemm_mp<h" in text, text[:300]
     st = grp.stats()
-    assert st["multi_launches"] == 157, st
+    assert st["lanes"] == 2 and st["multi_launches"] == 2 * 157, st  # two lanes of two scales each
     # the device pose decode of every member reads the grouped results
     for m, sc in zip(grp.nets, (0.5, 0.75, 1.0, 1.25)):
         pose = m.decode_pose(sc)

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of a hipGraph (counter collection)")
     ap.add_argument("--pmc-run", type=int, default=0, help="only this many grouped forwards, nothing else (the command rocprofv3 --pmc wraps; "
                                                            "seed DC_TUNE_CACHE from a plain run so that no timing launches are profiled)")
+    ap.add_argument("--lanes", type=int, default=0, help="also measure ONE pyramid batch as this many sub-groups on their own streams "
+                                                         "(members dealt largest+smallest, ...), one batch at a time and two in flight")
     ap.add_argument("--inflight", type=int, default=1, help="also measure this many groups in flight, each on its own stream")
     ap.add_argument("--pyramids", type=int, default=1, help="pyramid batches coalesced into ONE group (members = 4 x this)")
     args = ap.parse_args()
@@ -74,6 +76,44 @@ def main():
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) / 10 * 1e3)
         print("%-36s %.3f ms per pyramid batch (min %.3f max %.3f) = %.1f image-pyramids/s" % (name, sorted(ts)[2], min(ts), max(ts), B * args.pyramids / sorted(ts)[2] * 1e3), flush=True)
+    if args.lanes > 1:
+        # one pyramid batch = `lanes` sub-groups running concurrently on their own streams: the tails of one fill with the other
+        order = sorted(range(len(gshapes)), key=lambda i: -gshapes[i][1] * gshapes[i][2])
+        lanes = [[] for _ in range(args.lanes)]
+        for j, i in enumerate(order):  # snake: largest + smallest together
+            r, c = divmod(j, args.lanes)
+            lanes[c if r % 2 == 0 else args.lanes - 1 - c].append(i)
+
+        def make(copy):
+            out = []
+            for ln in lanes:
+                nets_l = [grp.nets[i].clone() if copy else grp.nets[i] for i in ln]
+                for m, i in zip(nets_l, ln):
+                    m.reserve(*gshapes[i])
+                out.append((caffe.NetGroup(nets_l), ln))
+            return out
+
+        sets = [make(False), make(True)]
+        lstreams = [[torch.cuda.Stream(dev) for _ in lanes] for _ in sets]
+
+        def lane_step(k):
+            for (g2, ln), st in zip(sets[k % 2], lstreams[k % 2]):
+                g2.forward_device([xs[i].data_ptr() for i in ln], [gshapes[i] for i in ln], stream=st.cuda_stream)
+
+        for mode, sync_each in (("%d lanes, one pyramid batch at a time" % args.lanes, True), ("%d lanes, two pyramid batches in flight" % args.lanes, False)):
+            for k in range(4):
+                lane_step(k)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for k in range(10):
+                    lane_step(k if not sync_each else 0)
+                    if sync_each:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 10 * 1e3)
+            print("%-44s %.3f ms per pyramid batch (min %.3f max %.3f) = %.1f image-pyramids/s" % (mode, sorted(ts)[2], min(ts), max(ts), B * args.pyramids / sorted(ts)[2] * 1e3), flush=True)
     if args.inflight > 1:
         grps = [grp] + [caffe.NetGroup.for_shapes(net.clone(), gshapes[::-1]) for _ in range(args.inflight - 1)]
         for g2 in grps[1:]:
