@@ -124,7 +124,7 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
     680x920), float16 operands with float32 accumulation, device-resident.  A step = one pyramid batch (32 forwards = 8
     images).  Measured two ways in the same run: GROUPED (caffe.NetGroup: the four scales as ONE launch sequence of
-    multi-problem gather-GEMMs, 158 + 3 launches per pyramid batch instead of 632 — `value`) and, as in rounds 1-3, scale by
+    multi-problem gather-GEMMs, in two concurrent lanes of two scales: 318 launches per pyramid batch instead of 632 — `value`) and, as in rounds 1-3, scale by
     scale (four batch-8 forwards per step; reported as `scale_by_scale`).  Each: one step at a time, then `execs` in flight."""
     import torch
     from deepcut_tools import deepercut_prototxt
@@ -156,7 +156,8 @@ def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=Tru
     gshapes = [(8, s[0], s[1]) for s in shapes]
     # ... and the `execs` pyramid batches in flight COALESCED into one group (a net may sit in several groups as long as they do
     # not run at the same time): every layer once over 4 x execs tensors — more rows per launch for the matrix-class layers
-    big = caffe.NetGroup([m for grp in groups for m in grp.nets]) if execs > 1 else None
+    # (one lane: the point of this form is ONE launch per layer over all 4 x execs tensors; the groups above run in two lanes)
+    big = caffe.NetGroup([m for grp in groups for m in grp.nets], lanes=1) if execs > 1 else None
 
     def pyramid(inflight, k0=0):
         for i, s in enumerate(shapes):

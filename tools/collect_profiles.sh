@@ -7,5 +7,6 @@ for f in bench.json bench_f16_batch8.json bench_under_rocprof.json bench_config3
 done
 [ -s $S/per_launch.txt ] && cp $S/per_launch.txt profiles/${PFX}_per_launch_hipevents.txt
 [ -s $S/group_per_launch.txt ] && cp $S/group_per_launch.txt profiles/${PFX}_per_launch_hipevents_group.txt
+[ -s $S/group_per_launch_lanes2.txt ] && cp $S/group_per_launch_lanes2.txt profiles/${PFX}_per_launch_hipevents_group_lanes2.txt
 [ -s $S/tune_cache_group.txt ] && cp $S/tune_cache_group.txt profiles/${PFX}_tune_cache_group.txt
 ls profiles/${PFX}_*
