@@ -64,12 +64,16 @@ def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synt
     st = grp.stats()
     text = grp.plan_text()
     assert st["lanes"] == (lanes or 2)
-    assert st["multi_launches"] >= 100 and "conv_gemm_mp<" in text, text[:400]
-    if wino == "0":
-        # 158 launches per forward: 157 convolutions, all merged per lane, + the max-pool member by member
-        assert st["multi_launches"] == 157 * st["lanes"] and st["launches"] == 157 * st["lanes"] + len(SHAPES), st
-    # the heads: (members of a lane) x 4 residue classes problems in one launch
-    assert "problems=%d" % (16 // st["lanes"]) in text
+    if st["lanes"] == 4:
+        # one member per lane: nothing to merge, every member's own 158 launches, four streams
+        assert st["multi_launches"] == 0 and st["launches"] == 158 * len(SHAPES), st
+    else:
+        assert st["multi_launches"] >= 100 and "conv_gemm_mp<" in text, text[:400]
+        if wino == "0":
+            # 158 launches per forward: 157 convolutions, all merged per lane, + the max-pool member by member
+            assert st["multi_launches"] == 157 * st["lanes"] and st["launches"] == 157 * st["lanes"] + len(SHAPES), st
+        # the heads: (members of a lane) x 4 residue classes problems in one launch
+        assert "problems=%d" % (16 // st["lanes"]) in text
     if st["lanes"] == 2:
         assert "lane=0" in text and "lane=1" in text
     keep = [{k: v.copy() for k, v in o.items()} for o in outs]
