@@ -2875,10 +2875,8 @@ NetGroup* NetGroup::create(const std::vector<Net*>& members) {
 void* NetGroup::stream() { return nets[0]->stream; }
 
 void NetGroup::drop_plan(GroupPlan& gp) {
-  // nothing enqueued may still read the tables or replay the graph
-  for (Net* n : nets)
-    if (n->stream) (void)hipStreamSynchronize((hipStream_t)n->stream);
-  for (void* st : lane_streams_) (void)hipStreamSynchronize((hipStream_t)st);
+  // nothing enqueued may still replay the graphs.  The device-wide wait covers the members' streams, the lanes' and the caller's
+  // without touching a member: a group may be destroyed AFTER its nets (a garbage collector finalises a cycle in any order)
   (void)hipDeviceSynchronize();
   gp.drop_graphs();
 }

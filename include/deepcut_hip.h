@@ -291,8 +291,8 @@ int dc_conv_variant_esize(int i);
  * (a 4-scale pyramid: 158 launches instead of 632).  Members are a net and its clones (dc_net_clone: shared parameters, own
  * activations); they stay usable on their own, and their blobs hold the results of a grouped forward exactly as after their own
  * (dc_net_blob / dc_net_decode_pose / dc_net_emit_maps / dc_net_detect_parts on a member see them).  Results equal the members'
- * own forwards up to the fp32 summation order of the tile chosen (bit-identical for the same tile).  The group borrows the nets:
- * destroy it before them.  Arrays below have one entry per member, in the order given at creation.                          */
+ * own forwards up to the fp32 summation order of the tile chosen (bit-identical for the same tile).  The group borrows the nets: it
+ * must not RUN after one of them is gone (destroying it afterwards is harmless).  Arrays below have one entry per member, in the order given at creation.                          */
 typedef struct dc_group dc_group;
 int dc_group_create(dc_net* const* nets, int n, dc_group** out);
 int dc_group_destroy(dc_group* group);

@@ -37,3 +37,21 @@ def test_group_forward_needs_the_gpu_path():
     assert "CPU mode" in str(e.value) or "no HIP device" in str(e.value)
     with pytest.raises(ValueError):
         g.forward_batch([x])  # one batch per member
+
+
+def test_a_group_may_be_destroyed_after_its_nets():
+    """A garbage collector finalises a reference cycle in any order (the demo mirror keeps its scale groups ON the net): destroying
+    the group after one of its members must not touch the dead net."""
+    import ctypes as C
+
+    from caffe import pycaffe as P
+
+    L = P._lib
+    text = deepercut_prototxt(101, 64, 64).encode()
+    a, b, g = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.dc_net_create_from_text(text, None, caffe.TEST, C.byref(a)) == 0
+    assert L.dc_net_clone(a, C.byref(b)) == 0
+    arr = (C.c_void_p * 2)(a, b)
+    assert L.dc_group_create(arr, 2, C.byref(g)) == 0 and L.dc_group_size(g) == 2
+    assert L.dc_net_destroy(b) == 0 and L.dc_net_destroy(a) == 0
+    assert L.dc_group_destroy(g) == 0
