@@ -7,7 +7,7 @@
 A step = one forward of the hot path (ResNet-152 FCN + deconvolution heads -> prob / loc_pred /
 next_pred) over one batch of synthetic input already resident in HBM, on every rank, followed (N>1)
 by the RCCL gather of the three score maps to rank 0.  Two timed regions of exactly K steps each are
-run: one forward at a time (kernel durations for the roofline), then with `--streams` (default 3)
+run: one forward at a time (kernel durations for the roofline), then with `--streams` (default 4 at batch 1)
 independent batch-B forwards in flight on separate HIP streams — a batch-1 layer of this net fills
 only ~3/4 of the 256 CUs, the next request's kernels fill the rest; `value` is that throughput and the
 one-at-a-time figure is reported beside it.  Workload at N=1 = BASELINE.json configs[1]:
@@ -424,8 +424,8 @@ def main():
         args.batch = 8 if args.config == 3 else 1
     if args.dry_run:
         return dry_run(args)
-    if args.streams <= 0:  # forwards kept in flight: 3 at batch 1, 2 at batch 8
-        args.streams = 3 if args.batch < 4 else 2
+    if args.streams <= 0:  # forwards kept in flight: 4 at batch 1 (one per hardware queue of a HIP process), 2 at batch 8
+        args.streams = 4 if args.batch < 4 else 2
 
     import numpy as np
     import torch
@@ -738,9 +738,10 @@ def main():
             # the service figure, with the latency a request sees under that load; `value` stays strict batch-1 forwards in flight.
             from deepcut_tools import Pipeline
 
-            pipe = Pipeline(net, depth=len(nets), max_batch=args.coalesce)
-            pipe.nets = nets  # reuse the executors (and their tuned plans)
-            window = pipe.max_queue + len(nets) * pipe.max_batch
+            pipe = Pipeline(net, depth=1, max_batch=args.coalesce)
+            pipe.nets = nets[:3]  # reuse the executors (and their tuned plans); three of them: a fourth adds latency, not throughput
+            pipe.max_queue = pipe.max_batch * len(pipe.nets)
+            window = pipe.max_queue + len(pipe.nets) * pipe.max_batch
             nreq = max(args.steps, 10) * 8
             bufs = [(xs[i % S], [torch.empty(B, c, H // 8, W // 8, device=dev) for c in (shp["prob"][1], shp["loc_pred"][1], shp["next_pred"][1])])
                     for i in range(2 * window)]
@@ -768,7 +769,7 @@ def main():
             pct = pipe.latency_percentiles((50, 90, 99))
             return {"value": nreq / dtc, "value_min": nreq / max(dts), "value_max": nreq / min(dts), "unit": "images/s",
                     "policy": "opportunistic (whatever is queued when an executor frees, up to %d requests per batch forward)" % pipe.max_batch,
-                    "executors": len(nets), "requests_outstanding": window, "requests_per_region": nreq, "regions": len(dts),
+                    "executors": len(pipe.nets), "requests_outstanding": window, "requests_per_region": nreq, "regions": len(dts),
                     "latency_ms": {"p50": pct.get(50), "p90": pct.get(90), "p99": pct.get(99)},
                     "batch_sizes": {str(k): v for k, v in sorted(pipe.batch_sizes.items())},
                     "note": "independent batch-1 requests through deepcut_tools.Pipeline (dc_net_forward_requests); latency = submit -> seen finished, closed loop"}
