@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT="/root/repo"
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, ROOT+"/deepcut-cnn_amd", ROOT+"/deepcut-cnn_amd/python"): sys.path.insert(0,p)
 import numpy as np, torch
 import caffe
