@@ -327,7 +327,8 @@ struct Net {
 // starting on L2s that hold neither its filters nor its input, each with its own dispatch ramp and tail.  A NetGroup runs
 // several executors of ONE model (a net and its clones, each at its own input shape) as ONE launch sequence: launch i of
 // the group is launch i of every member's plan merged into a multi-problem gather-GEMM (kernels.h ConvProblem) — the
-// residue classes of the deconvolution heads become problems too —, so a 4-scale pyramid is 158 launches instead of 632.
+// residue classes of the deconvolution heads become problems too —, so a 4-scale pyramid is 161 launches (one lane) or 318 (the default two
+// concurrent lanes of two scales, GroupPlan::lane_members) instead of 632.
 // Members keep their blobs, plans and tile choices: a member can still be run alone.  Launches that cannot merge (Winograd
 // form, max-pool, stand-alone element-wise layers) run member by member inside the same sequence.
 struct GroupLaunch {

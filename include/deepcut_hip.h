@@ -288,7 +288,7 @@ int dc_conv_variant_esize(int i);
  * full Reshape) and, per layer, the reference's one-SGEMM-per-image loop (src/caffe/layers/base_conv_layer.cpp:326-341,
  * conv_layer.cpp:31): launch i of the group is launch i of EVERY member merged into one multi-problem gather-GEMM, so a layer's
  * filters are pulled through the L2s once for all scales and the chip sees one dispatch ramp and one tail per layer
- * (a 4-scale pyramid: 158 launches instead of 632).  Members are a net and its clones (dc_net_clone: shared parameters, own
+ * (a 4-scale pyramid: 161 launches as one lane, 318 as the default two concurrent lanes, instead of 632).  Members are a net and its clones (dc_net_clone: shared parameters, own
  * activations); they stay usable on their own, and their blobs hold the results of a grouped forward exactly as after their own
  * (dc_net_blob / dc_net_decode_pose / dc_net_emit_maps / dc_net_detect_parts on a member see them).  Results equal the members'
  * own forwards up to the fp32 summation order of the tile chosen (bit-identical for the same tile).  The group borrows the nets: it
