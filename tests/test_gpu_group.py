@@ -369,3 +369,30 @@ def test_group_follows_its_members_weights_and_tiles(gpu_caffe, synth152, refs):
         assert float(np.abs(o["loc_pred"] - x["loc_pred"]).max()) > 1e-3  # really other weights
         ref = O.OracleNet(deepercut_prototxt(152, h, w, n), layers2).forward(data=img)
         _check32(o, ref)
+
+
+def test_group_plan_cache_serves_shape_sets_met_before(gpu_caffe, synth152, refs):
+    """Like a net's per-shape plan cache (layer.hpp:451-456: every forward re-derives the shapes): a group keeps the merged plan and
+    the graphs of every tuple of member shapes it has met; alternating two shape sets costs two merges in total, members run alone
+    in between keep working, and the results do not drift."""
+    path, _ = synth152
+    grp = _group(gpu_caffe, path, SHAPES[:2], hipgraph=1)
+    set_a = [refs[0][0], refs[1][0]]           # shapes (2,40,56), (2,64,64)
+    set_b = [refs[1][0], refs[0][0]]           # the same tensors on the other members: another tuple of shapes
+    first_a = [{k: v.copy() for k, v in o.items()} for o in grp.forward_batch(set_a)]
+    first_b = [{k: v.copy() for k, v in o.items()} for o in grp.forward_batch(set_b)]
+    base = grp.stats()
+    assert base["merges"] == 2
+    for rnd in range(3):
+        own = grp.nets[rnd % 2].forward_batch(refs[2][0])  # a member alone, at a third shape, between grouped forwards
+        _check32(own, refs[2][1])
+        for imgs, first in ((set_a, first_a), (set_b, first_b)):
+            outs = grp.forward_batch(imgs)
+            for o, f in zip(outs, first):
+                for k in o:
+                    assert np.array_equal(o[k], f[k]), (rnd, k)
+    st = grp.stats()
+    # the lone forwards lowered a third shape on each member once: that re-merges each cached tuple at most once more
+    assert st["merges"] <= base["merges"] + 4 and st["plan_hits"] >= 2, st
+    for o, (_, ref) in zip(first_b, (refs[1], refs[0])):
+        _check32(o, ref)
