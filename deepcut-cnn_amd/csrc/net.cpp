@@ -2964,9 +2964,12 @@ void NetGroup::merge(GroupPlan& gp) {
   // merged on its own and runs on a stream of its own, concurrently with the others: the launches of one lane fill the
   // dispatch ramps and the tails of the other's (a grouped 4-scale float16 pyramid batch: 12.06 ms as one lane, 10.61 ms as two
   // lanes of two scales — what two independent groups in flight reach, for ONE request), at the price of fetching a layer's
-  // filters once per lane.  Default: two lanes from four members up; dc_group_set_lanes / DC_GROUP_LANES override.
+  // filters once per lane.  Default (measured on float16 batch-8 members, tools/group_profile.py --scales): TWO members run as two
+  // lanes — nothing merged, plain concurrency: 8.26 against 9.27 ms merged (544x736 + 680x920), 5.44 against 6.10 (408x552 + 544x736) —,
+  // THREE as one lane (one merged launch per layer: 11.15 against 12.06 ms for the lop-sided {A, C} | {B}), FOUR or more as two lanes
+  // of merged members.  dc_group_set_lanes / DC_GROUP_LANES override.
   int nl = lanes_opt_ > 0 ? lanes_opt_ : env_int("DC_GROUP_LANES", 0);
-  if (nl <= 0) nl = NM >= 4 ? 2 : 1;
+  if (nl <= 0) nl = NM == 3 ? 1 : 2;
   nl = std::max(1, std::min<int>(nl, (int)NM));
   gp.nlanes = nl;
   gp.lane_members.assign(nl, {});

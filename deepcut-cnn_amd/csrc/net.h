@@ -374,7 +374,7 @@ struct NetGroup {
   // forward, then per member the maps / the decoded pose
   void forward_images(const unsigned char* const* bgr, const int* n, const int* h, const int* w, const double* scale, bool is_device,
                       float* const* prob, float* const* loc, float* const* next, double* const* pose, void* user_stream);
-  // lanes: 0 = automatic (two from four members up), else that many (at most one per member); every merged plan is dropped
+  // lanes: 0 = automatic (2 members: two lanes; 3: one; 4 and more: two), else that many (at most one per member); every merged plan is dropped
   void set_lanes(int n);
   int lanes() const { return cur_ ? cur_->nlanes : lanes_opt_; }
   std::string plan_text();

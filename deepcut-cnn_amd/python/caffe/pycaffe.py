@@ -636,8 +636,9 @@ class NetGroup(object):
     STAT_NAMES = ("merges", "graph_instantiations", "autotune_runs", "plan_hits", "launches", "multi_launches", "lanes")
 
     def __init__(self, nets, lanes=None):
-        """lanes: None / 0 = automatic (two lanes from four members up: the members are dealt largest-with-smallest to lanes that
-        run concurrently on their own streams), n = that many."""
+        """lanes: None / 0 = automatic (the members are dealt largest-with-smallest to lanes that run concurrently on their own
+        streams: two members -> two lanes, i.e. plain concurrency; three -> one lane; four and more -> two lanes of merged members),
+        n = that many."""
         self.nets = list(nets)
         arr = (C.c_void_p * len(self.nets))(*[n._h for n in self.nets])
         h = C.c_void_p()

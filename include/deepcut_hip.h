@@ -300,7 +300,8 @@ int dc_group_size(dc_group* group);
 /* LANES: the members are dealt to `lanes` lanes (largest with smallest), every lane is merged on its own and runs on a stream of
  * its own, concurrently with the others — the launches of one lane fill the dispatch ramps and tails of the other's (one grouped
  * 4-scale float16 pyramid batch: 12.1 ms as one lane, 10.6 ms as two), at the price of one filter fetch per lane and layer.
- * 0 (default) = automatic: two lanes from four members up, else one.  Drops the merged plans.                                */
+ * 0 (default) = automatic: two members run as two lanes (plain concurrency: faster than merging two tensors), three as one lane,
+ * four or more as two lanes of merged members.  Drops the merged plans.                                                      */
 int dc_group_set_lanes(dc_group* group, int lanes);
 /* dc_net_forward_batch for every member at once: member c forwards inputs[c] = n[c] x 3 x h[c] x w[c]; output pointer arrays
  * (or single entries) may be NULL.  stream as dc_net_forward_batch (NULL = the first member's own stream, synchronous).      */

@@ -29,8 +29,12 @@ def refs(synth152):
     return [_oracle(layers, n, h, w, 40 + i) for i, (n, h, w) in enumerate(SHAPES)]
 
 
-def _group(caffe, path, shapes, lanes=None, **kw):
+def _group(caffe, path, shapes, lanes=1, **kw):
+    """lanes=1 by default HERE: most of these tests are about the merged (multi-problem) launches, and the library's automatic
+    choice for two members is two lanes of one member each — nothing merged.  "auto" asks for the library's choice."""
     from deepcut_tools import deepercut_prototxt
+
+    lanes = None if lanes == "auto" else lanes
 
     n, h, w = shapes[0]
     net = caffe.Net(deepercut_prototxt(152, h, w, n), path, caffe.TEST, from_text=True, **kw)
@@ -49,7 +53,7 @@ def _check16(out, ref):
         assert float(np.abs(out[k] - ref[k]).max()) <= 4e-3 * max(1.0, float(np.abs(ref[k]).max())), k
 
 
-@pytest.mark.parametrize("wino,lanes", [("0", 1), (None, 1), ("0", None), (None, 4)])
+@pytest.mark.parametrize("wino,lanes", [("0", 1), (None, 1), ("0", "auto"), (None, 4)])
 def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synth152, refs, monkeypatch, wino, lanes):
     """All four 'scales' in one plan vs the oracle (1e-3) and vs each member run on its own (same arithmetic: 1e-4) — as one
     lane (every layer ONE launch over the four tensors), as the default two lanes (largest + smallest scale | the middle two,
@@ -63,7 +67,7 @@ def test_group_of_four_scales_matches_the_oracle_and_the_members(gpu_caffe, synt
         _check32(o, ref)
     st = grp.stats()
     text = grp.plan_text()
-    assert st["lanes"] == (lanes or 2)
+    assert st["lanes"] == (2 if lanes == "auto" else lanes)
     if st["lanes"] == 4:
         # one member per lane: nothing to merge, every member's own 158 launches, four streams
         assert st["multi_launches"] == 0 and st["launches"] == 158 * len(SHAPES), st
@@ -98,7 +102,7 @@ def test_group_fp16_batch8_pyramid(gpu_caffe, synth152):
     """BASELINE configs[2] in miniature: batch 8 at four scales of a 136x184 image, float16 operands, one grouped plan."""
     path, layers = synth152
     shapes = [(8, 72, 96), (8, 104, 144), (8, 136, 184), (8, 176, 232)]
-    grp = _group(gpu_caffe, path, shapes, dtype="f16", hipgraph=1)
+    grp = _group(gpu_caffe, path, shapes, lanes="auto", dtype="f16", hipgraph=1)
     data = [_oracle(layers, n, h, w, 60 + i) for i, (n, h, w) in enumerate(shapes)]
     outs = grp.forward_batch([d[0] for d in data])
     for o, (_, ref) in zip(outs, data):
@@ -310,7 +314,7 @@ def test_group_tune_report_and_set_tile(gpu_caffe, synth152, refs, monkeypatch):
     with pytest.raises(gpu_caffe.DeepcutError):
         grp.set_tile("G2:1/2/3", other)
     # the descent itself, over two groups of the model (the second one picks the override up from the shared table)
-    grp2 = gpu_caffe.NetGroup.for_shapes(grp.nets[0].clone(), shapes)
+    grp2 = gpu_caffe.NetGroup.for_shapes(grp.nets[0].clone(), shapes, lanes=1)
     grp2.forward_batch(imgs)
     assert [r["tile"] for r in grp2.tune_report() if r["signature"] == busiest["signature"]] == [other]
     import time
@@ -396,3 +400,16 @@ def test_group_plan_cache_serves_shape_sets_met_before(gpu_caffe, synth152, refs
     assert st["merges"] <= base["merges"] + 4 and st["plan_hits"] >= 2, st
     for o, (_, ref) in zip(first_b, (refs[1], refs[0])):
         _check32(o, ref)
+
+
+def test_automatic_lanes(gpu_caffe, synth152, refs):
+    """The library's own choice: two members -> two lanes of one member (plain concurrency, nothing merged: measured faster than
+    merging two tensors), three -> one lane (everything merged), four -> two lanes of two merged members; results as ever."""
+    path, _ = synth152
+    for k, want_lanes, merged in ((2, 2, False), (3, 1, True), (4, 2, True)):
+        grp = _group(gpu_caffe, path, SHAPES[:k], lanes="auto", hipgraph=1)
+        outs = grp.forward_batch([r[0] for r in refs[:k]])
+        st = grp.stats()
+        assert st["lanes"] == want_lanes and (st["multi_launches"] > 100) == merged, (k, st)
+        for o, (_, ref) in zip(outs, refs[:k]):
+            _check32(o, ref)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="plain launches instead of a hipGraph (counter collection)")
     ap.add_argument("--pmc-run", type=int, default=0, help="only this many grouped forwards, nothing else (the command rocprofv3 --pmc wraps; "
                                                            "seed DC_TUNE_CACHE from a plain run so that no timing launches are profiled)")
+    ap.add_argument("--scales", default="0,1,2,3", help="which of the four pyramid scales (indices, smallest first) take part")
     ap.add_argument("--lanes", type=int, default=0, help="also measure ONE pyramid batch as this many sub-groups on their own streams "
                                                          "(members dealt largest+smallest, ...), one batch at a time and two in flight")
     ap.add_argument("--inflight", type=int, default=1, help="also measure this many groups in flight, each on its own stream")
@@ -38,7 +39,7 @@ def main():
     caffe.set_mode_gpu()
     caffe.set_device(0)
     B = args.batch
-    shapes = [(272, 368), (408, 552), (544, 736), (680, 920)] * args.pyramids
+    shapes = [[(272, 368), (408, 552), (544, 736), (680, 920)][int(i)] for i in args.scales.split(",")] * args.pyramids
     layers = synth_weights(152, seed=0)
     net = caffe.Net(deepercut_prototxt(152, 544, 736, B), caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1, dtype=args.dtype)
     for name, _t, blobs in layers:
@@ -90,7 +91,7 @@ def main():
                 nets_l = [grp.nets[i].clone() if copy else grp.nets[i] for i in ln]
                 for m, i in zip(nets_l, ln):
                     m.reserve(*gshapes[i])
-                out.append((caffe.NetGroup(nets_l), ln))
+                out.append((caffe.NetGroup(nets_l, lanes=1), ln))
             return out
 
         sets = [make(False), make(True)]
