@@ -309,22 +309,49 @@ class ShardedPoseRunner(object):
             self._comm_stream.synchronize()
         maps = {}
         if want_maps and rank == 0:
-            def unpack(buf, b):
+            # All maps of a run land in ONE pinned float32 host buffer and are handed out as views of it; the buffer is taken
+            # again by a later run once nobody references those views any more (else a new one is made).  A device-to-host copy
+            # straight into fresh pageable memory faults every page inside the driver's pinning path — the 39-ms host entry of
+            # round 3; here 237 MB per run of configs[4]: 320-520 crops/s depending on the box's page luck.
+            todo = [(payload[bi], b) for bi, b in enumerate(mine)] + [(buf, batches_of[r][k]) for (r, k), buf in recv.items()]
+            total = sum(int(buf.numel()) for buf, _b in todo)
+            stage_t, stage_a = self._result_stage(total)
+            off = 0
+            for buf, b in todo:
                 n, (h, w) = len(b[3]), (b[2][0] // 8, b[2][1] // 8)
-                a = buf.float().cpu().numpy()
-                p = 0
+                m = int(buf.numel())
+                stage_t[off:off + m].copy_(buf)  # (converts float16 payloads on the way)
+                p = off
                 parts = []
                 for c in chans:
-                    parts.append(a[p:p + n * c * h * w].reshape(n, c, h, w))
+                    parts.append(stage_a[p:p + n * c * h * w].reshape(n, c, h, w))
                     p += n * c * h * w
                 for j, k in enumerate(b[3]):
                     maps[k] = {name: parts[q][j] for q, name in enumerate(MAP_NAMES)}
-
-            for bi, b in enumerate(mine):
-                unpack(payload[bi], b)
-            for (r, k), buf in recv.items():
-                unpack(buf, batches_of[r][k])
+                off += m
         return poses, maps
+
+    def _result_stage(self, numel):
+        """(pinned float32 host tensor of `numel` elements, numpy view of it) for the maps of one run: a buffer of an earlier
+        run is taken again when nothing refers to its views any more (a view keeps its base array alive, so the reference count
+        of the base tells), else a new one is allocated; at most four are kept."""
+        import sys
+
+        import torch
+
+        pool = self.__dict__.setdefault("_stage_pool", [])
+        for t, a in pool:
+            if t.numel() >= numel and sys.getrefcount(a) <= 3:  # the pool's tuple, this loop variable, getrefcount's argument
+                return t[:numel], a[:numel]
+        try:
+            t = torch.empty(max(numel, 1), dtype=torch.float32, pin_memory=True)
+        except RuntimeError:
+            t = torch.empty(max(numel, 1), dtype=torch.float32)
+        a = t.numpy()
+        pool.append((t, a))
+        if len(pool) > 4:
+            pool.pop(0)
+        return t[:numel], a[:numel]
 
     # ------------------------------------------------------------------------------------------------------------
     def _run_host(self, images, items, mine, want_maps):
