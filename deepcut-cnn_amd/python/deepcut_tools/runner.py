@@ -249,7 +249,12 @@ class ShardedPoseRunner(object):
                 with torch.cuda.device(dev), torch.cuda.stream(st):
                     # the scales of a pyramid forward the SAME images: their uint8 pixels are stacked and uploaded once
                     if ids not in uploaded:
-                        up = torch.from_numpy(np.stack([images[i] for i in ids])).to(dev, non_blocking=True)
+                        # image by image straight into the device tensor: `np.stack` first would copy the 1.2 MB images once more
+                        # on the host (a millisecond per 8 images of a 12-ms pyramid batch)
+                        first = np.asarray(images[ids[0]])
+                        up = torch.empty((len(ids),) + first.shape, dtype=torch.uint8, device=dev)
+                        for j, i in enumerate(ids):
+                            up[j].copy_(torch.from_numpy(np.ascontiguousarray(images[i])), non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(st)
                         uploaded[ids] = (up, ev)
