@@ -2854,6 +2854,29 @@ std::string Net::debug_info_text() {
 }
 
 // ---- NetGroup: the same model over several tensors as ONE launch sequence (net.h) ---------------------------------------
+// Candidate streams for the lanes of groups (per device, process-wide, never destroyed: a destroyed stream would hand its
+// hardware-queue slot to the next one created).  WHICH of them a group's lanes run on is decided by measurement
+// (NetGroup::choose_lane_streams): a HIP process has a handful of hardware queues, the runtime binds a stream to one of them at
+// creation, and whether two streams really run side by side cannot be asked.
+static std::mutex g_lane_mu;
+static std::map<void*, int> g_lane_users;  // candidate stream -> groups whose lanes run on it (two groups in flight must not share one)
+static std::vector<void*>& lane_stream_candidates(int device, size_t want) {
+  static std::map<int, std::vector<void*>> pool;
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  std::vector<void*>& p = pool[device];
+  while (p.size() < want) {
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+    p.push_back(st);
+  }
+  return p;
+}
+static void lane_streams_release(const std::vector<void*>& side) {
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  for (void* st : side)
+    if (st && g_lane_users[st] > 0) --g_lane_users[st];
+}
+
 NetGroup* NetGroup::create(const std::vector<Net*>& members) {
   if (members.empty()) throw DcError(DC_EINVAL, "a group needs at least one net");
   for (Net* n : members) {
@@ -2885,7 +2908,7 @@ NetGroup::~NetGroup() {
   for (auto& gp : plans_) drop_plan(*gp);
   for (void* e : lane_events_) (void)hipEventDestroy((hipEvent_t)e);
   if (fork_event_) (void)hipEventDestroy((hipEvent_t)fork_event_);
-  for (void* st : lane_streams_) (void)hipStreamDestroy((hipStream_t)st);
+  for (auto& kv : lane_choice_) lane_streams_release(kv.second);  // (the streams themselves belong to the process-wide list)
 }
 
 void GroupPlan::drop_graphs() {
@@ -2897,6 +2920,8 @@ void NetGroup::set_lanes(int n) {
   if (n < 0) throw DcError(DC_EINVAL, "lanes must be 0 (automatic) or positive");
   if (n == lanes_opt_) return;
   lanes_opt_ = n;
+  for (auto& kv : lane_choice_) lane_streams_release(kv.second);
+  lane_choice_.clear();
   for (auto& gp : plans_) drop_plan(*gp);  // every merged plan was cut for the old lane count
   plans_.clear();
   cur_ = nullptr;
@@ -3316,58 +3341,127 @@ void NetGroup::enqueue(void* s) {
   for (Net* n : nets) use_graph = use_graph && n->use_graph;
   const int nl = gp.nlanes;
   if (use_graph && (int)gp.lane_graphs.size() != nl) gp.lane_graphs.assign(nl, nullptr);
-  // lanes beyond the first run on streams of the group's own, forked from and joined back into the caller's stream by events
-  while ((int)lane_streams_.size() < nl - 1) {
-    hipStream_t st;
-    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    lane_streams_.push_back(st);
-    hipEvent_t ev;
-    HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    lane_events_.push_back(ev);
-  }
+  // With more than one lane, lane 0 runs on the caller's stream and every other lane on a stream of the device's candidate list,
+  // forked from and joined back into the caller's stream by events — WHICH candidate is measured (choose_lane_streams).
   if (nl > 1) {
+    while ((int)lane_events_.size() < nl) {
+      hipEvent_t ev;
+      HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      lane_events_.push_back(ev);
+    }
     if (!fork_event_) {
       hipEvent_t ev;
       HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       fork_event_ = ev;
     }
-    HIPCHECK(hipEventRecord((hipEvent_t)fork_event_, (hipStream_t)s));
   }
-  for (int lane = 0; lane < nl; ++lane) {
-    void* ls = lane == 0 ? s : lane_streams_[lane - 1];
-    if (lane > 0) HIPCHECK(hipStreamWaitEvent((hipStream_t)ls, (hipEvent_t)fork_event_, 0));
-    if (use_graph) {
-      if (!gp.lane_graphs[lane]) {
-        hipGraph_t graph;
-        void* cs = stream();
-        HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
-        try {
-          run(gp, lane, cs);
-        } catch (...) {
-          hipGraph_t g2;
-          (void)hipStreamEndCapture((hipStream_t)cs, &g2);
-          throw;
-        }
-        HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
-        hipGraphExec_t ge;
-        HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        gp.lane_graphs[lane] = ge;
-        ++stats.graph_instantiations;
+  // (graphs first: the measurement below replays them)
+  if (use_graph)
+    for (int lane = 0; lane < nl; ++lane) {
+      if (gp.lane_graphs[lane]) continue;
+      hipGraph_t graph;
+      void* cs = stream();
+      HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
+      try {
+        run(gp, lane, cs);
+      } catch (...) {
+        hipGraph_t g2;
+        (void)hipStreamEndCapture((hipStream_t)cs, &g2);
+        throw;
       }
-      HIPCHECK(hipGraphLaunch((hipGraphExec_t)gp.lane_graphs[lane], (hipStream_t)ls));
-    } else {
-      run(gp, lane, ls);
+      HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
+      hipGraphExec_t ge;
+      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      gp.lane_graphs[lane] = ge;
+      ++stats.graph_instantiations;
     }
-    if (lane > 0) {
-      HIPCHECK(hipEventRecord((hipEvent_t)lane_events_[lane - 1], (hipStream_t)ls));
-      HIPCHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)lane_events_[lane - 1], 0));
+  if (nl > 1) {
+    auto it = lane_choice_.find(s);
+    if (it == lane_choice_.end() || (int)it->second.size() != nl) {
+      if (lane_choice_.size() >= 8) {  // a caller that keeps changing streams: start over rather than grow
+        for (auto& kv : lane_choice_) lane_streams_release(kv.second);
+        lane_choice_.clear();
+      }
+      choose_lane_streams(gp, s, use_graph);
+      it = lane_choice_.find(s);
     }
+    launch_lanes(gp, s, it->second, use_graph);
+  } else {
+    launch_lanes(gp, s, lane_streams_, use_graph);
   }
   for (Net* n : nets) {
     for (auto& l : n->plan) n->storages[l.out]->head = HEAD_AT_GPU;
     for (int v : n->plan_views_) n->storages[v]->head = HEAD_AT_GPU;
   }
+}
+
+// one grouped forward: lane 0 on s, lane k on side[k] (side[0] unused), fork / join by events
+void NetGroup::launch_lanes(GroupPlan& gp, void* s, const std::vector<void*>& side, bool use_graph) {
+  const int nl = gp.nlanes;
+  if (nl > 1) HIPCHECK(hipEventRecord((hipEvent_t)fork_event_, (hipStream_t)s));
+  for (int lane = 0; lane < nl; ++lane) {
+    void* ls = lane == 0 ? s : side[lane];
+    if (lane > 0) HIPCHECK(hipStreamWaitEvent((hipStream_t)ls, (hipEvent_t)fork_event_, 0));
+    if (use_graph) HIPCHECK(hipGraphLaunch((hipGraphExec_t)gp.lane_graphs[lane], (hipStream_t)ls));
+    else run(gp, lane, ls);
+    if (lane > 0) {
+      HIPCHECK(hipEventRecord((hipEvent_t)lane_events_[lane], (hipStream_t)ls));
+      HIPCHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)lane_events_[lane], 0));
+    }
+  }
+}
+
+// Which streams do the lanes beyond the first run on?  Measured, per caller stream: the forward itself is timed (warm run + one
+// timed run, events on s) with the side lanes on successive candidates, and the assignment with the shortest forward stays.  A
+// side stream that shares a hardware queue with the caller's stream — or with another side lane's — runs its lane AFTER the other
+// one (a grouped float16 pyramid batch: 12.0 instead of 10.7 ms); which candidate does depends on everything the process created
+// before, so nothing but a measurement on the real launch sequence tells.  Costs a dozen forwards, once per (group, caller stream).
+void NetGroup::choose_lane_streams(GroupPlan& gp, void* s, bool use_graph) {
+  const int nl = gp.nlanes;
+  const size_t ncand = 6;
+  std::vector<void*>& cand = lane_stream_candidates(nets[0]->device, ncand + (size_t)nl);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct EvGuard {
+    hipEvent_t &a, &b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } guard{e0, e1};
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+  float best = 1e30f, best_free = 1e30f;
+  std::vector<void*> best_set, best_free_set;
+  for (size_t first = 0; first + (size_t)(nl - 1) <= cand.size(); ++first) {
+    std::vector<void*> side(nl, nullptr);
+    for (int k = 1; k < nl; ++k) side[k] = cand[first + (size_t)k - 1];
+    launch_lanes(gp, s, side, use_graph);  // warm
+    HIPCHECK(hipEventRecord(e0, (hipStream_t)s));
+    launch_lanes(gp, s, side, use_graph);
+    HIPCHECK(hipEventRecord(e1, (hipStream_t)s));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms, best_set = side;
+    bool free_ = true;
+    {
+      std::lock_guard<std::mutex> lk(g_lane_mu);
+      for (int k = 1; k < nl; ++k) free_ = free_ && g_lane_users[side[k]] == 0;
+    }
+    if (free_ && ms < best_free) best_free = ms, best_free_set = side;
+  }
+  // a stream no other group's lanes run on, if one is (nearly) as good: two groups in flight whose side lanes share ONE stream
+  // run those lanes one after the other (measured alone, both would pick the same winner)
+  if (!best_free_set.empty() && best_free <= best * 1.04f) best_set = best_free_set;
+  {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    for (int k = 1; k < nl; ++k) ++g_lane_users[best_set[k]];
+  }
+  auto old = lane_choice_.find(s);
+  if (old != lane_choice_.end()) lane_streams_release(old->second);
+  lane_choice_[s] = best_set;
 }
 
 void NetGroup::forward_batch(const float* const* inputs, const int* n, const int* h, const int* w, bool is_device, float* const* prob,

@@ -392,7 +392,8 @@ struct NetGroup {
   GroupPlan* cur_ = nullptr;
   uint64_t use_clock_ = 0;
   int lanes_opt_ = 0;
-  std::vector<void*> lane_streams_, lane_events_;  // lanes 1.. : own stream + join event
+  std::vector<void*> lane_streams_, lane_events_;  // (lane_streams_: empty, the one-lane case) per lane: join event
+  std::map<void*, std::vector<void*>> lane_choice_;  // caller's stream -> per lane the side stream measured best (index 0 unused; borrowed)
   void* fork_event_ = nullptr;
   GroupPlan& ensure_plan();   // after every member's begin_batch: the merged plan of the members' current shapes
   void merge(GroupPlan& gp);
@@ -400,6 +401,8 @@ struct NetGroup {
   void apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant);
   void run(GroupPlan& gp, int lane, void* s);  // lane < 0: every launch
   void enqueue(void* s);
+  void launch_lanes(GroupPlan& gp, void* s, const std::vector<void*>& side, bool use_graph);
+  void choose_lane_streams(GroupPlan& gp, void* s, bool use_graph);
   void drop_plan(GroupPlan& gp);
   void* stream();
 };
