@@ -230,10 +230,6 @@ struct ImagePrepParams {
 };
 int launch_image_prep(const ImagePrepParams& p, void* stream);
 
-// One 64-lane wave that does nothing for `ticks` ticks of the chip-wide 100 MHz clock: what NetGroup uses to find out which
-// streams really run side by side (streams that share one of the runtime's hardware queues do not).
-int launch_spin(long ticks, void* stream);
-
 int launch_pose_decode(const void* prob, int pcp, int pc0, const void* loc, int lcp, int lc0, int esize, int NB, int H,
                        int W, int J, double scale, double* out, void* stream);
 

@@ -1380,15 +1380,6 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   return (int)hipGetLastError();
 }
 
-__global__ void spin_kernel(long ticks) {
-  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-int launch_spin(long ticks, void* stream) {
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
-  return (int)hipGetLastError();
-}
-
 bool conv_variant_multiproblem(int i) { return kVariants[i].kernel_mp != nullptr; }
 
 // Multi-problem launch: host-side preparation (once per plan), see kernels.h.

@@ -2936,12 +2936,7 @@ GroupPlan& NetGroup::ensure_plan() {
   for (auto& gp : plans_)
     if (gp->shapes == shapes) hit = gp.get();
   if (hit) {
-    bool stale = false;
-    for (size_t c = 0; c < nets.size(); ++c)
-      if (hit->lowerings[c] != (uint64_t)nets[c]->stats.lowerings || hit->buf_gens[c] != nets[c]->buf_gen_ ||
-          hit->weight_gens[c] != nets[c]->seen_weights_gen || hit->tile_gens[c] != nets[c]->tile_gen_)
-        stale = true;
-    if (!stale) {
+    if (plan_current(*hit)) {
       hit->last_use = ++use_clock_;
       ++stats.plan_hits;
       return *hit;
@@ -2949,7 +2944,12 @@ GroupPlan& NetGroup::ensure_plan() {
     drop_plan(*hit);  // a member re-lowered (weights, options), reallocated a buffer or changed a tile: merge again (choices are cached)
     hit->launches.clear();
     hit->tuned = false;
-    merge(*hit);
+    try {
+      merge(*hit);
+    } catch (...) {  // a half-merged plan must not be found again
+      forget_plan(hit);
+      throw;
+    }
     hit->last_use = ++use_clock_;
     return *hit;
   }
@@ -2959,14 +2959,45 @@ GroupPlan& NetGroup::ensure_plan() {
     for (size_t i = 1; i < plans_.size(); ++i)
       if (plans_[i]->last_use < plans_[lru]->last_use) lru = i;
     drop_plan(*plans_[lru]);
-    plans_.erase(plans_.begin() + lru);
+    forget_plan(plans_[lru].get());
   }
   plans_.emplace_back(new GroupPlan());
   GroupPlan& gp = *plans_.back();
   gp.shapes = shapes;
-  merge(gp);
+  try {
+    merge(gp);
+  } catch (...) {
+    forget_plan(&gp);
+    throw;
+  }
   gp.last_use = ++use_clock_;
   return gp;
+}
+
+// does the merged plan still describe its members (their lowering, buffers, filter images, tiles)?
+bool NetGroup::plan_current(const GroupPlan& gp) const {
+  for (size_t c = 0; c < nets.size(); ++c)
+    if (gp.shapes[c] != nets[c]->plan_input_shape || gp.lowerings[c] != (uint64_t)nets[c]->stats.lowerings || gp.buf_gens[c] != nets[c]->buf_gen_ ||
+        gp.weight_gens[c] != nets[c]->seen_weights_gen || gp.tile_gens[c] != nets[c]->tile_gen_)
+      return false;
+  return true;
+}
+
+// the plan of the last forward, for the calls that launch from it outside a forward: a member that has been reshaped, re-lowered or
+// re-tiled on its own since then has moved the buffers the prepared launches point at
+GroupPlan& NetGroup::current_plan() {
+  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
+  if (!plan_current(*cur_)) throw DcError(DC_EINVAL, "group: a member changed (shape, weights, tiles) since the group's last forward: run a forward first");
+  return *cur_;
+}
+
+void NetGroup::forget_plan(GroupPlan* gp) {
+  if (cur_ == gp) cur_ = nullptr;
+  for (size_t i = 0; i < plans_.size(); ++i)
+    if (plans_[i].get() == gp) {
+      plans_.erase(plans_.begin() + (long)i);
+      return;
+    }
 }
 
 void NetGroup::merge(GroupPlan& gp) {
@@ -3388,7 +3419,7 @@ void NetGroup::enqueue(void* s) {
     }
     launch_lanes(gp, s, it->second, use_graph);
   } else {
-    launch_lanes(gp, s, lane_streams_, use_graph);
+    launch_lanes(gp, s, {}, use_graph);
   }
   for (Net* n : nets) {
     for (auto& l : n->plan) n->storages[l.out]->head = HEAD_AT_GPU;
@@ -3455,6 +3486,7 @@ void NetGroup::choose_lane_streams(GroupPlan& gp, void* s, bool use_graph) {
   // a stream no other group's lanes run on, if one is (nearly) as good: two groups in flight whose side lanes share ONE stream
   // run those lanes one after the other (measured alone, both would pick the same winner)
   if (!best_free_set.empty() && best_free <= best * 1.04f) best_set = best_free_set;
+  if (best_set.empty()) throw DcError(DC_EDEVICE, "group: no stream could be created for the lanes beyond the first (dc_group_set_lanes(g, 1) runs one lane)");
   {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     for (int k = 1; k < nl; ++k) ++g_lane_users[best_set[k]];
@@ -3568,7 +3600,7 @@ std::string NetGroup::tune_report_text() {
 }
 
 void NetGroup::set_tile(const std::string& key, const std::string& tile) {
-  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
+  current_plan();
   int v = -1;
   for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
     if (tile == conv_variant(i).name) v = i;
@@ -3584,9 +3616,9 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
     any = true;
   }
   if (!any) throw DcError(DC_EINVAL, "the group's current plan has no launch with signature '" + key + "'");
-  // nothing of this plan may be in flight while its launches change
-  for (Net* n : nets)
-    if (n->stream) (void)hipStreamSynchronize((hipStream_t)n->stream);
+  // nothing of this plan may be in flight while its launches change (the forward may have run on a caller's stream and on lane
+  // streams: the device-wide wait covers them all)
+  (void)hipDeviceSynchronize();
   for (auto& gl : cur_->launches)
     if (gl.multi && gl.key == key) apply_variant(*cur_, gl, v);
   {
@@ -3601,8 +3633,7 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
 }
 
 std::string NetGroup::profile_text(int iters) {
-  if (!cur_) throw DcError(DC_EINVAL, "group: run a forward first");
-  GroupPlan& gp = *cur_;
+  GroupPlan& gp = current_plan();
   void* s = stream();
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct EvGuard {

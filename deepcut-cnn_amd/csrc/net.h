@@ -392,11 +392,14 @@ struct NetGroup {
   GroupPlan* cur_ = nullptr;
   uint64_t use_clock_ = 0;
   int lanes_opt_ = 0;
-  std::vector<void*> lane_streams_, lane_events_;  // (lane_streams_: empty, the one-lane case) per lane: join event
+  std::vector<void*> lane_events_;  // per lane: its join event
   std::map<void*, std::vector<void*>> lane_choice_;  // caller's stream -> per lane the side stream measured best (index 0 unused; borrowed)
   void* fork_event_ = nullptr;
   GroupPlan& ensure_plan();   // after every member's begin_batch: the merged plan of the members' current shapes
   void merge(GroupPlan& gp);
+  bool plan_current(const GroupPlan& gp) const;
+  GroupPlan& current_plan();
+  void forget_plan(GroupPlan* gp);  // out of the cache (a merge that threw, an eviction); cur_ never dangles
   void autotune(GroupPlan& gp);
   void apply_variant(GroupPlan& gp, GroupLaunch& gl, int variant);
   void run(GroupPlan& gp, int lane, void* s);  // lane < 0: every launch

@@ -413,3 +413,26 @@ def test_automatic_lanes(gpu_caffe, synth152, refs):
         assert st["lanes"] == want_lanes and (st["multi_launches"] > 100) == merged, (k, st)
         for o, (_, ref) in zip(outs, refs[:k]):
             _check32(o, ref)
+
+
+def test_group_profile_refuses_a_plan_its_members_have_left(gpu_caffe, synth152, refs):
+    """profile_text() / set_tile() launch from the plan of the group's LAST forward.  A member that has since been run alone at
+    another shape has moved on (other plan, possibly other buffers): the group says so instead of launching into the old ones,
+    and the next grouped forward puts it right."""
+    path, _ = synth152
+    grp = _group(gpu_caffe, path, SHAPES[:2], hipgraph=1)
+    with pytest.raises(gpu_caffe.DeepcutError, match="forward first"):
+        grp.profile_text(1)
+    outs = grp.forward_batch([refs[0][0], refs[1][0]])
+    assert "conv_gemm_mp<" in grp.profile_text(1)
+    rep = grp.tune_report()[0]
+    key, tile = rep["signature"], rep["tile"]
+    grp.nets[0].forward_batch(refs[3][0])  # member 0 alone at the largest shape: its buffers grow
+    with pytest.raises(gpu_caffe.DeepcutError, match="member changed"):
+        grp.profile_text(1)
+    with pytest.raises(gpu_caffe.DeepcutError, match="member changed"):
+        grp.set_tile(key, tile)
+    again = grp.forward_batch([refs[0][0], refs[1][0]])
+    for o, a, (_, ref) in zip(outs, again, refs[:2]):
+        _check32(a, ref)
+    assert "conv_gemm_mp<" in grp.profile_text(1)
