@@ -44,14 +44,89 @@ int device_count() {
   return n;
 }
 
+// ---- stream capture against everything else ------------------------------------------------------
+// While ANY stream of the process is being captured, this HIP runtime fails the synchronous legacy-stream calls of EVERY thread
+// (hipMemset, hipMemcpy: hipErrorStreamCaptureImplicit, "would make the legacy stream depend on a capturing blocking stream" —
+// whatever the capturing stream's flags and the capture mode) and invalidates the capture on top; allocation and release
+// synchronise the device, which a capturing stream cannot take either.  Seen with three groups driven by three host threads
+// (tools/stress_groups.py): one thread's buffer growth killed another's graph capture.  So (1) the library makes no
+// legacy-stream call: fills and uploads go asynchronously to a utility stream of its own and are waited for there; and (2)
+// its captures and its allocations / releases / device-wide waits exclude each other through one process-wide lock (captures
+// take a millisecond and happen once per shape; allocations likewise).  Lock order: ModelShared::mu before this one.
+static std::recursive_mutex& runtime_mu() {
+  static std::recursive_mutex* m = new std::recursive_mutex();  // never destroyed: blobs may be released at exit
+  return *m;
+}
+struct RuntimeLock {
+  std::lock_guard<std::recursive_mutex> lk;
+  RuntimeLock() : lk(runtime_mu()) {}
+};
+// utility stream of the current device (non-blocking, never destroyed); caller holds the runtime lock
+static hipStream_t util_stream() {
+  static std::map<int, hipStream_t> streams;
+  int d = 0;
+  HIPCHECK(hipGetDevice(&d));
+  auto it = streams.find(d);
+  if (it != streams.end()) return it->second;
+  hipStream_t st;
+  HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  streams[d] = st;
+  return st;
+}
+// zero-fill / upload, complete on return, no legacy stream involved
+static void dev_zero(void* p, size_t bytes) {
+  RuntimeLock rl;
+  hipStream_t us = util_stream();
+  HIPCHECK(hipMemsetAsync(p, 0, bytes, us));
+  HIPCHECK(hipStreamSynchronize(us));
+}
+static void dev_upload(void* dst, const void* src, size_t bytes) {
+  RuntimeLock rl;
+  hipStream_t us = util_stream();
+  HIPCHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, us));
+  HIPCHECK(hipStreamSynchronize(us));
+}
+static void dev_free(void* p) {
+  if (!p) return;
+  RuntimeLock rl;
+  (void)hipFree(p);
+}
+static void dev_alloc(void** p, size_t bytes) {
+  RuntimeLock rl;
+  HIPCHECK(hipMalloc(p, bytes));
+}
+// The launches `enqueue(cs)` puts on stream cs, as an executable graph.  Relaxed mode: cs is a non-blocking stream of the
+// library's own and only kernel launches are recorded — nothing another thread does can belong to the capture.
+template <class F>
+static hipGraphExec_t capture_graph(void* cs, F&& enqueue) {
+  RuntimeLock rl;
+  hipGraph_t graph;
+  HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeRelaxed));
+  try {
+    enqueue(cs);
+  } catch (...) {
+    hipGraph_t g2;
+    (void)hipStreamEndCapture((hipStream_t)cs, &g2);
+    throw;
+  }
+  HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
+  hipGraphExec_t ge;
+  const hipError_t e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) throw DcError(DC_EDEVICE, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+  return ge;
+}
+
 // ---- Storage ------------------------------------------------------------------------------------
 Storage::~Storage() {
   if (host) {
-    if (host_pinned) (void)hipHostFree(host);
-    else std::free(host);
+    if (host_pinned) {
+      RuntimeLock rl;
+      (void)hipHostFree(host);
+    } else std::free(host);
   }
-  if (dev) (void)hipFree(dev);
-  if (stage) (void)hipFree(stage);
+  dev_free(dev);
+  dev_free(stage);
 }
 size_t Storage::count() const {
   size_t c = 1;
@@ -70,8 +145,10 @@ void Storage::reshape(const std::vector<int>& s) {
   shape = s;
   if (count() > host_cap && host) {
     // Blob::Reshape replaces the SyncedMemory when capacity grows (blob.cpp:37-41)
-    if (host_pinned) (void)hipHostFree(host);
-    else std::free(host);
+    if (host_pinned) {
+      RuntimeLock rl;
+      (void)hipHostFree(host);
+    } else std::free(host);
     host = nullptr;
     host_cap = 0;
     head = UNINITIALIZED;
@@ -96,6 +173,7 @@ float* Storage::host_ptr() {
     host_pinned = false;
     if (device_count() > 0 && !is_param) {
       void* p = nullptr;
+      RuntimeLock rl;
       if (hipHostMalloc(&p, n * sizeof(float), hipHostMallocDefault) == hipSuccess) {
         host = (float*)p;
         host_pinned = true;
@@ -113,14 +191,13 @@ float* Storage::host_ptr() {
 void Storage::ensure_dev(size_t n) {
   const size_t bytes = std::max<size_t>(n, 8) * (size_t)esize;
   if (bytes <= dev_cap && dev) return;
-  if (dev) HIPCHECK(hipFree(dev));
+  dev_free(dev);
   dev = nullptr;
-  HIPCHECK(hipMalloc((void**)&dev, bytes));
-  // pitch-padding channels stay 0.  The fill runs on the NULL stream and may return before it has executed, while the
-  // executors' streams are non-blocking (they do not wait for the NULL stream): without the wait below the fill could land
-  // AFTER the first kernels of a forward had written the buffer (seen once as garbage in a clone's first request).
-  HIPCHECK(hipMemset(dev, 0, bytes));
-  HIPCHECK(hipStreamSynchronize(nullptr));
+  dev_alloc((void**)&dev, bytes);
+  // pitch-padding channels stay 0.  The fill is complete when dev_zero returns: the executors' streams are non-blocking and
+  // order themselves after nothing, a fill still in flight could land AFTER the first kernels of a forward had written the
+  // buffer (seen once as garbage in a clone's first request, when the fill went to the NULL stream unwaited).
+  dev_zero(dev, bytes);
   dev_cap = bytes;
   if (owner) {  // captured graphs carry the old address: they are re-captured lazily (PlanState::graph_buf_gen)
     ++owner->buf_gen_;
@@ -129,9 +206,9 @@ void Storage::ensure_dev(size_t n) {
 }
 void Storage::ensure_stage(size_t n) {
   if (n <= stage_cap && stage) return;
-  if (stage) HIPCHECK(hipFree(stage));
+  dev_free(stage);
   stage = nullptr;
-  HIPCHECK(hipMalloc((void**)&stage, std::max<size_t>(n, 4) * sizeof(float)));
+  dev_alloc((void**)&stage, std::max<size_t>(n, 4) * sizeof(float));
   stage_cap = n;
 }
 
@@ -222,7 +299,7 @@ int pair_or(const TextMsg* m, const char* rep, const char* single, int idx, int 
 
 // ---- Net: construction ----------------------------------------------------------------------------
 DevVec::~DevVec() {
-  if (dev) (void)hipFree(dev);
+  dev_free(dev);
 }
 
 Net::~Net() {
@@ -230,10 +307,10 @@ Net::~Net() {
   for (auto& ps : parked_)
     if (ps->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ps->graph_exec);
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
-  if (pose_dev) (void)hipFree(pose_dev);
-  if (scratch_dev_) (void)hipFree(scratch_dev_);
-  if (img_dev_) (void)hipFree(img_dev_);
-  if (tmp_dev_) (void)hipFree(tmp_dev_);
+  dev_free(pose_dev);
+  dev_free(scratch_dev_);
+  dev_free(img_dev_);
+  dev_free(tmp_dev_);
 }
 
 Net* Net::create(const std::string& text, int phase, const Net* clone_of) {
@@ -281,7 +358,7 @@ void Net::set_dtype(int d) {
     if (st->head == HEAD_AT_GPU) sync_to_host(*st);  // keep what the user can still read
     if (st->head == SYNCED) st->head = HEAD_AT_CPU;
     if (st->dev) {
-      (void)hipFree(st->dev);
+      dev_free(st->dev);
       st->dev = nullptr;
       st->dev_cap = 0;
     }
@@ -1664,15 +1741,18 @@ void Net::upload_vecs() {
     if (!v.dev && !v.host.empty()) {
       if (v.as_half) {  // filter image of an fp16 net: upload as float, convert on the device, keep the half copy
         float* tmp = nullptr;
-        HIPCHECK(hipMalloc((void**)&tmp, v.host.size() * sizeof(float)));
-        HIPCHECK(hipMemcpy(tmp, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * 2));
+        dev_alloc((void**)&tmp, v.host.size() * sizeof(float));
+        struct TmpGuard {
+          float* p;
+          ~TmpGuard() { dev_free(p); }
+        } tmp_guard{tmp};
+        dev_upload(tmp, v.host.data(), v.host.size() * sizeof(float));
+        dev_alloc((void**)&v.dev, v.host.size() * 2);
         KCHECK(launch_f32_to_f16(tmp, v.dev, (long)v.host.size(), stream));
         HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
-        HIPCHECK(hipFree(tmp));
       } else {
-        HIPCHECK(hipMalloc((void**)&v.dev, v.host.size() * sizeof(float)));
-        HIPCHECK(hipMemcpy(v.dev, v.host.data(), v.host.size() * sizeof(float), hipMemcpyHostToDevice));
+        dev_alloc((void**)&v.dev, v.host.size() * sizeof(float));
+        dev_upload(v.dev, v.host.data(), v.host.size() * sizeof(float));
       }
       v.uploaded = v.host.size();
       std::vector<float>().swap(v.host);  // the packed image lives in HBM only
@@ -2145,9 +2225,8 @@ void Net::run_launch(const Launch& l, void* s) {
         const int nwv = wino ? 8 : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
         const long n = (l.grid * 2 + 64) * nwv * 12;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
-        HIPCHECK(hipMalloc((void**)&d, n * sizeof(long long)));
-        HIPCHECK(hipMemset(d, 0, n * sizeof(long long)));
-        HIPCHECK(hipStreamSynchronize(nullptr));
+        dev_alloc((void**)&d, n * sizeof(long long));
+        dev_zero(d, n * sizeof(long long));
         for (int rep = 0; rep < 3; ++rep) {
           g.dbg = d;
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
@@ -2156,8 +2235,9 @@ void Net::run_launch(const Launch& l, void* s) {
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
         }
         std::vector<long long> h(n);
-        HIPCHECK(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
-        (void)hipFree(d);
+        HIPCHECK(hipMemcpyAsync(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost, (hipStream_t)s));
+        HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+        dev_free(d);
         double dsum[8] = {0}, karg = 0;
         long cnt = 0;
         long long t0min = 0, t0max = 0, t7max = 0;
@@ -2283,20 +2363,7 @@ void Net::forward(int start, int end) {
   if (use_graph && whole) {
     if (graph_exec && graph_buf_gen != buf_gen_) release_graph();  // a buffer it addresses was reallocated since
     if (!graph_exec) {
-      hipGraph_t graph;
-      HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
-      try {
-        run_plan(start, end, stream);
-      } catch (...) {
-        hipGraph_t g2;
-        (void)hipStreamEndCapture((hipStream_t)stream, &g2);
-        throw;
-      }
-      HIPCHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
-      hipGraphExec_t ge;
-      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      graph_exec = ge;
+      graph_exec = capture_graph(stream, [&](void* cs) { run_plan(start, end, cs); });
       graph_buf_gen = buf_gen_;
       ++stats.graph_instantiations;
     }
@@ -2352,20 +2419,7 @@ void Net::enqueue_plan(void* s) {
     // the caller works on (a graph is not tied to its capture stream)
     if (graph_exec && graph_buf_gen != buf_gen_) release_graph();  // a buffer it addresses was reallocated since
     if (!graph_exec) {
-      hipGraph_t graph;
-      HIPCHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
-      try {
-        run_plan(0, last, stream);
-      } catch (...) {
-        hipGraph_t g2;
-        (void)hipStreamEndCapture((hipStream_t)stream, &g2);
-        throw;
-      }
-      HIPCHECK(hipStreamEndCapture((hipStream_t)stream, &graph));
-      hipGraphExec_t ge;
-      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      graph_exec = ge;
+      graph_exec = capture_graph(stream, [&](void* cs) { run_plan(0, last, cs); });
       graph_buf_gen = buf_gen_;
       ++stats.graph_instantiations;
     }
@@ -2476,8 +2530,8 @@ void Net::forward_requests(int n, const float* const* inputs, int h, int w, floa
 // Pillow's precompute_coeffs / normalize_coeffs_8bpc do, so the device result is bit-identical to the reference's.
 #pragma clang fp contract(off)
 ResampleTable::~ResampleTable() {
-  if (dev_bounds) (void)hipFree(dev_bounds);
-  if (dev_coeffs) (void)hipFree(dev_coeffs);
+  dev_free(dev_bounds);
+  dev_free(dev_coeffs);
 }
 
 void resample_coeffs(int in_size, int out_size, int& ksize, std::vector<int>& bounds, std::vector<int>& coeffs) {
@@ -2523,10 +2577,10 @@ std::shared_ptr<ResampleTable> Net::resample_table(int in_size, int out_size) {
   std::vector<int> b, c;
   resample_coeffs(in_size, out_size, t->ksize, b, c);
   t->bounds = b;
-  HIPCHECK(hipMalloc((void**)&t->dev_bounds, b.size() * sizeof(int)));
-  HIPCHECK(hipMalloc((void**)&t->dev_coeffs, c.size() * sizeof(int)));
-  HIPCHECK(hipMemcpy(t->dev_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHECK(hipMemcpy(t->dev_coeffs, c.data(), c.size() * sizeof(int), hipMemcpyHostToDevice));
+  dev_alloc((void**)&t->dev_bounds, b.size() * sizeof(int));
+  dev_alloc((void**)&t->dev_coeffs, c.size() * sizeof(int));
+  dev_upload(t->dev_bounds, b.data(), b.size() * sizeof(int));
+  dev_upload(t->dev_coeffs, c.data(), c.size() * sizeof(int));
   if (resample_.size() > 64) resample_.clear();  // a pyramid uses a handful; bound the cache anyway
   resample_[key] = t;
   return t;
@@ -2574,9 +2628,9 @@ void Net::prep_images(const unsigned char* bgr, int n, int h, int w, double scal
   const size_t bytes = (size_t)n * h * w * 3;
   if (!is_device) {
     if (bytes > img_cap_) {
-      if (img_dev_) HIPCHECK(hipFree(img_dev_));
+      dev_free(img_dev_);
       img_dev_ = nullptr;
-      HIPCHECK(hipMalloc((void**)&img_dev_, bytes));
+      dev_alloc((void**)&img_dev_, bytes);
       img_cap_ = bytes;
     }
     HIPCHECK(hipMemcpyAsync(img_dev_, bgr, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
@@ -2606,9 +2660,9 @@ void Net::prep_images(const unsigned char* bgr, int n, int h, int w, double scal
     q.x_bounds = tx.dev_bounds, q.x_coeffs = tx.dev_coeffs, q.x_ksize = tx.ksize;
     const size_t tb = (size_t)n * q.rows * use_w * 4;
     if (tb > tmp_cap_) {
-      if (tmp_dev_) HIPCHECK(hipFree(tmp_dev_));
+      dev_free(tmp_dev_);
       tmp_dev_ = nullptr;
-      HIPCHECK(hipMalloc((void**)&tmp_dev_, tb));
+      dev_alloc((void**)&tmp_dev_, tb);
       tmp_cap_ = tb;
     }
     q.tmp = tmp_dev_;
@@ -2656,9 +2710,9 @@ void Net::decode_pose(double scale, double* out, bool is_device, void* user_stre
     return;
   }
   if (cnt > pose_cap) {
-    if (pose_dev) HIPCHECK(hipFree(pose_dev));
+    dev_free(pose_dev);
     pose_dev = nullptr;
-    HIPCHECK(hipMalloc((void**)&pose_dev, cnt * sizeof(double)));
+    dev_alloc((void**)&pose_dev, cnt * sizeof(double));
     pose_cap = cnt;
   }
   KCHECK(launch_pose_decode(pp, pcp, pc0, lp, lcp, lc0, pes, NB, H, W, J, scale, pose_dev, s));
@@ -2686,9 +2740,9 @@ Net::MapRef Net::map_ref(const char* blob_name) {
 
 void* Net::scratch(size_t bytes) {
   if (bytes > scratch_cap_) {
-    if (scratch_dev_) HIPCHECK(hipFree(scratch_dev_));
+    dev_free(scratch_dev_);
     scratch_dev_ = nullptr;
-    HIPCHECK(hipMalloc((void**)&scratch_dev_, bytes));
+    dev_alloc((void**)&scratch_dev_, bytes);
     scratch_cap_ = bytes;
   }
   return scratch_dev_;
@@ -2900,7 +2954,10 @@ void* NetGroup::stream() { return nets[0]->stream; }
 void NetGroup::drop_plan(GroupPlan& gp) {
   // nothing enqueued may still replay the graphs.  The device-wide wait covers the members' streams, the lanes' and the caller's
   // without touching a member: a group may be destroyed AFTER its nets (a garbage collector finalises a cycle in any order)
-  (void)hipDeviceSynchronize();
+  {
+    RuntimeLock rl;  // (no capture of ours is open while the device is waited for)
+    (void)hipDeviceSynchronize();
+  }
   gp.drop_graphs();
 }
 
@@ -3223,6 +3280,7 @@ void NetGroup::autotune(GroupPlan& gp) {
   std::lock_guard<std::mutex> lk(n0.shared->mu);
   std::map<std::string, int>& cache = n0.shared->tune_cache;
   bool timed_any = false;
+  std::set<std::string> fresh;  // the signatures timed by THIS call: a choice that is in the table stays (other plans run it)
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct EvGuard {
     hipEvent_t &a, &b;
@@ -3237,6 +3295,7 @@ void NetGroup::autotune(GroupPlan& gp) {
   for (auto& gl : gp.launches) {
     if (!gl.multi || cache.count(gl.key)) continue;
     timed_any = true;
+    fresh.insert(gl.key);
     std::vector<std::pair<float, int>> c;
     for (int v = 0; v < conv_num_variants(); ++v) {
       if (!conv_variant_multiproblem(v) || gl.p.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != gl.p.esize) continue;
@@ -3273,7 +3332,7 @@ void NetGroup::autotune(GroupPlan& gp) {
     std::map<std::string, std::vector<int>> shortlist;
     size_t rounds = 0;
     for (auto& gl : gp.launches) {
-      if (!gl.multi || shortlist.count(gl.key)) continue;
+      if (!gl.multi || shortlist.count(gl.key) || !fresh.count(gl.key)) continue;
       auto t = n0.shared->tune_timings.find(gl.key);
       if (t == n0.shared->tune_timings.end()) continue;
       std::vector<int> sl;
@@ -3390,21 +3449,7 @@ void NetGroup::enqueue(void* s) {
   if (use_graph)
     for (int lane = 0; lane < nl; ++lane) {
       if (gp.lane_graphs[lane]) continue;
-      hipGraph_t graph;
-      void* cs = stream();
-      HIPCHECK(hipStreamBeginCapture((hipStream_t)cs, hipStreamCaptureModeThreadLocal));
-      try {
-        run(gp, lane, cs);
-      } catch (...) {
-        hipGraph_t g2;
-        (void)hipStreamEndCapture((hipStream_t)cs, &g2);
-        throw;
-      }
-      HIPCHECK(hipStreamEndCapture((hipStream_t)cs, &graph));
-      hipGraphExec_t ge;
-      HIPCHECK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(graph);
-      gp.lane_graphs[lane] = ge;
+      gp.lane_graphs[lane] = capture_graph(stream(), [&](void* cs) { run(gp, lane, cs); });
       ++stats.graph_instantiations;
     }
   if (nl > 1) {
@@ -3618,7 +3663,10 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
   if (!any) throw DcError(DC_EINVAL, "the group's current plan has no launch with signature '" + key + "'");
   // nothing of this plan may be in flight while its launches change (the forward may have run on a caller's stream and on lane
   // streams: the device-wide wait covers them all)
-  (void)hipDeviceSynchronize();
+  {
+    RuntimeLock rl;
+    (void)hipDeviceSynchronize();
+  }
   for (auto& gl : cur_->launches)
     if (gl.multi && gl.key == key) apply_variant(*cur_, gl, v);
   {

@@ -436,3 +436,23 @@ def test_group_profile_refuses_a_plan_its_members_have_left(gpu_caffe, synth152,
     for o, a, (_, ref) in zip(outs, again, refs[:2]):
         _check32(a, ref)
     assert "conv_gemm_mp<" in grp.profile_text(1)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_groups_on_concurrent_host_threads(dtype):
+    """Three groups of one model, each driven by its own host thread on its own stream (tools/stress_groups.py): alternating tuples
+    of member shapes, members run alone in between — also at new, ever larger shapes: lowering, tile timing, buffer growth and a
+    graph capture while the other threads run and capture — and synchronous legacy-stream work of the host application beside
+    it.  Every grouped result must equal the group's first for the same inputs bit for bit, and the groups must agree with each
+    other (they share the model's tile choices).  A process of its own: the HIP runtime's capture rule is process-wide
+     and so is what this guards."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_groups.py"), dtype, "120", "3", "3"], capture_output=True,
+                       text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "sequential round" not in r.stdout, tail  # the groups agreed before the threads started
+    assert "OK mismatches [0, 0, 0] rounds done [120, 120, 120]" in r.stdout, tail
