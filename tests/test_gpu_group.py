@@ -456,3 +456,18 @@ def test_groups_on_concurrent_host_threads(dtype):
     assert r.returncode == 0, tail
     assert "sequential round" not in r.stdout, tail  # the groups agreed before the threads started
     assert "OK mismatches [0, 0, 0] rounds done [120, 120, 120]" in r.stdout, tail
+
+
+@pytest.mark.parametrize("dtype,threads", [("f32", 3), ("f16", 4)])
+def test_clones_on_concurrent_host_threads(dtype, threads):
+    """The plain-net companion (tools/stress_clones.py): every thread drives a clone of its own through the device, host and
+    image entries over shapes old and new; every result bit-identical to executor 0's sequential one."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_clones.py"), dtype, "60", str(threads)], capture_output=True,
+                       text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "OK mismatches %r rounds done %r" % ([0] * threads, [60] * threads) in r.stdout, tail
