@@ -18,6 +18,8 @@ import time
 
 
 class Pipeline(object):
+    LATENCY_WINDOW = 1 << 16
+
     def __init__(self, net, depth=3, coalesce=None, max_batch=4, max_queue=None):
         self.nets = [net] + [net.clone() for _ in range(max(1, depth) - 1)]
         self.opportunistic = coalesce is None
@@ -29,7 +31,8 @@ class Pipeline(object):
         self._pending = collections.deque()  # (executor, [(tag, submit time)]) in launch order
         self._held = collections.deque()     # queued requests: (in, h, w, prob, loc, next, tag, n, submit time)
         self._done = collections.deque()     # tags of finished requests not yet handed back
-        self.latencies = []                  # seconds from submit() to the moment the request was seen finished
+        # seconds from submit() to the moment the request was seen finished: the last LATENCY_WINDOW requests (a service runs for days)
+        self.latencies = collections.deque(maxlen=self.LATENCY_WINDOW)
         self.batch_sizes = collections.Counter()
 
     @property
@@ -131,6 +134,8 @@ class Pipeline(object):
 
     def wait_one(self):
         """Block until a request has finished; returns its tag (requests of one executor finish in order)."""
+        if not (self._done or self._pending or self._held):
+            raise RuntimeError("wait_one() with nothing submitted")
         if not self._done:
             if self.opportunistic:
                 self._pump()
@@ -161,7 +166,7 @@ class Pipeline(object):
         return {q: v[min(len(v) - 1, int(round(q / 100.0 * (len(v) - 1))))] * 1e3 for q in qs}
 
     def reset_stats(self):
-        self.latencies = []
+        self.latencies = collections.deque(maxlen=self.LATENCY_WINDOW)
         self.batch_sizes = collections.Counter()
 
     def tune(self, requests, rounds=4, **kw):
@@ -181,7 +186,7 @@ class Pipeline(object):
         fixed.__dict__.update(self.__dict__)
         fixed.opportunistic, fixed.coalesce = False, self.max_batch
         fixed._pending, fixed._held, fixed._done = collections.deque(), collections.deque(), collections.deque()
-        fixed.latencies, fixed.batch_sizes = [], collections.Counter()
+        fixed.latencies, fixed.batch_sizes = collections.deque(maxlen=self.LATENCY_WINDOW), collections.Counter()
 
         def load():
             t0 = time.perf_counter()
