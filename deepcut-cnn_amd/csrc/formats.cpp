@@ -278,7 +278,7 @@ BlobData parse_blob(Reader r) {
       size_t n = (size_t)(d.e - d.p) / 4;
       size_t old = b.data.size();
       b.data.resize(old + n);
-      std::memcpy(b.data.data() + old, d.p, n * 4);
+      if (n) std::memcpy(b.data.data() + old, d.p, n * 4);  // (an empty packed field: no copy from / to a null vector)
     } else if (fn == 5 && wt == 5) {  // unpacked float
       r.need(4);
       float f;

@@ -171,11 +171,24 @@ BlobData read_dataset(const H5& f, uint64_t header, const std::string& what) {
     }
   }
   if (!have_space || !have_type || !have_layout) f.bad(what + " is not a simple dataset");
-  const size_t cnt = out.count();
-  out.data.assign(cnt, 0.f);
-  if (data_len == 0) return out;
+  // the element count: 32 dimensions of up to 2^31 - 1 overflow any integer; a blob holds at most INT_MAX elements (blob.cpp:33)
+  uint64_t cnt64 = 1;
+  for (int d : out.shape) {
+    cnt64 *= (uint64_t)d;
+    if (cnt64 > 0x7fffffffull) f.bad(what + ": more than INT_MAX elements");
+  }
+  const size_t cnt = (size_t)cnt64;
+  if (data_len == 0) {
+    // never written: all zeros — from no bytes at all, so the size is capped (2^29 elements = 2 GiB; the largest layer
+    // blob of the model zoo, VGG's fc6, has 1.0e8) instead of letting a 1-KB file ask for 8 GB
+    if (cnt > ((size_t)1 << 29)) f.bad(what + ": an unwritten dataset of " + std::to_string(cnt) + " elements");
+    out.data.assign(cnt, 0.f);
+    return out;
+  }
   if (data_len < (uint64_t)cnt * elem) f.bad(what + ": stored size smaller than the dataspace");
-  f.need(data_at, (uint64_t)cnt * elem);
+  f.need(data_at, (uint64_t)cnt * elem);  // (the bytes are there: the allocation below is justified by the file's size)
+  out.data.assign(cnt, 0.f);
+  if (cnt == 0) return out;
   if (elem == 4) {
     std::memcpy(out.data.data(), f.b + data_at, cnt * 4);
   } else {  // double -> Dtype, as hdf5_load_nd_dataset<float> does through H5LTread_dataset_float
