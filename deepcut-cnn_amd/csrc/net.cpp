@@ -142,8 +142,14 @@ int Storage::cp() const {
 }
 size_t Storage::dev_count() const { return (size_t)dim(0) * dim(2) * dim(3) * cp(); }
 void Storage::reshape(const std::vector<int>& s) {
-  for (int d : s)
+  long long total = 1;
+  for (int d : s) {
     if (d < 0) throw DcError(DC_ESHAPE, "negative blob dimension");
+    // Blob::Reshape: CHECK_LE(shape[i], INT_MAX / count_) << "blob size exceeds INT_MAX" (blob.cpp:31-34) — four dimensions of
+    // 65536 would otherwise wrap the element count to 0
+    if (d != 0 && total > 0x7fffffffLL / d) throw DcError(DC_ESHAPE, "blob size exceeds INT_MAX");
+    total *= d;
+  }
   shape = s;
   if (count() > host_cap && host) {
     // Blob::Reshape replaces the SyncedMemory when capacity grows (blob.cpp:37-41)
