@@ -418,6 +418,9 @@ def main():
     ap.add_argument("--breakdown", default="", help="write the per-launch hipEvent table to this file")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "0")),
                     help="independent batch-B forwards kept in flight per GPU (each on its own HIP stream and Net)")
+    ap.add_argument("--stream-candidates", type=int, default=int(os.environ.get("DC_BENCH_STREAM_CANDIDATES", "8")),
+                    help="the streams of the forwards in flight are the fastest --streams-subset of this many candidates, by measurement "
+                         "(0: the first streams created)")
     ap.add_argument("--backend", default=os.environ.get("DC_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real thing) or gloo (lets two ranks share one "
                          "GPU to smoke-test the N>1 code path on a 1-GPU box)")
@@ -484,7 +487,6 @@ def main():
     # "no stream given: the net's own stream, synchronous" (rounds 1-3 ran executor 0 that way: the host blocked on it after
     # every one of its forwards while the other executors ran ahead)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    main = streams[0]
     xs = [(torch.randn(B, 3, H, W, generator=g) * 50).to(dev) for _ in range(S)]
     # the maps leave the net in its own element type: float16 payloads from a float16 net (half the gather bytes)
     half = args.dtype == "f16"
@@ -546,6 +548,7 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        main = streams[0]
         e0.record(main)
         for st in streams[1:nstreams]:
             st.wait_stream(main)
@@ -574,6 +577,38 @@ def main():
     # (2) the reported throughput: S independent batch-B forwards in flight (S streams, S Nets).  The tiles region (1) ran with were
     # chosen for the latency of one forward; a service that keeps S forwards in flight tunes for THAT load (untimed, like the
     # autotuning inside the warm-up): deepcut_tools.tune_in_flight, coordinate descent over the busiest GEMM signatures.
+    # WHICH S streams?  A HIP process has four hardware queues and the runtime binds every stream to one of them when it is
+    # created; S forwards "in flight" on streams that share queues are fewer forwards in flight (tools/stream_subset_probe.py, four
+    # executors on the 70 four-subsets of eight streams: 12 subsets at 478-492 images/s, 53 at 419-434, 5 at 376-390 — and which
+    # subset the first S streams of a process are depends on every stream created before them).  So, like the lanes of a group
+    # (NetGroup::choose_lane_streams): candidates, the real forwards on every S-subset, the fastest subset stays.  Untimed.
+    stream_choice = None
+    if S > 1 and args.stream_candidates > S:
+        import itertools
+
+        cands = list(streams) + [torch.cuda.Stream(dev) for _ in range(args.stream_candidates - S)]
+
+        def burst(sub):
+            for k, j in enumerate(sub):
+                streams[k] = cands[j]
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(6 * S):
+                forward_slot(i % S)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        rows = []
+        for sub in itertools.combinations(range(len(cands)), S):
+            burst(sub)
+            rows.append((min(burst(sub), burst(sub)), sub))
+        rows.sort()
+        first = [t for t, sub in rows if sub == tuple(range(S))][0]
+        for k, j in enumerate(rows[0][1]):
+            streams[k] = cands[j]
+        stream_choice = {"candidates": len(cands), "subsets_timed": len(rows), "chosen": list(rows[0][1]),
+                         "images_per_s_chosen": 6 * S * B / rows[0][0], "images_per_s_first_created": 6 * S * B / first,
+                         "images_per_s_worst": 6 * S * B / rows[-1][0]}
     tuning = None
     if S > 1 and not args.no_tune_in_flight:
         from deepcut_tools import tune_in_flight
@@ -653,6 +688,7 @@ def main():
                 "launches_per_forward": launches,
                 "hipgraph": not args.no_graph,
                 "forwards_in_flight": S,
+                "stream_choice": stream_choice,
                 "tile_tuning": ("in flight (deepcut_tools.tune_in_flight: %d signatures re-tiled, %d without isolated timings skipped, %.2f -> %.2f ms per %d forwards, %d untimed runs)"
                                 % (len(tuning["changed"]), tuning.get("skipped", 0), tuning["before"] * 1e3, tuning["after"] * 1e3, 6 * S, tuning["runs"])
                                 if tuning and "error" not in tuning else ("latency" if not tuning else tuning["error"])),
