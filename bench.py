@@ -10,7 +10,8 @@ by the RCCL gather of the three score maps to rank 0.  Two timed regions of exac
 run: one forward at a time (kernel durations for the roofline), then with `--streams` (default 4 at batch 1)
 independent batch-B forwards in flight on separate HIP streams — a batch-1 layer of this net fills
 only ~3/4 of the 256 CUs, the next request's kernels fill the rest; `value` is that throughput and the
-one-at-a-time figure is reported beside it.  Workload at N=1 = BASELINE.json configs[1]:
+one-at-a-time figure is reported beside it.  The streams of the forwards in flight are the fastest subset of
+`--stream-candidates` (8) streams, measured untimed on the real forwards (`config.stream_choice`).  Workload at N=1 = BASELINE.json configs[1]:
 batch=1, 1x3x544x736, fp32 (the shipped prototxt is ResNet-152 — SURVEY F1 — not the "ResNet-101"
 of the config string).  Weak scaling: every rank forwards its own image each step.
 Rank 0 prints ONE JSON line.
