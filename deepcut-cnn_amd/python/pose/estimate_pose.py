@@ -173,6 +173,14 @@ def pose_from_maps(prob, loc_pred, scale=1.0):
     return pose
 
 
+def pose_cells(pose, scale=1.0):
+    """(rows, cols) of the arg-max cells a 5xJ pose was decoded from (the inverse of `pose_from_maps`' position rule)."""
+    pose = _np.asarray(pose, _np.float64)
+    cols = _np.rint(((pose[0] - pose[4]) * scale - 0.5 * STRIDE) / STRIDE).astype(int)
+    rows = _np.rint(((pose[1] - pose[3]) * scale - 0.5 * STRIDE) / STRIDE).astype(int)
+    return rows, cols
+
+
 def select_best(poses):
     """Keep the pose whose minimum joint confidence is highest (strict >, initial 0): None if no scale
     reaches a positive minimum, like the reference."""
@@ -203,28 +211,50 @@ def forward_maps(net, net_input):
     return net.blobs["prob"].data[0].copy(), net.blobs["loc_pred"].data[0].copy()
 
 
-def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None, on_device=True):
+def _scale_group(net, n):
+    """The grouped executor of an n-scale pyramid for `net`: the net itself plus n - 1 clones.  The clones are kept with
+    the net and shared by the groups of every n (a 2-scale and a 4-scale call use the same first clone), and at most
+    `_MAX_SCALE_GROUPS` groups are kept per net (least recently used first out), so neither grows with the number of
+    distinct len(scales) a caller goes through."""
+    import caffe as _caffe
+
+    groups = net.__dict__.setdefault("_scale_groups", {})
+    grp = groups.pop(n, None)
+    if grp is None:
+        clones = net.__dict__.setdefault("_scale_clones", [])
+        while len(clones) < n - 1:
+            clones.append(net.clone())
+        grp = _caffe.NetGroup([net] + clones[: n - 1])
+        while len(groups) >= _MAX_SCALE_GROUPS:
+            groups.pop(next(iter(groups)))
+    groups[n] = grp  # most recently used last
+    return grp
+
+
+_MAX_SCALE_GROUPS = 4
+
+
+def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None, on_device=True, grouped=None):
     """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring).
     tiling: None (one forward per scale), "exact" or "reference" (see `forward_maps_tiled`).
     on_device: without tiling, pre-process and decode on the GPU (`Net.forward_images`: the same canvas bit
     for bit, the same forward, 70 doubles back instead of the maps); False keeps every step where the
-    reference has it (Pillow + NumPy on the host around `net.forward()`)."""
+    reference has it (Pillow + NumPy on the host around `net.forward()`).
+    grouped: None = several scales on the device run as ONE grouped forward (`caffe.NetGroup`); False = the
+    reference's loop, one forward per scale (bit-identical to the host route's forwards)."""
     if scales is None:
         scales = [1.0]
     if net is None:
         net = _get_model(model_def, model_bin)
     poses = []
-    if tiling is None and on_device and len(scales) > 1 and hasattr(net, "clone") and _np.asarray(image).dtype == _np.uint8:
+    if (grouped is None or grouped) and tiling is None and on_device and len(scales) > 1 and hasattr(net, "clone") \
+            and _np.asarray(image).dtype == _np.uint8:
         # the scale loop of the reference (:81-128) as ONE grouped forward: a member per scale (the net and clones of it, kept
         # with the net), every layer a single launch over all the scales (caffe.NetGroup / dc_group_forward_images)
         import caffe as _caffe
 
         if hasattr(_caffe, "NetGroup"):
-            groups = net.__dict__.setdefault("_scale_groups", {})
-            grp = groups.get(len(scales))
-            if grp is None:
-                grp = groups[len(scales)] = _caffe.NetGroup([net] + [net.clone() for _ in scales[1:]])
-            outs = grp.forward_images(_np.asarray(image), list(scales), want=(), pose=True)
+            outs = _scale_group(net, len(scales)).forward_images(_np.asarray(image), list(scales), want=(), pose=True)
             return select_best([o["pose"][0] for o in outs])
     for s in scales:
         if tiling is None and on_device and hasattr(net, "forward_images") and _np.asarray(image).dtype == _np.uint8:

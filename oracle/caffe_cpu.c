@@ -309,15 +309,18 @@ int oracle_pool_out(int in, int k, int p, int s) {
   if (p && (o - 1) * s >= in + p) --o;
   return o;
 }
-void oracle_maxpool_forward(const float* x, int N, int C, int H, int W, int k, int s, int p, float* y) {
-  const int OH = oracle_pool_out(H, k, p, s), OW = oracle_pool_out(W, k, p, s);
+/* kernel_h/kernel_w, stride_h/stride_w, pad_h/pad_w as pooling_layer.cpp:22-77 accepts them (the path uses the square k3 s2 p0
+ * form only; the rectangular form exists so that the reference's own literals test_pooling_layer.cpp:121-372 can pin this loop) */
+void oracle_maxpool_forward_rect(const float* x, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 float* y) {
+  const int OH = oracle_pool_out(H, kh, ph, sh), OW = oracle_pool_out(W, kw, pw, sw);
   for (int nc = 0; nc < N * C; ++nc) {
     const float* xi = x + (size_t)nc * H * W;
     float* yo = y + (size_t)nc * OH * OW;
     for (int oy = 0; oy < OH; ++oy)
       for (int ox = 0; ox < OW; ++ox) {
-        int hs = oy * s - p, ws = ox * s - p;
-        int he = hs + k < H ? hs + k : H, we = ws + k < W ? ws + k : W;
+        int hs = oy * sh - ph, ws = ox * sw - pw;
+        int he = hs + kh < H ? hs + kh : H, we = ws + kw < W ? ws + kw : W;
         if (hs < 0) hs = 0;
         if (ws < 0) ws = 0;
         float m = -FLT_MAX;
@@ -327,6 +330,9 @@ void oracle_maxpool_forward(const float* x, int N, int C, int H, int W, int k, i
         yo[oy * OW + ox] = m;
       }
   }
+}
+void oracle_maxpool_forward(const float* x, int N, int C, int H, int W, int k, int s, int p, float* y) {
+  oracle_maxpool_forward_rect(x, N, C, H, W, k, k, s, s, p, p, y);
 }
 
 /* ---- Crop (fork-specific, crop_layer.cpp:25-50): top = bottom0[:, :, oh:oh+H1, ow:ow+W1] ------------------ */

@@ -44,6 +44,7 @@ def lib():
         L.oracle_pool_out.argtypes = [ci] * 4
         L.oracle_pool_out.restype = ci
         L.oracle_maxpool_forward.argtypes = [fp, ci, ci, ci, ci, ci, ci, ci, fp]
+        L.oracle_maxpool_forward_rect.argtypes = [fp] + [ci] * 10 + [fp]
         L.oracle_crop_forward.argtypes = [fp] + [ci] * 8 + [fp]
         L.oracle_sgemm.argtypes = [ci, ci, ci, ci, fp, fp, cf, fp]
         L.oracle_im2col.argtypes = [fp] + [ci] * 11 + [fp]
@@ -145,11 +146,16 @@ def eltwise_sum(a, b):
 
 
 def maxpool_forward(x, k, stride, pad=0):
+    """k / stride / pad: int or (h, w)."""
     x = _f32(x)
     n, c, h, w = x.shape
-    oh, ow = lib().oracle_pool_out(h, k, pad, stride), lib().oracle_pool_out(w, k, pad, stride)
+    (kh, kw), (sh, sw), (ph, pw) = _hw(k), _hw(stride), _hw(pad)
+    oh, ow = lib().oracle_pool_out(h, kh, ph, sh), lib().oracle_pool_out(w, kw, pw, sw)
     y = np.empty((n, c, oh, ow), np.float32)
-    lib().oracle_maxpool_forward(_p(x), n, c, h, w, k, stride, pad, _p(y))
+    if (kh, sh, ph) == (kw, sw, pw):
+        lib().oracle_maxpool_forward(_p(x), n, c, h, w, kh, sh, ph, _p(y))
+    else:
+        lib().oracle_maxpool_forward_rect(_p(x), n, c, h, w, kh, kw, sh, sw, ph, pw, _p(y))
     return y
 
 

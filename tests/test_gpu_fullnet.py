@@ -135,11 +135,17 @@ def test_pose_demo_pipeline_config0(gpu_caffe, synth152):
     assert float(np.abs(net.blobs["loc_pred"].data - ref["loc_pred"]).max()) <= TOL
     ref_pose = ep.select_best([ep.pose_from_maps(ref["prob"][0], ref["loc_pred"][0], 1.0)])
     assert pose is not None and pose.shape == (5, 14) and np.isfinite(pose).all()
-    # same arg-max cells unless two cells tie within the tolerance; positions agree to sqrt(53)*1e-3 px
-    assert np.abs(pose - ref_pose).max() <= 8.0 + 1e-2
-    same = np.abs(pose[:2] - ref_pose[:2]).max(axis=0) < 1.0
-    assert same.sum() >= 13
-    assert np.abs(pose[:, same] - ref_pose[:, same]).max() <= 1e-2
+    # same arg-max cells, or a cell that ties with the oracle's maximum within the tolerance (proved on the oracle's own map:
+    # a joint decoded from any other cell is a wrong cell, however few there are); positions agree to sqrt(53)*1e-3 px
+    rows, cols = ep.pose_cells(pose, 1.0)
+    rrows, rcols = ep.pose_cells(ref_pose, 1.0)
+    rp = ref["prob"][0]
+    jj = np.arange(rp.shape[0])
+    assert ((rows >= 0) & (rows < rp.shape[1]) & (cols >= 0) & (cols < rp.shape[2])).all()
+    assert (rp[jj, rows, cols] >= rp.reshape(len(jj), -1).max(axis=1) - TOL).all()
+    assert np.allclose(pose[2], ref_pose[2], rtol=0, atol=TOL)
+    same = (rows == rrows) & (cols == rcols)
+    assert np.abs(pose[:, same] - ref_pose[:, same]).max(initial=0.0) <= 1e-2
 
 
 @pytest.mark.parametrize("fuse", [0, 2])

@@ -192,3 +192,42 @@ def test_float64_accumulation_mode_bounds_float32_noise():
     finally:
         O.set_double_acc(False)
     assert 0 < np.abs(y32 - y64).max() < 1e-4
+
+
+_MAGIC6 = np.array([[35, 1, 6, 26, 19, 24], [3, 32, 7, 21, 23, 25], [31, 9, 2, 22, 27, 20],
+                    [8, 28, 33, 17, 10, 15], [30, 5, 34, 12, 14, 16], [4, 36, 29, 13, 18, 11]], np.float32)
+
+
+def test_maxpool_rectangular_literals():
+    # src/caffe/test/test_pooling_layer.cpp:121-245 (TestForwardRectHigh: kernel_h 3, kernel_w 2, stride 1 on magic(6)) and
+    # :246-372 (TestForwardRectWide: kernel_h 2, kernel_w 3) — the literals the reference holds for its pooling loop
+    x = np.tile(_MAGIC6, (2, 2, 1, 1))
+    high = O.maxpool_forward(x, (3, 2), 1)
+    assert high.shape == (2, 2, 4, 5)
+    want_high = np.array([[35, 32, 26, 27, 27], [32, 33, 33, 27, 27], [31, 34, 34, 27, 27], [36, 36, 34, 18, 18]], np.float32)
+    wide = O.maxpool_forward(x, (2, 3), 1)
+    assert wide.shape == (2, 2, 5, 4)
+    want_wide = np.array([[35, 32, 26, 26], [32, 32, 27, 27], [33, 33, 33, 27], [34, 34, 34, 17], [36, 36, 34, 18]], np.float32)
+    for n in range(2):
+        for c in range(2):
+            assert np.array_equal(high[n, c], want_high)
+            assert np.array_equal(wide[n, c], want_wide)
+
+
+def test_bias_broadcast_middle_and_channel():
+    # src/caffe/test/test_bias_layer.cpp:199-220 (TestForwardBroadcastMiddle): bottom 2x3x4x5 and a 3x4 bias at axis 1, both
+    # uniform in [1, 10]: top(n,c,h,w) = bottom(n,c,h,w) + bias(c,h) within 1e-5.  BiasLayer flattens that to
+    # outer 2 x bias_dim 12 x inner 5 (bias_layer.cpp:30-46,72-87) — the same loop the net's Scale(bias_term) layers run
+    # with bias_dim = C, inner = H*W, which is the second half of this test.
+    rs = np.random.RandomState(1701)
+    x = rs.uniform(1, 10, (2, 3, 4, 5)).astype(np.float32)
+    bias = rs.uniform(1, 10, (3, 4)).astype(np.float32)
+    y = O.scale_forward(x.reshape(2, 12, 1, 5), np.ones(12, np.float32), bias.reshape(12)).reshape(2, 3, 4, 5)
+    for n in range(2):
+        for c in range(3):
+            for h in range(4):
+                for w in range(5):
+                    assert abs(float(y[n, c, h, w]) - (float(x[n, c, h, w]) + float(bias[c, h]))) <= 1e-5
+    bc = rs.uniform(1, 10, 3).astype(np.float32)
+    y = O.scale_forward(x, np.ones(3, np.float32), bc)
+    assert np.abs(y - (x + bc.reshape(1, 3, 1, 1))).max() <= 1e-5
