@@ -61,10 +61,12 @@ def effective_cores():
 
 def cpu_baseline(proto_fn, layers, flops_full, full_hw):
     """The reference's CPU algorithm (oracle/: per-image im2col + SGEMM, unfused BatchNorm / Scale / ReLU /
-    Eltwise passes, NCHW fp32) timed on this host's cores on a bounded sample of the SAME workload:
-    whole 544x736 forwards on all cores until >= 10 s have elapsed, and one 240x320 forward on a single
-    thread (the reference's default BLAS, ATLAS, is single-threaded) scaled by FLOPs (the path's cost is
-    linear in H*W)."""
+    Eltwise passes, NCHW fp32) timed on this host's cores on a bounded sample of the SAME workload, `caffe time` style
+    (tools/caffe.cpp:302-388: one warm-up forward, then timed forwards, median and min):
+    whole 544x736 forwards on all cores (>= 10 forwards or 10 s, whichever comes first), then whole 544x736 forwards
+    on ONE thread — the reference's default BLAS, ATLAS, is single-threaded: this is the denominator of the
+    north-star's ">= 50x" — (>= 3 forwards, up to 10 or 15 s).  Both are measured on the configuration itself; nothing is
+    extrapolated from a smaller image."""
     import numpy as np
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -72,35 +74,34 @@ def cpu_baseline(proto_fn, layers, flops_full, full_hw):
 
     threads = max(1, effective_cores())
     h, w = full_hw
-    O.set_threads(threads)
     net = O.OracleNet(proto_fn(h, w), layers)
     img = (np.random.RandomState(0).randn(1, 3, h, w) * 50).astype(np.float32)
-    n, t0 = 0, time.time()
-    while True:
-        net.forward(data=img)
-        n += 1
-        dt_all = time.time() - t0
-        if dt_all >= 10.0 or n >= 50:
-            break
-    O.set_threads(1)
-    h1, w1 = 240, 320
-    net1 = O.OracleNet(proto_fn(h1, w1), layers)
-    img1 = (np.random.RandomState(0).randn(1, 3, h1, w1) * 50).astype(np.float32)
-    t0 = time.time()
-    net1.forward(data=img1)
-    dt_one = time.time() - t0
-    fl1 = flops_full * (h1 * w1) / float(h * w)
+
+    def timed(nthreads, min_n, max_n, budget):
+        O.set_threads(nthreads)
+        net.forward(data=img)  # warm-up (page faults of the blob dict, OpenMP team start-up)
+        ts, t_start = [], time.time()
+        while len(ts) < max_n and (len(ts) < min_n or time.time() - t_start < budget):
+            t0 = time.time()
+            net.forward(data=img)
+            ts.append(time.time() - t0)
+        return ts
+
+    ts_all = timed(threads, 3, 50, 10.0)
+    ts_one = timed(1, 3, 10, 15.0)
+    med_all, med_one = sorted(ts_all)[len(ts_all) // 2], sorted(ts_one)[len(ts_one) // 2]
     return {
-        "value": n / dt_all,
+        "value": 1.0 / med_all,
         "unit": "images/s",
         "cores": threads,
         "kind": "port",
-        "sample": "oracle (C restatement of Caffe's im2col+SGEMM CPU path, OpenMP) on %d whole 1x3x%dx%d forward(s), "
-                  "%.1f s, %.1f GFLOP/s on %d threads (= the cgroup CPU quota of this box; %d hardware threads visible)"
-                  % (n, h, w, dt_all, n * flops_full / dt_all / 1e9, threads, os.cpu_count() or 0),
-        "single_thread_value": (fl1 / dt_one) / flops_full,
-        "single_thread_sample": "same code, 1 thread, one 1x3x%dx%d forward (%.1f GFLOP) in %.1f s = %.1f GFLOP/s, "
-                                "scaled by FLOPs to the 544x736 image" % (h1, w1, fl1 / 1e9, dt_one, fl1 / dt_one / 1e9),
+        "sample": "oracle (C restatement of Caffe's im2col+SGEMM CPU path, OpenMP) on %d whole 1x3x%dx%d forward(s) after one warm-up, "
+                  "median %.3f s (min %.3f s), %.1f GFLOP/s on %d threads (= the cgroup CPU quota of this box; %d hardware threads visible)"
+                  % (len(ts_all), h, w, med_all, min(ts_all), flops_full / med_all / 1e9, threads, os.cpu_count() or 0),
+        "single_thread_value": 1.0 / med_one,
+        "single_thread_sample": "same code, 1 thread, %d whole 1x3x%dx%d forward(s) after one warm-up: median %.2f s (min %.2f s) = %.1f GFLOP/s "
+                                "(measured on the configuration, not scaled from a smaller image)"
+                                % (len(ts_one), h, w, med_one, min(ts_one), flops_full / med_one / 1e9),
     }
 
 

@@ -1,0 +1,480 @@
+// pair_kernel.hip — two layers of consecutive bottleneck blocks as ONE launch (float16 operands, round 5):
+//
+//     Y = relu( (B · W2cᵀ) ∘ a1 + b1 + S )        res<i>_branch2c + BatchNorm + Scale, + shortcut, ReLU    (1x1, WD -> 4·WD)
+//     Z = relu( (Y · W2aᵀ) ∘ a2 + b2 )            res<i+1>_branch2a + BatchNorm + Scale + ReLU             (1x1, 4·WD -> WD)
+//
+// B is the output of branch2b (M pixels x WD channels, dense NHWC rows), S the block's input (M x 4·WD), Y the block's output —
+// stored, the next block's shortcut needs it — and Z the next block's branch2a output.  The reference runs them as two SGEMMs
+// per image with BatchNorm / Scale / Eltwise / ReLU passes in between (src/caffe/layers/base_conv_layer.cpp:326-341,
+// batch_norm_layer.cpp:86-149, scale_layer.cpp:109-134, eltwise_layer.cpp:59-65, relu_layer.cpp:15-18); rounds 1-4 as two
+// gather-GEMM launches, the second re-reading the 4·WD-wide Y (25.6 MB per res4 block at float16 batch 8) that the first had
+// just written.
+//
+// Here Y never comes back from memory.  A wave owns 32 pixels.  The 4·WD intermediate channels are walked in CHUNKS of 64:
+//   GEMM 1 (swapped operands: filters are the MFMA's row operand)  Sacc[64 ch x 32 px] = W2c[chunk] · Bᵀ      K = WD
+//   epilogue 1   affine, + shortcut, ReLU, round to float16; the chunk of Y is stored; the SAME registers, packed, ...
+//   GEMM 2       Zacc[WD ch x 32 px] += W2a[:, chunk] · Y[chunk]ᵀ                                                K = 64
+// ... are GEMM 2's column operand: with the filters as the row operand a lane's 16 accumulators are 16 CHANNELS of one pixel,
+// which is exactly the shape of v_mfma_f32_32x32x16_f16's B operand (8 K-values of one column per lane) up to a permutation of
+// K — and K is a summation index, so the permutation is applied to W2a's K order ON THE HOST when the filter image is packed
+// (pair_pack_filters).  No LDS round trip, no cross-lane traffic for the intermediate.  Resident per wave: its 32 rows of B as
+// MFMA operands (WD/4 registers), Zacc (WD/2 registers); streamed through LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave
+// instruction): the filter chunks, pre-swizzled on the host into the exact LDS image (so the requests are linear), in a ring of
+// three stages, and the shortcut chunk (128 px x 128 B, double buffered).
+//
+// One workgroup = 4 waves = 128 pixels (one wave per SIMD: the kernel needs ~330 registers).  A launch may cover several
+// tensors (the scales of a pyramid): PairArgs::prob[].
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace dc {
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf16x2 __attribute__((ext_vector_type(2)));
+typedef int pi32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kPairOOB = 0x80000000u;  // beyond any buffer: loads return 0, LDS-DMA writes 0, stores are dropped
+
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ pi32x4 pair_rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  return pi32x4{(int)(unsigned)a, (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+// LDS-DMA: 64 lanes x 16 bytes from global memory straight into LDS at M0 + 16*lane.  Inline asm: through the builtin the
+// compiler would make every later ds_read wait for vmcnt(0); the kernel counts vmcnt itself (kernels.hip, dc_dma16).
+__device__ __forceinline__ void pair_dma16(pi32x4 rs, unsigned lds, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff)
+               : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void pair_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// nothing is scheduled across: inline asm orders memory operations only, and the MFMAs of one period would otherwise drift into
+// the next one's region (where the pipeline described by its sched_group_barriers counts them as its own)
+#define PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Geometry of the filter image (shared by the kernel and the host packer).  Stage 2c holds chunk c of W2c: 64 rows (the chunk's
+// channels) of WD halves; stage 2c+1 holds chunk c of W2a: WD rows (output channels) of 64 halves in the permuted K order.
+// 16-byte pieces of a row are XOR-swizzled so that the 16 lanes a ds_read_b128 serves together hit 16 distinct bank groups.
+__host__ __device__ constexpr int pair_stage_bytes(int WD) { return 128 * WD; }
+__host__ __device__ inline int pair_w1_off(int WD, int row, int q) {  // byte offset inside a W2c stage: row 0..63, 16-byte piece q of WD/8
+  return row * WD * 2 + ((q & ~15) | ((q & 15) ^ (row & 15))) * 16;
+}
+__host__ __device__ inline int pair_w2_off(int row, int q) {  // inside a W2a stage: row 0..WD-1 of 128 bytes, piece q of 8
+  return row * 128 + (q ^ ((row >> 1) & 7)) * 16;
+}
+// the channel (within the chunk) that sits in K slot t (0..7) of lane half h in GEMM 2's step s4 (0..3): accumulator register
+// i = 8*(s4&1) + t of fragment f = s4 >> 1 is channel 32f + 8*(i>>2) + 4h + (i&3)   (C layout of the 32x32 MFMAs)
+__host__ __device__ inline int pair_chan(int s4, int h, int t) {
+  const int i = 8 * (s4 & 1) + t;
+  return 32 * (s4 >> 1) + 8 * (i >> 2) + 4 * h + (i & 3);
+}
+
+// sched_group_barrier masks (the machine scheduler builds the pipeline described by a sequence of them inside one region)
+#define PAIR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int kSgbVALU = 0x002, kSgbMFMA = 0x008, kSgbVMEMW = 0x040, kSgbDSR = 0x100;
+
+// ORDER OF WORK.  With one wave per SIMD the wave issues in order, so everything that is not an MFMA has to sit in the shadow of
+// one (a v_mfma_f32_32x32x16_f16 occupies the pipe for 32 cycles: ~5 other instructions fit).  The first layer's epilogue is ~160
+// VALU instructions per chunk, so it is skewed by one chunk and interleaved with the SECOND layer's MFMAs of the chunk before:
+//     t = 0          GEMM 1 (chunk 0), epilogue 1 (0)                                    [prologue, not overlapped]
+//     t = 2c + 1     GEMM 1 (chunk c+1)                        reads filter stage W2c[c+1]
+//     t = 2c + 2     GEMM 2 (chunk c)  ||  epilogue 1 (c+1)    reads filter stage W2a[c] and shortcut chunk c+1; stores Y chunk c+1
+//     t = 2*NCH - 1  GEMM 2 (chunk NCH-1)
+// The filter image holds the stages in exactly this order of consumption; stage t sits in ring slot t mod 3 and is requested two
+// periods ahead (at the top of period t-2, right behind the barrier that says every wave is done with the slot's previous tenant).
+template <int WD, bool DBG = false>
+__global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
+  constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 4096, KS1 = WD / 16, G2 = WD / 32;
+  constexpr int RING = 0, SC = 3 * SB, CONSTS = SC + 2 * 16384, CONSTS2 = CONSTS + NC * 8;
+  constexpr int NY = 8;   // stores of Y per lane and chunk
+  constexpr int LA = 6;   // filter fragments read ahead of the MFMA that uses them
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int px = lane & 31, h = lane >> 5;
+  // DBG: shader-clock stamps of wave 0 of every workgroup -> ka.dbg[block][slot] (tools/probes/pair_probe --stamps)
+  int dbg_n = 0;
+  auto stamp = [&]() {
+    if constexpr (DBG) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (wave == 0 && lane == 0 && dbg_n < 256) ka.dbg[(size_t)blockIdx.x * 256 + dbg_n] = (long long)t;
+      ++dbg_n;
+    }
+  };
+
+  // which tensor, which 128-pixel tile
+  int k = 0;
+  const int tile = blockIdx.x;
+  for (int i = 1; i < kMaxPairProblems; ++i)
+    if (i < ka.nprob && tile >= ka.prob[i].tile0) k = i;
+  const PairProblem pr = ka.prob[k];
+  const int m0 = (tile - pr.tile0) * 128;
+  const int M = pr.M;
+  const int row = m0 + wave * 32 + px;
+
+  // ---- epilogue constants -> LDS (a1[NC], b1[NC]; a2[WD], b2[WD]); this wave's 32 rows of B -> registers
+  {
+    const pf32x4* src = reinterpret_cast<const pf32x4*>(ka.ab1);
+    pf32x4* dst = reinterpret_cast<pf32x4*>(lds + CONSTS);
+    for (int i = threadIdx.x; i < 2 * NC / 4; i += 256) dst[i] = src[i];
+    const pf32x4* src2 = reinterpret_cast<const pf32x4*>(ka.ab2);
+    pf32x4* dst2 = reinterpret_cast<pf32x4*>(lds + CONSTS2);
+    for (int i = threadIdx.x; i < 2 * WD / 4; i += 256) dst2[i] = src2[i];
+  }
+  pf16x8 breg[KS1];
+  {
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pr.b), 0, (unsigned)M * WD * 2, 0x00020000);
+    const unsigned vo = (unsigned)row * (WD * 2) + h * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      breg[ks] = __builtin_bit_cast(pf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, row < M ? vo + ks * 32 : kPairOOB, 0, 0));
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" ::"v"(breg[ks]));  // the compiler's own vmcnt waits happen HERE, not in the loop
+  }
+  pair_wait_vm<0>();
+  __syncthreads();
+
+  // ---- LDS-DMA requests
+  const pi32x4 rw = pair_rsrc_words(ka.w, (unsigned)(2 * NCH) * SB);
+  const pi32x4 rs = pair_rsrc_words(pr.s, (unsigned)M * NC * 2);
+  const unsigned lane16 = lane * 16;
+  unsigned sc_vo[4];  // this wave's four shortcut requests: rows 32*wave + 8i + lane/8, piece (lane%8) ^ swizzle(row)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = 32 * wave + 8 * i + (lane >> 3);
+    const int piece = (lane & 7) ^ ((rl >> 1) & 7);
+    sc_vo[i] = (m0 + rl < M) ? (unsigned)(m0 + rl) * (NC * 2) + piece * 16 : kPairOOB;
+  }
+  // stage image `stage` -> ring slot `slot`: piece i of this wave's NWI (of the workgroup's 4*NWI) requests
+  auto dma_w_piece = [&](int stage, int slot, int i) {
+    const unsigned piece = (unsigned)(wave + 4 * i) * 1024u;
+    pair_dma16(rw, RING + slot * SB + piece, stage < 2 * NCH ? lane16 : kPairOOB, (unsigned)stage * SB + piece);
+  };
+  auto dma_w = [&](int stage, int slot) {
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) dma_w_piece(stage, slot, i);
+  };
+  // shortcut chunk c (64 channels = 128 bytes of every pixel row) -> buffer c & 1: piece i of this wave's four (its own rows)
+  auto dma_sc_piece = [&](int c, int i) {
+    pair_dma16(rs, SC + (c & 1) * 16384 + (32 * wave + 8 * i) * 128, c < NCH ? sc_vo[i] : kPairOOB, (unsigned)c * 128u);
+  };
+  auto dma_sc = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_sc_piece(c, i);
+  };
+
+  // ---- per-lane LDS read offsets
+  unsigned off1[8];  // W2c stage: row px (+32f), piece 2*ks + h: the eight values of (piece & 15) this lane ever needs
+#pragma unroll
+  for (int e = 0; e < 8; ++e) off1[e] = pair_w1_off(WD, px, 2 * e + h);
+  unsigned off2[4];  // W2a stage: row px (+32g), piece 2*s4 + h
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) off2[s4] = pair_w2_off(px, 2 * s4 + h);
+  const int rl_own = 32 * wave + px;
+  unsigned offs[8];  // shortcut buffer: own row, piece 4f + j, this lane half's 8 bytes of it (channels 4h .. 4h+3 of the piece's 8)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) offs[q] = rl_own * 128 + ((q ^ ((rl_own >> 1) & 7)) * 16) + h * 8;
+
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(pr.y, 0, (unsigned)M * NC * 2, 0x00020000);
+  const unsigned y_vo = row < M ? (unsigned)row * (NC * 2) + h * 8 : kPairOOB;
+
+  pf32x16 zacc[G2];
+#pragma unroll
+  for (int g = 0; g < G2; ++g)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zacc[g][i] = 0.f;
+  pf32x16 sacc[2];
+  unsigned xr[4][4];  // the chunk of Y GEMM 2 is about to consume, packed float16 pairs: [step s4][dword]
+
+  // GEMM 1 of one chunk from ring slot `slot` -> sacc.  One step = one MFMA, pinned by a sched_barrier: the fragment read LA
+  // steps ahead, the MFMA, and every few steps one LDS-DMA request of the stage that will be needed two periods later (issued
+  // in one block at the top of the period the requests stalled the wave for ~100 cycles each with the matrix pipe idle).
+  auto gemm1 = [&](int slot, auto&& piece, auto np_tag) {
+    constexpr int NM = 2 * KS1, NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
+    const unsigned char* st = lds + RING + slot * SB;
+    pf16x8 wf[NM];
+#pragma unroll
+    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + off1[(n >> 1) & 7] + (n >> 4) * 256 + (n & 1) * 32 * WD * 2);
+    PAIR_FENCE();
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      if (n + LA < NM) {
+        const int m = n + LA;
+        wf[m] = *reinterpret_cast<const pf16x8*>(st + off1[(m >> 1) & 7] + (m >> 4) * 256 + (m & 1) * 32 * WD * 2);
+      }
+      if (n < 2) {
+        pf32x16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+        sacc[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n >> 1], zero, 0, 0, 0);
+      } else {
+        sacc[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n >> 1], sacc[n & 1], 0, 0, 0);
+      }
+      if (NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
+      PAIR_FENCE();
+    }
+  };
+  // epilogue 1 of chunk c in parts p = 4f + j (4 channels of this lane's pixel each): affine + shortcut + ReLU, rounded to
+  // float16, stored, and left in xn (the next GEMM 2's operand).  Split into the pieces the pipeline below places one by one:
+  pf16x4 e_s8[2];
+  pf32x4 e_a4[2], e_b4[2];
+  float e_v[4];
+  auto epi_load = [&](int c, int p) {  // the part's shortcut values and constants: LDS -> registers (issued one part ahead)
+    const unsigned char* sb = lds + SC + (c & 1) * 16384;
+    const unsigned char* cb = lds + CONSTS + (c * 64 + 4 * h) * 4;
+    const int f = p >> 2, j = p & 3;
+    e_s8[p & 1] = *reinterpret_cast<const pf16x4*>(sb + offs[p]);
+    e_a4[p & 1] = *reinterpret_cast<const pf32x4*>(cb + (32 * f + 8 * j) * 4);
+    e_b4[p & 1] = *reinterpret_cast<const pf32x4*>(cb + NC * 4 + (32 * f + 8 * j) * 4);
+  };
+  auto epi_calc = [&](int p, int half) {  // two of the part's four values
+    const int f = p >> 2, j = p & 3;
+#pragma unroll
+    for (int r = 2 * half; r < 2 * half + 2; ++r) {
+      const float sh = (float)e_s8[p & 1][r];
+      e_v[r] = fmaxf(sacc[f][4 * j + r] * e_a4[p & 1][r] + e_b4[p & 1][r] + sh, 0.f);
+    }
+  };
+  auto epi_store = [&](int c, int p, unsigned (&xn)[4][4]) {
+    const int f = p >> 2, j = p & 3;
+    const pf16x2 lo = {(_Float16)e_v[0], (_Float16)e_v[1]}, hi = {(_Float16)e_v[2], (_Float16)e_v[3]};
+    const unsigned ulo = __builtin_bit_cast(unsigned, lo), uhi = __builtin_bit_cast(unsigned, hi);
+    // register i = 4j + r of fragment f  ->  step s4 = 2f + (j >> 1), slots t = 4*(j&1) + r
+    xn[2 * f + (j >> 1)][2 * (j & 1)] = ulo;
+    xn[2 * f + (j >> 1)][2 * (j & 1) + 1] = uhi;
+    __builtin_amdgcn_raw_buffer_store_b64(pu32x2{ulo, uhi}, ry, y_vo + (c * 64 + 32 * f + 8 * j) * 2, 0, 0);
+  };
+  // GEMM 2 of one chunk (operand xr) from ring slot `slot`; EPI: epilogue 1 of chunk cn rides in the MFMAs' shadow -> xn.
+  // One step = one MFMA: the fragment read LA steps ahead, the MFMA, one piece of the epilogue; a sched_barrier pins each step
+  // (left alone, the scheduler serialises read -> wait -> MFMA and parks the epilogue in one block behind the MFMAs).
+  auto gemm2 = [&](int slot, auto epi_tag, int cn, unsigned (&xn)[4][4], auto&& piece, auto np_tag) {
+    constexpr bool EPI = decltype(epi_tag)::value;
+    constexpr int NM = 4 * G2, SP = NM / 8;  // MFMAs; steps per epilogue part
+    constexpr int NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
+    const unsigned char* st = lds + RING + slot * SB;
+    pf16x8 wf[NM];
+    pf16x8 xop[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xop[s4] = __builtin_bit_cast(pf16x8, pu32x4{xr[s4][0], xr[s4][1], xr[s4][2], xr[s4][3]});
+#pragma unroll
+    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + off2[n / G2] + (n % G2) * 32 * 128);
+    if constexpr (EPI) epi_load(cn, 0);
+    PAIR_FENCE();
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      if (n + LA < NM) wf[n + LA] = *reinterpret_cast<const pf16x8*>(st + off2[(n + LA) / G2] + ((n + LA) % G2) * 32 * 128);
+      zacc[n % G2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], xop[n / G2], zacc[n % G2], 0, 0, 0);
+      if constexpr (EPI) {
+        const int p = n / SP, q = n % SP;
+        if (SP == 4) {
+          if (q == 0 && p + 1 < 8) epi_load(cn, p + 1);
+          if (q == 1) epi_calc(p, 0);
+          if (q == 2) epi_calc(p, 1);
+          if (q == 3) epi_store(cn, p, xn);
+        } else {
+          if (q == 0) {
+            if (p + 1 < 8) epi_load(cn, p + 1);
+            epi_calc(p, 0);
+          } else {
+            epi_calc(p, 1);
+            epi_store(cn, p, xn);
+          }
+        }
+      }
+      if (NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
+      PAIR_FENCE();
+    }
+  };
+  using TagT = std::true_type;
+  using TagF = std::false_type;
+
+  stamp();
+  dma_w(0, 0);
+  dma_sc(0);
+  dma_w(1, 1);
+  dma_sc(1);
+  // ================= t = 0: GEMM 1 and epilogue 1 of chunk 0
+  PAIR_FENCE();
+  using NP0 = std::integral_constant<int, 0>;
+  using NP1 = std::integral_constant<int, NWI>;
+  using NP2 = std::integral_constant<int, NWI + 4>;
+  pair_wait_vm<NWI + 4>();  // younger than W(0), SC(0): W(1), SC(1)
+  pair_barrier();
+  PAIR_FENCE();
+  gemm1(0, [&](int i) { dma_w_piece(2, 2, i); }, NP1{});
+  PAIR_FENCE();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    epi_load(0, p);
+    epi_calc(p, 0);
+    epi_calc(p, 1);
+    epi_store(0, p, xr);
+  }
+  PAIR_FENCE();
+  int slot = 1;  // ring slot of stage t = 2c + 1
+  for (int c = 0; c < NCH - 1; ++c) {
+    const int slot1 = slot + 1 >= 3 ? slot - 2 : slot + 1;  // stage 2c+2
+    const int slot2 = slot1 + 1 >= 3 ? slot1 - 2 : slot1 + 1;  // stage 2c+3 (= the slot stage 2c sat in)
+    // ================= t = 2c+1: GEMM 1 of chunk c+1
+    PAIR_FENCE();
+    stamp();
+    pair_wait_vm<NWI + 4 + NY>();  // younger than W(t): the shortcut chunk and the stage requested since, the stores of chunk c
+    stamp();
+    pair_barrier();
+    stamp();
+    PAIR_FENCE();
+    gemm1(slot, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
+    PAIR_FENCE();
+    // ================= t = 2c+2: GEMM 2 of chunk c || epilogue 1 of chunk c+1
+    stamp();
+    pair_wait_vm<NWI>();  // younger than W(t) and the shortcut chunk c+1: stage t+1 (and, older, the stores of chunk c: waited for too)
+    stamp();
+    pair_barrier();
+    stamp();
+    PAIR_FENCE();
+    unsigned xn[4][4];
+    gemm2(slot1, TagT{}, c + 1, xn, [&](int i) {
+      if (i < NWI) dma_w_piece(2 * c + 4, slot, i);
+      else dma_sc_piece(c + 2, i - NWI);
+    }, NP2{});
+    PAIR_FENCE();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xr[a][b] = xn[a][b];
+    slot = slot2;
+  }
+  // ================= t = 2*NCH - 1: GEMM 2 of the last chunk
+  PAIR_FENCE();
+  pair_wait_vm<NWI + 4 + NY>();
+  pair_barrier();
+  PAIR_FENCE();
+  {
+    unsigned xn[4][4];
+    gemm2(slot, TagF{}, 0, xn, [](int) {}, NP0{});
+  }
+  PAIR_FENCE();
+  stamp();
+  pair_wait_vm<0>();  // the out-of-range tail requests (they write zeros into free slots) must not outlive the workgroup's LDS
+
+  // ---- epilogue 2: Z = relu(Zacc * a2 + b2), float16
+  {
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(pr.z, 0, (unsigned)M * WD * 2, 0x00020000);
+    const unsigned z_vo = row < M ? (unsigned)row * (WD * 2) + h * 8 : kPairOOB;
+    const unsigned char* cb = lds + CONSTS2 + 4 * h * 4;
+#pragma unroll
+    for (int g = 0; g < G2; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const pf32x4 a4 = *reinterpret_cast<const pf32x4*>(cb + (32 * g + 8 * j) * 4);
+        const pf32x4 b4 = *reinterpret_cast<const pf32x4*>(cb + WD * 4 + (32 * g + 8 * j) * 4);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = zacc[g][4 * j + r] * a4[r] + b4[r];
+          if (ka.relu2) v[r] = fmaxf(v[r], 0.f);
+        }
+        const pf16x2 lo = {(_Float16)v[0], (_Float16)v[1]}, hi = {(_Float16)v[2], (_Float16)v[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(pu32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rz,
+                                              z_vo + (32 * g + 8 * j) * 2, 0, 0);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+bool pair_supported(int WD) { return WD == 128 || WD == 256; }
+size_t pair_packed_halves(int WD) { return (size_t)(4 * WD / 64) * 2 * pair_stage_bytes(WD) / 2; }
+size_t pair_lds_bytes(int WD) { return 3 * (size_t)pair_stage_bytes(WD) + 2 * 16384 + (size_t)4 * WD * 8 + (size_t)WD * 8; }
+
+static unsigned short pair_f2h(float f) {
+  const _Float16 hv = (_Float16)f;  // round to nearest even, as v_cvt_f16_f32
+  unsigned short u;
+  std::memcpy(&u, &hv, 2);
+  return u;
+}
+
+// w1: [4*WD][WD] (branch2c, K contiguous), w2: [WD][4*WD] (next branch2a), float (already carrying the per-row power-of-two
+// scaling of the float16 path) -> the stage images the kernel streams, as float16 bit patterns
+void pair_pack_filters(const float* w1, const float* w2, int WD, unsigned short* out) {
+  const int NC = 4 * WD, NCH = NC / 64, SB = pair_stage_bytes(WD);
+  // stage order = the kernel's order of consumption: W2c[0], then (W2c[c+1], W2a[c]) for c = 0 .. NCH-2, then W2a[NCH-1]
+  for (int c = 0; c < NCH; ++c) {
+    const int t1 = c == 0 ? 0 : 2 * c - 1, t2 = c == NCH - 1 ? 2 * NCH - 1 : 2 * c + 2;
+    unsigned short* s1 = out + (size_t)t1 * SB / 2;
+    for (int r = 0; r < 64; ++r)
+      for (int q = 0; q < WD / 8; ++q) {
+        unsigned short* d = s1 + pair_w1_off(WD, r, q) / 2;
+        for (int e = 0; e < 8; ++e) d[e] = pair_f2h(w1[(size_t)(64 * c + r) * WD + 8 * q + e]);
+      }
+    unsigned short* s2 = out + (size_t)t2 * SB / 2;
+    for (int r = 0; r < WD; ++r)
+      for (int q = 0; q < 8; ++q) {
+        unsigned short* d = s2 + pair_w2_off(r, q) / 2;
+        for (int t = 0; t < 8; ++t) d[t] = pair_f2h(w2[(size_t)r * NC + 64 * c + pair_chan(q >> 1, q & 1, t)]);
+      }
+  }
+}
+
+long pair_grid(PairArgs& a) {  // fills prob[].tile0; returns the number of workgroups
+  long t = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    a.prob[i].tile0 = (int)t;
+    t += (a.prob[i].M + 127) / 128;
+  }
+  return t;
+}
+
+int launch_pair_gemm(const PairArgs& a, long grid, void* stream) {
+  if (!pair_supported(a.WD) || a.nprob < 1 || a.nprob > kMaxPairProblems || grid <= 0) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < a.nprob; ++i)
+    if ((long)a.prob[i].M * 4 * a.WD * 2 >= (1L << 31)) return (int)hipErrorInvalidValue;  // 32-bit buffer offsets
+  const size_t ldsb = pair_lds_bytes(a.WD);
+  static bool attr_set[2] = {false, false};
+  hipError_t e = hipSuccess;
+  if (a.WD == 256) {
+    if (!attr_set[0]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) return (int)e;
+      attr_set[0] = true;
+    }
+    if (a.dbg) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((pair_gemm_kernel<256, true>), dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL(pair_gemm_kernel<256>, dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+    }
+  } else {
+    if (!attr_set[1]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) return (int)e;
+      attr_set[1] = true;
+    }
+    if (a.dbg) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((pair_gemm_kernel<128, true>), dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL(pair_gemm_kernel<128>, dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace dc

@@ -54,7 +54,8 @@ def test_resnet101_fp32_matches_oracle(gpu_caffe, synth101, hw):
         err = float(np.abs(out[k] - ref[k]).max())
         print(k, out[k].shape, "max abs err", err)
         assert err <= TOL, k
-    assert net.flops() < 0.75 * 46.24e9 * (h * w) / (240.0 * 320.0)  # 101 is ~2/3 of 152's arithmetic
+    full = gpu_caffe.Net(deepercut_prototxt(152, h, w), gpu_caffe.TEST, from_text=True).flops()  # host only: shapes
+    assert 0.6 * full < net.flops() < 0.8 * full  # 101 is ~0.7 of 152's arithmetic (33.0 of 46.2 GFLOP at 240x320)
 
 
 @pytest.mark.parametrize("fuse", [0, 2])
