@@ -30,7 +30,7 @@
 #include <cstring>
 #include <type_traits>
 
-#include "kernels.h"
+#include "pair_kernel.h"
 
 namespace dc {
 
@@ -61,9 +61,8 @@ __device__ __forceinline__ void pair_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// nothing is scheduled across: inline asm orders memory operations only, and the MFMAs of one period would otherwise drift into
-// the next one's region (where the pipeline described by its sched_group_barriers counts them as its own)
-#define PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
+// PAIR_FENCE (below): nothing is scheduled across it — inline asm orders memory operations only, and the MFMAs of one period
+// would otherwise drift into the next one
 
 // Geometry of the filter image (shared by the kernel and the host packer).  Stage 2c holds chunk c of W2c: 64 rows (the chunk's
 // channels) of WD halves; stage 2c+1 holds chunk c of W2a: WD rows (output channels) of 64 halves in the permuted K order.
@@ -82,29 +81,37 @@ __host__ __device__ inline int pair_chan(int s4, int h, int t) {
   return 32 * (s4 >> 1) + 8 * (i >> 2) + 4 * h + (i & 3);
 }
 
-// sched_group_barrier masks (the machine scheduler builds the pipeline described by a sequence of them inside one region)
-#define PAIR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-constexpr int kSgbVALU = 0x002, kSgbMFMA = 0x008, kSgbVMEMW = 0x040, kSgbDSR = 0x100;
-
-// ORDER OF WORK.  With one wave per SIMD the wave issues in order, so everything that is not an MFMA has to sit in the shadow of
-// one (a v_mfma_f32_32x32x16_f16 occupies the pipe for 32 cycles: ~5 other instructions fit).  The first layer's epilogue is ~160
-// VALU instructions per chunk, so it is skewed by one chunk and interleaved with the SECOND layer's MFMAs of the chunk before:
-//     t = 0          GEMM 1 (chunk 0), epilogue 1 (0)                                    [prologue, not overlapped]
-//     t = 2c + 1     GEMM 1 (chunk c+1)                        reads filter stage W2c[c+1]
-//     t = 2c + 2     GEMM 2 (chunk c)  ||  epilogue 1 (c+1)    reads filter stage W2a[c] and shortcut chunk c+1; stores Y chunk c+1
-//     t = 2*NCH - 1  GEMM 2 (chunk NCH-1)
-// The filter image holds the stages in exactly this order of consumption; stage t sits in ring slot t mod 3 and is requested two
-// periods ahead (at the top of period t-2, right behind the barrier that says every wave is done with the slot's previous tenant).
+// ORDER OF WORK.  Eight waves, two per SIMD: wave (pg, r) = pixel group pg (32 of the workgroup's 128 pixels) x role r.  The two
+// roles of a pixel group hold the same 32 rows of B and split the work of every chunk:
+//     GEMM 1      role r computes fragment r of the chunk (its 32 channels): WD/16 MFMAs
+//     epilogue 1  ... and finishes those 32 channels: affine + shortcut + ReLU, rounded to float16.  The values go back INTO the
+//                 shortcut buffer in place (Y has the shortcut's shape) and leave the workgroup one period later as whole 128-byte
+//                 rows (16-byte vectors, 8 lanes per row: the mirror image of the LDS-DMA that brought the shortcut), and they
+//                 stay in registers, packed, as two of GEMM 2's four K steps; the other two come from the partner through a
+//                 16 KB exchange buffer (written behind one barrier, read behind the next)
+//     GEMM 2      role r owns output channels [r*WD/2, (r+1)*WD/2): 4 K steps x WD/64 fragments
+// With one wave per SIMD (the first form of this kernel, EXPERIMENTS.md) every LDS-DMA request, store and epilogue instruction
+// stalled the matrix pipe: 4 600 cycles per chunk for 2 048 of MFMA.  Two waves per SIMD issue independently, so one wave's
+// memory and vector work hides under its partner's MFMAs — which needs <= 256 registers per wave, hence the split.
+// The first layer's epilogue is skewed by one chunk so that it runs beside the second layer's MFMAs of the chunk before:
+//     t = 0          GEMM 1 (chunk 0), epilogue 1 (0)
+//     t = 2c + 1     [X(c) -> exchange buffer; rows of Y(c) -> memory]  GEMM 1 (chunk c+1)         filter stage W2c[c+1]
+//     t = 2c + 2     [partner's half of X(c) <- exchange buffer]        GEMM 2 (c) || epilogue 1 (c+1)   stage W2a[c], shortcut c+1
+//     t = 2*NCH - 1  [X, Y of the last chunk]  t = 2*NCH: GEMM 2 (NCH-1)
+// The filter image holds the stages in this order of consumption; stage t sits in ring slot t mod 3 and is requested two
+// periods ahead, its requests spread over the MFMA steps of the period.  One s_barrier per period.
+#define PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <int WD, bool DBG = false>
-__global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
-  constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 4096, KS1 = WD / 16, G2 = WD / 32;
-  constexpr int RING = 0, SC = 3 * SB, CONSTS = SC + 2 * 16384, CONSTS2 = CONSTS + NC * 8;
-  constexpr int NY = 8;   // stores of Y per lane and chunk
-  constexpr int LA = 6;   // filter fragments read ahead of the MFMA that uses them
+__global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
+  constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 8192, KS1 = WD / 16, G2H = WD / 64;
+  constexpr int RING = 0, SC = 3 * SB, XB = SC + 2 * 16384, CONSTS = XB + 16384, CONSTS2 = CONSTS + NC * 8;
+  constexpr int LA = 4;   // filter fragments read ahead of the MFMA that uses them
+  constexpr int NVM = NWI + 2;  // what every period's wait leaves in flight: the youngest stage's requests + 2 (see the order below)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pg = wave & 3, role = wave >> 2;
   const int px = lane & 31, h = lane >> 5;
   // DBG: shader-clock stamps of wave 0 of every workgroup -> ka.dbg[block][slot] (tools/probes/pair_probe --stamps)
   int dbg_n = 0;
@@ -124,16 +131,16 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
   const PairProblem pr = ka.prob[k];
   const int m0 = (tile - pr.tile0) * 128;
   const int M = pr.M;
-  const int row = m0 + wave * 32 + px;
+  const int row = m0 + pg * 32 + px;
 
-  // ---- epilogue constants -> LDS (a1[NC], b1[NC]; a2[WD], b2[WD]); this wave's 32 rows of B -> registers
+  // ---- epilogue constants -> LDS (a1[NC], b1[NC]; a2[WD], b2[WD]); this pixel group's 32 rows of B -> registers
   {
     const pf32x4* src = reinterpret_cast<const pf32x4*>(ka.ab1);
     pf32x4* dst = reinterpret_cast<pf32x4*>(lds + CONSTS);
-    for (int i = threadIdx.x; i < 2 * NC / 4; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < 2 * NC / 4; i += 512) dst[i] = src[i];
     const pf32x4* src2 = reinterpret_cast<const pf32x4*>(ka.ab2);
     pf32x4* dst2 = reinterpret_cast<pf32x4*>(lds + CONSTS2);
-    for (int i = threadIdx.x; i < 2 * WD / 4; i += 256) dst2[i] = src2[i];
+    for (int i = threadIdx.x; i < 2 * WD / 4; i += 512) dst2[i] = src2[i];
   }
   pf16x8 breg[KS1];
   {
@@ -151,147 +158,156 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
   // ---- LDS-DMA requests
   const pi32x4 rw = pair_rsrc_words(ka.w, (unsigned)(2 * NCH) * SB);
   const pi32x4 rs = pair_rsrc_words(pr.s, (unsigned)M * NC * 2);
+  const pi32x4 ryw = pair_rsrc_words(pr.y, (unsigned)M * NC * 2);
   const unsigned lane16 = lane * 16;
-  unsigned sc_vo[4];  // this wave's four shortcut requests: rows 32*wave + 8i + lane/8, piece (lane%8) ^ swizzle(row)
+  // this wave's two row pieces of the workgroup's 128 x 128-byte shortcut / Y chunk: rows 32*pg + 16*role + 8i + lane/8, 16-byte
+  // piece (lane%8) ^ swizzle(row) — the same per-lane offsets serve the LDS-DMA of the shortcut and the stores of Y
+  unsigned sc_vo[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rl = 32 * wave + 8 * i + (lane >> 3);
+  for (int i = 0; i < 2; ++i) {
+    const int rl = 32 * pg + 16 * role + 8 * i + (lane >> 3);
     const int piece = (lane & 7) ^ ((rl >> 1) & 7);
     sc_vo[i] = (m0 + rl < M) ? (unsigned)(m0 + rl) * (NC * 2) + piece * 16 : kPairOOB;
   }
-  // stage image `stage` -> ring slot `slot`: piece i of this wave's NWI (of the workgroup's 4*NWI) requests
+  const unsigned sc_row0 = (32 * pg + 16 * role) * 128;
+  // stage image `stage` -> ring slot `slot`: piece i of this wave's NWI (of the workgroup's 8*NWI) requests
   auto dma_w_piece = [&](int stage, int slot, int i) {
-    const unsigned piece = (unsigned)(wave + 4 * i) * 1024u;
+    const unsigned piece = (unsigned)(wave + 8 * i) * 1024u;
     pair_dma16(rw, RING + slot * SB + piece, stage < 2 * NCH ? lane16 : kPairOOB, (unsigned)stage * SB + piece);
   };
   auto dma_w = [&](int stage, int slot) {
 #pragma unroll
     for (int i = 0; i < NWI; ++i) dma_w_piece(stage, slot, i);
   };
-  // shortcut chunk c (64 channels = 128 bytes of every pixel row) -> buffer c & 1: piece i of this wave's four (its own rows)
-  auto dma_sc_piece = [&](int c, int i) {
-    pair_dma16(rs, SC + (c & 1) * 16384 + (32 * wave + 8 * i) * 128, c < NCH ? sc_vo[i] : kPairOOB, (unsigned)c * 128u);
+  auto dma_sc_piece = [&](int c, int i) {  // shortcut chunk c (128 bytes of every pixel row) -> buffer c & 1
+    pair_dma16(rs, SC + (c & 1) * 16384 + sc_row0 + i * 1024, c < NCH ? sc_vo[i] : kPairOOB, (unsigned)c * 128u);
   };
   auto dma_sc = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_sc_piece(c, i);
+    dma_sc_piece(c, 0);
+    dma_sc_piece(c, 1);
+  };
+  // rows of Y chunk c (finished in place in the shortcut buffer by BOTH roles: call behind a barrier) -> memory, 16 bytes per lane
+  auto store_y = [&](int c) {
+    const unsigned char* sb = lds + SC + (c & 1) * 16384 + sc_row0 + lane16;
+    const pu32x4 v0 = *reinterpret_cast<const pu32x4*>(sb), v1 = *reinterpret_cast<const pu32x4*>(sb + 1024);
+    asm volatile("s_nop 0\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(v0), "v"(sc_vo[0]), "s"(ryw), "s"((unsigned)c * 128u) : "memory");
+    asm volatile("s_nop 0\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(v1), "v"(sc_vo[1]), "s"(ryw), "s"((unsigned)c * 128u) : "memory");
   };
 
-  // ---- per-lane LDS read offsets
-  unsigned off1[8];  // W2c stage: row px (+32f), piece 2*ks + h: the eight values of (piece & 15) this lane ever needs
+  // ---- per-lane LDS read offsets.  A swizzled piece index is (piece & ~15) | ((piece & 15) ^ key(row)), and piece = 2*step + h,
+  // so base ^ (step << 5) walks the steps (the XORed bits never reach the row part of the address)
+  const unsigned base1 = (unsigned)pair_w1_off(WD, px, h) + role * (32 * WD * 2);  // W2c stage: row 32*role + px
+  const unsigned base2 = (unsigned)pair_w2_off(px, h) + role * (G2H * 32 * 128);   // W2a stage: rows of this role's output channels
+  unsigned offs[4];  // shortcut buffer: own pixel row, 16-byte piece 4*role + j, this lane half's 8 bytes of it
+  {
+    const int rl_own = 32 * pg + px;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) off1[e] = pair_w1_off(WD, px, 2 * e + h);
-  unsigned off2[4];  // W2a stage: row px (+32g), piece 2*s4 + h
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) off2[s4] = pair_w2_off(px, 2 * s4 + h);
-  const int rl_own = 32 * wave + px;
-  unsigned offs[8];  // shortcut buffer: own row, piece 4f + j, this lane half's 8 bytes of it (channels 4h .. 4h+3 of the piece's 8)
-#pragma unroll
-  for (int q = 0; q < 8; ++q) offs[q] = rl_own * 128 + ((q ^ ((rl_own >> 1) & 7)) * 16) + h * 8;
+    for (int j = 0; j < 4; ++j) offs[j] = rl_own * 128 + (((4 * role + j) ^ ((rl_own >> 1) & 7)) * 16) + h * 8;
+  }
+  const unsigned xb_own = XB + ((pg * 2 + role) * 2) * 1024 + lane16, xb_other = XB + ((pg * 2 + (1 - role)) * 2) * 1024 + lane16;
 
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(pr.y, 0, (unsigned)M * NC * 2, 0x00020000);
-  const unsigned y_vo = row < M ? (unsigned)row * (NC * 2) + h * 8 : kPairOOB;
-
-  pf32x16 zacc[G2];
+  pf32x16 zacc[G2H];
 #pragma unroll
-  for (int g = 0; g < G2; ++g)
+  for (int g = 0; g < G2H; ++g)
 #pragma unroll
     for (int i = 0; i < 16; ++i) zacc[g][i] = 0.f;
-  pf32x16 sacc[2];
-  unsigned xr[4][4];  // the chunk of Y GEMM 2 is about to consume, packed float16 pairs: [step s4][dword]
+  pf32x16 sacc;
+  unsigned xown[2][4], xnext[2][4];  // this role's two K steps of the chunk GEMM 2 consumes next / of the chunk after it
 
-  // GEMM 1 of one chunk from ring slot `slot` -> sacc.  One step = one MFMA, pinned by a sched_barrier: the fragment read LA
-  // steps ahead, the MFMA, and every few steps one LDS-DMA request of the stage that will be needed two periods later (issued
-  // in one block at the top of the period the requests stalled the wave for ~100 cycles each with the matrix pipe idle).
+  // GEMM 1 of this role's fragment of one chunk from ring slot `slot` -> sacc.  One step = one MFMA, pinned by a sched_barrier:
+  // the fragment read LA steps ahead, the MFMA, and every few steps one piece of the period's memory work
   auto gemm1 = [&](int slot, auto&& piece, auto np_tag) {
-    constexpr int NM = 2 * KS1, NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
+    constexpr int NM = KS1, NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
     const unsigned char* st = lds + RING + slot * SB;
     pf16x8 wf[NM];
 #pragma unroll
-    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + off1[(n >> 1) & 7] + (n >> 4) * 256 + (n & 1) * 32 * WD * 2);
+    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((n & 7) << 5)) + (n >> 3) * 256);
     PAIR_FENCE();
 #pragma unroll
     for (int n = 0; n < NM; ++n) {
       if (n + LA < NM) {
         const int m = n + LA;
-        wf[m] = *reinterpret_cast<const pf16x8*>(st + off1[(m >> 1) & 7] + (m >> 4) * 256 + (m & 1) * 32 * WD * 2);
+        wf[m] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((m & 7) << 5)) + (m >> 3) * 256);
       }
-      if (n < 2) {
+      if (n == 0) {
         pf32x16 zero;
 #pragma unroll
         for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-        sacc[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n >> 1], zero, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n], zero, 0, 0, 0);
       } else {
-        sacc[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n >> 1], sacc[n & 1], 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n], sacc, 0, 0, 0);
       }
       if (NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
       PAIR_FENCE();
     }
   };
-  // epilogue 1 of chunk c in parts p = 4f + j (4 channels of this lane's pixel each): affine + shortcut + ReLU, rounded to
-  // float16, stored, and left in xn (the next GEMM 2's operand).  Split into the pieces the pipeline below places one by one:
+  // epilogue 1 of chunk c, this role's fragment, in parts j (4 channels of the lane's pixel each), split into the pieces the
+  // pipeline places one by one
   pf16x4 e_s8[2];
   pf32x4 e_a4[2], e_b4[2];
   float e_v[4];
-  auto epi_load = [&](int c, int p) {  // the part's shortcut values and constants: LDS -> registers (issued one part ahead)
+  auto epi_load = [&](int c, int j) {  // the part's shortcut values and constants: LDS -> registers (issued one part ahead)
     const unsigned char* sb = lds + SC + (c & 1) * 16384;
-    const unsigned char* cb = lds + CONSTS + (c * 64 + 4 * h) * 4;
-    const int f = p >> 2, j = p & 3;
-    e_s8[p & 1] = *reinterpret_cast<const pf16x4*>(sb + offs[p]);
-    e_a4[p & 1] = *reinterpret_cast<const pf32x4*>(cb + (32 * f + 8 * j) * 4);
-    e_b4[p & 1] = *reinterpret_cast<const pf32x4*>(cb + NC * 4 + (32 * f + 8 * j) * 4);
+    const unsigned char* cb = lds + CONSTS + (c * 64 + 32 * role + 4 * h) * 4;
+    e_s8[j & 1] = *reinterpret_cast<const pf16x4*>(sb + offs[j]);
+    e_a4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + 8 * j * 4);
+    e_b4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + NC * 4 + 8 * j * 4);
   };
-  auto epi_calc = [&](int p, int half) {  // two of the part's four values
-    const int f = p >> 2, j = p & 3;
+  auto epi_calc = [&](int j, int half) {  // two of the part's four values
 #pragma unroll
-    for (int r = 2 * half; r < 2 * half + 2; ++r) {
-      const float sh = (float)e_s8[p & 1][r];
-      e_v[r] = fmaxf(sacc[f][4 * j + r] * e_a4[p & 1][r] + e_b4[p & 1][r] + sh, 0.f);
-    }
+    for (int r = 2 * half; r < 2 * half + 2; ++r)
+      e_v[r] = fmaxf(sacc[4 * j + r] * e_a4[j & 1][r] + e_b4[j & 1][r] + (float)e_s8[j & 1][r], 0.f);
   };
-  auto epi_store = [&](int c, int p, unsigned (&xn)[4][4]) {
-    const int f = p >> 2, j = p & 3;
+  auto epi_store = [&](int c, int j, unsigned (&xn)[2][4]) {  // round, keep (GEMM 2's operand), put back into the shortcut buffer
     const pf16x2 lo = {(_Float16)e_v[0], (_Float16)e_v[1]}, hi = {(_Float16)e_v[2], (_Float16)e_v[3]};
     const unsigned ulo = __builtin_bit_cast(unsigned, lo), uhi = __builtin_bit_cast(unsigned, hi);
-    // register i = 4j + r of fragment f  ->  step s4 = 2f + (j >> 1), slots t = 4*(j&1) + r
-    xn[2 * f + (j >> 1)][2 * (j & 1)] = ulo;
-    xn[2 * f + (j >> 1)][2 * (j & 1) + 1] = uhi;
-    __builtin_amdgcn_raw_buffer_store_b64(pu32x2{ulo, uhi}, ry, y_vo + (c * 64 + 32 * f + 8 * j) * 2, 0, 0);
+    // accumulator register i = 4j + r  ->  K step (j >> 1) of this role's two, slots t = 4*(j&1) + r
+    xn[j >> 1][2 * (j & 1)] = ulo;
+    xn[j >> 1][2 * (j & 1) + 1] = uhi;
+    *reinterpret_cast<pu32x2*>(lds + SC + (c & 1) * 16384 + offs[j]) = pu32x2{ulo, uhi};
   };
-  // GEMM 2 of one chunk (operand xr) from ring slot `slot`; EPI: epilogue 1 of chunk cn rides in the MFMAs' shadow -> xn.
-  // One step = one MFMA: the fragment read LA steps ahead, the MFMA, one piece of the epilogue; a sched_barrier pins each step
-  // (left alone, the scheduler serialises read -> wait -> MFMA and parks the epilogue in one block behind the MFMAs).
-  auto gemm2 = [&](int slot, auto epi_tag, int cn, unsigned (&xn)[4][4], auto&& piece, auto np_tag) {
+  // GEMM 2 of one chunk from ring slot `slot`: K steps [own 0, own 1, partner 0, partner 1] x this role's G2H output fragments;
+  // EPI: epilogue 1 of chunk cn rides in the MFMAs' shadow -> xn
+  auto gemm2 = [&](int slot, const unsigned (&xo)[2][4], auto epi_tag, int cn, unsigned (&xn)[2][4], auto&& piece, auto np_tag) {
     constexpr bool EPI = decltype(epi_tag)::value;
-    constexpr int NM = 4 * G2, SP = NM / 8;  // MFMAs; steps per epilogue part
+    constexpr int NM = 4 * G2H;
     constexpr int NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
+    constexpr int SP = NM / 4;  // steps per epilogue part (4 or 2)
     const unsigned char* st = lds + RING + slot * SB;
-    pf16x8 wf[NM];
     pf16x8 xop[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) xop[s4] = __builtin_bit_cast(pf16x8, pu32x4{xr[s4][0], xr[s4][1], xr[s4][2], xr[s4][3]});
+    for (int q = 0; q < 2; ++q) {
+      xop[q] = __builtin_bit_cast(pf16x8, pu32x4{xown[q][0], xown[q][1], xown[q][2], xown[q][3]});
+      xop[2 + q] = __builtin_bit_cast(pf16x8, pu32x4{xo[q][0], xo[q][1], xo[q][2], xo[q][3]});
+    }
+    // step n: K step index q = n / G2H in the order above = chunk step s4 = 2*role + q (own) or 2*(1-role) + (q-2) (partner)
+    const unsigned s4x[4] = {(unsigned)(2 * role) << 5, (unsigned)(2 * role + 1) << 5, (unsigned)(2 * (1 - role)) << 5, (unsigned)(2 * (1 - role) + 1) << 5};
+    pf16x8 wf[NM];
 #pragma unroll
-    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + off2[n / G2] + (n % G2) * 32 * 128);
+    for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + (base2 ^ s4x[n / G2H]) + (n % G2H) * 32 * 128);
     if constexpr (EPI) epi_load(cn, 0);
     PAIR_FENCE();
 #pragma unroll
     for (int n = 0; n < NM; ++n) {
-      if (n + LA < NM) wf[n + LA] = *reinterpret_cast<const pf16x8*>(st + off2[(n + LA) / G2] + ((n + LA) % G2) * 32 * 128);
-      zacc[n % G2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], xop[n / G2], zacc[n % G2], 0, 0, 0);
+      if (n + LA < NM) {
+        const int m = n + LA;
+        wf[m] = *reinterpret_cast<const pf16x8*>(st + (base2 ^ s4x[m / G2H]) + (m % G2H) * 32 * 128);
+      }
+      zacc[n % G2H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], xop[n / G2H], zacc[n % G2H], 0, 0, 0);
       if constexpr (EPI) {
-        const int p = n / SP, q = n % SP;
+        const int j = n / SP, q = n % SP;
         if (SP == 4) {
-          if (q == 0 && p + 1 < 8) epi_load(cn, p + 1);
-          if (q == 1) epi_calc(p, 0);
-          if (q == 2) epi_calc(p, 1);
-          if (q == 3) epi_store(cn, p, xn);
+          if (q == 0 && j + 1 < 4) epi_load(cn, j + 1);
+          if (q == 1) epi_calc(j, 0);
+          if (q == 2) epi_calc(j, 1);
+          if (q == 3) epi_store(cn, j, xn);
         } else {
           if (q == 0) {
-            if (p + 1 < 8) epi_load(cn, p + 1);
-            epi_calc(p, 0);
+            if (j + 1 < 4) epi_load(cn, j + 1);
+            epi_calc(j, 0);
           } else {
-            epi_calc(p, 1);
-            epi_store(cn, p, xn);
+            epi_calc(j, 1);
+            epi_store(cn, j, xn);
           }
         }
       }
@@ -299,9 +315,24 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
       PAIR_FENCE();
     }
   };
+  auto put_x = [&]() {  // this role's half of the chunk -> exchange buffer (behind a barrier: the partner is done with the previous one)
+    *reinterpret_cast<pu32x4*>(lds + xb_own) = pu32x4{xown[0][0], xown[0][1], xown[0][2], xown[0][3]};
+    *reinterpret_cast<pu32x4*>(lds + xb_own + 1024) = pu32x4{xown[1][0], xown[1][1], xown[1][2], xown[1][3]};
+  };
+  auto get_x = [&](unsigned (&xo)[2][4]) {
+    const pu32x4 a0 = *reinterpret_cast<const pu32x4*>(lds + xb_other), a1 = *reinterpret_cast<const pu32x4*>(lds + xb_other + 1024);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xo[0][e] = a0[e], xo[1][e] = a1[e];
+  };
   using TagT = std::true_type;
   using TagF = std::false_type;
+  using NP0 = std::integral_constant<int, 0>;
+  using NP1 = std::integral_constant<int, NWI>;
+  using NP2 = std::integral_constant<int, NWI + 2>;
 
+  // Order of this wave's vector-memory operations (vmcnt retires in order; every wait below leaves NVM = NWI + 2 in flight):
+  //   W(0) SC(0) W(1) SC(1) | t=0: W(2) | t=1: Y(0)x2 W(3) | t=2: W(4) SC(2) | t=3: Y(1)x2 W(5) | t=4: W(6) SC(3) | ...
+  // period t needs stage W(t) (and, t even, the shortcut chunk requested with W(t)): everything younger is NWI + 2 operations.
   stamp();
   dma_w(0, 0);
   dma_sc(0);
@@ -309,75 +340,85 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
   dma_sc(1);
   // ================= t = 0: GEMM 1 and epilogue 1 of chunk 0
   PAIR_FENCE();
-  using NP0 = std::integral_constant<int, 0>;
-  using NP1 = std::integral_constant<int, NWI>;
-  using NP2 = std::integral_constant<int, NWI + 4>;
-  pair_wait_vm<NWI + 4>();  // younger than W(0), SC(0): W(1), SC(1)
+  pair_wait_vm<NVM>();
   pair_barrier();
   PAIR_FENCE();
   gemm1(0, [&](int i) { dma_w_piece(2, 2, i); }, NP1{});
   PAIR_FENCE();
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    epi_load(0, p);
-    epi_calc(p, 0);
-    epi_calc(p, 1);
-    epi_store(0, p, xr);
+  for (int j = 0; j < 4; ++j) {
+    epi_load(0, j);
+    epi_calc(j, 0);
+    epi_calc(j, 1);
+    epi_store(0, j, xown);
   }
   PAIR_FENCE();
   int slot = 1;  // ring slot of stage t = 2c + 1
   for (int c = 0; c < NCH - 1; ++c) {
     const int slot1 = slot + 1 >= 3 ? slot - 2 : slot + 1;  // stage 2c+2
     const int slot2 = slot1 + 1 >= 3 ? slot1 - 2 : slot1 + 1;  // stage 2c+3 (= the slot stage 2c sat in)
-    // ================= t = 2c+1: GEMM 1 of chunk c+1
+    // ================= t = 2c+1: X(c), Y(c) leave; GEMM 1 of chunk c+1
     PAIR_FENCE();
     stamp();
-    pair_wait_vm<NWI + 4 + NY>();  // younger than W(t): the shortcut chunk and the stage requested since, the stores of chunk c
+    pair_wait_vm<NVM>();
     stamp();
     pair_barrier();
     stamp();
+    PAIR_FENCE();
+    put_x();
+    store_y(c);
     PAIR_FENCE();
     gemm1(slot, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
     PAIR_FENCE();
     // ================= t = 2c+2: GEMM 2 of chunk c || epilogue 1 of chunk c+1
     stamp();
-    pair_wait_vm<NWI>();  // younger than W(t) and the shortcut chunk c+1: stage t+1 (and, older, the stores of chunk c: waited for too)
+    pair_wait_vm<NVM>();
     stamp();
     pair_barrier();
     stamp();
     PAIR_FENCE();
-    unsigned xn[4][4];
-    gemm2(slot1, TagT{}, c + 1, xn, [&](int i) {
+    unsigned xo[2][4];
+    get_x(xo);
+    PAIR_FENCE();
+    gemm2(slot1, xo, TagT{}, c + 1, xnext, [&](int i) {
       if (i < NWI) dma_w_piece(2 * c + 4, slot, i);
       else dma_sc_piece(c + 2, i - NWI);
     }, NP2{});
     PAIR_FENCE();
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) xr[a][b] = xn[a][b];
+      for (int e = 0; e < 4; ++e) xown[a][e] = xnext[a][e];
     slot = slot2;
   }
-  // ================= t = 2*NCH - 1: GEMM 2 of the last chunk
+  // ================= t = 2*NCH - 1: X, Y of the last chunk leave
   PAIR_FENCE();
-  pair_wait_vm<NWI + 4 + NY>();
+  pair_wait_vm<NVM>();
+  pair_barrier();
+  PAIR_FENCE();
+  put_x();
+  store_y(NCH - 1);
+  // ================= t = 2*NCH: GEMM 2 of the last chunk
+  PAIR_FENCE();
+  pair_wait_vm<0>();  // stage 2*NCH - 1 has been in flight for a whole period; nothing else is requested any more
   pair_barrier();
   PAIR_FENCE();
   {
-    unsigned xn[4][4];
-    gemm2(slot, TagF{}, 0, xn, [](int) {}, NP0{});
+    unsigned xo[2][4];
+    get_x(xo);
+    PAIR_FENCE();
+    gemm2(slot, xo, TagF{}, 0, xnext, [](int) {}, NP0{});
   }
   PAIR_FENCE();
   stamp();
-  pair_wait_vm<0>();  // the out-of-range tail requests (they write zeros into free slots) must not outlive the workgroup's LDS
 
-  // ---- epilogue 2: Z = relu(Zacc * a2 + b2), float16
+  // ---- epilogue 2: Z = relu(Zacc * a2 + b2), float16: this role's WD/2 output channels
   {
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(pr.z, 0, (unsigned)M * WD * 2, 0x00020000);
-    const unsigned z_vo = row < M ? (unsigned)row * (WD * 2) + h * 8 : kPairOOB;
-    const unsigned char* cb = lds + CONSTS2 + 4 * h * 4;
+    const unsigned z_vo = row < M ? (unsigned)row * (WD * 2) + (role * (WD / 2) + 4 * h) * 2 : kPairOOB;
+    const unsigned char* cb = lds + CONSTS2 + (role * (WD / 2) + 4 * h) * 4;
 #pragma unroll
-    for (int g = 0; g < G2; ++g)
+    for (int g = 0; g < G2H; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const pf32x4 a4 = *reinterpret_cast<const pf32x4*>(cb + (32 * g + 8 * j) * 4);
@@ -400,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const PairArgs ka) {
 // ---------------------------------------------------------------------------------------------------------------------
 bool pair_supported(int WD) { return WD == 128 || WD == 256; }
 size_t pair_packed_halves(int WD) { return (size_t)(4 * WD / 64) * 2 * pair_stage_bytes(WD) / 2; }
-size_t pair_lds_bytes(int WD) { return 3 * (size_t)pair_stage_bytes(WD) + 2 * 16384 + (size_t)4 * WD * 8 + (size_t)WD * 8; }
+size_t pair_lds_bytes(int WD) { return 3 * (size_t)pair_stage_bytes(WD) + 2 * 16384 + 16384 + (size_t)4 * WD * 8 + (size_t)WD * 8; }
 
 static unsigned short pair_f2h(float f) {
   const _Float16 hv = (_Float16)f;  // round to nearest even, as v_cvt_f16_f32
@@ -456,9 +497,9 @@ int launch_pair_gemm(const PairArgs& a, long grid, void* stream) {
     if (a.dbg) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL((pair_gemm_kernel<256, true>), dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((pair_gemm_kernel<256, true>), dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
     } else {
-      hipLaunchKernelGGL(pair_gemm_kernel<256>, dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(pair_gemm_kernel<256>, dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
     }
   } else {
     if (!attr_set[1]) {
@@ -469,9 +510,9 @@ int launch_pair_gemm(const PairArgs& a, long grid, void* stream) {
     if (a.dbg) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL((pair_gemm_kernel<128, true>), dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+      hipLaunchKernelGGL((pair_gemm_kernel<128, true>), dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
     } else {
-      hipLaunchKernelGGL(pair_gemm_kernel<128>, dim3((unsigned)grid), dim3(256), ldsb, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(pair_gemm_kernel<128>, dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
     }
   }
   return (int)hipGetLastError();

@@ -1,4 +1,4 @@
-// pair_probe — stand-alone check + timing of the bottleneck-pair kernel (deepcut-cnn_amd/csrc/pair_kernel.hip):
+// pair_probe — stand-alone check + timing of the bottleneck-pair kernel (tools/probes/pair_kernel.hip):
 // res<i>_branch2c + shortcut + ReLU -> res<i+1>_branch2a + ReLU as ONE launch, the 4*WD-wide intermediate fed to the second
 // GEMM from registers.  No Python, no torch: one GPU call checks ragged and multi-tensor cases and times the layer shapes.
 //
@@ -19,7 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "../../deepcut-cnn_amd/csrc/kernels.h"
+#include "pair_kernel.h"
 
 using namespace dc;
 
