@@ -101,6 +101,9 @@ __host__ __device__ inline int pair_chan(int s4, int h, int t) {
 // The filter image holds the stages in this order of consumption; stage t sits in ring slot t mod 3 and is requested two
 // periods ahead, its requests spread over the MFMA steps of the period.  One s_barrier per period.
 #define PAIR_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef PAIR_ABL  // diagnostic builds (WRONG results, timing only): bit 0 no in-loop LDS-DMA requests, 1 no epilogue beside GEMM 2,
+#define PAIR_ABL 0  // 2 no stores of Y, 3 no exchange of the intermediate, 4 no in-loop fragment reads (operands = whatever is in the registers)
+#endif
 template <int WD, bool DBG = false>
 __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 8192, KS1 = WD / 16, G2H = WD / 64;
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     for (int n = 0; n < NM; ++n) {
       if (n + LA < NM) {
         const int m = n + LA;
-        wf[m] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((m & 7) << 5)) + (m >> 3) * 256);
+        if (PAIR_ABL & 16) wf[m] = wf[m - LA];
+        else wf[m] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((m & 7) << 5)) + (m >> 3) * 256);
       }
       if (n == 0) {
         pf32x16 zero;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
       } else {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n], sacc, 0, 0, 0);
       }
-      if (NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
+      if (!(PAIR_ABL & 1) && NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
       PAIR_FENCE();
     }
   };
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   // GEMM 2 of one chunk from ring slot `slot`: K steps [own 0, own 1, partner 0, partner 1] x this role's G2H output fragments;
   // EPI: epilogue 1 of chunk cn rides in the MFMAs' shadow -> xn
   auto gemm2 = [&](int slot, const unsigned (&xo)[2][4], auto epi_tag, int cn, unsigned (&xn)[2][4], auto&& piece, auto np_tag) {
-    constexpr bool EPI = decltype(epi_tag)::value;
+    constexpr bool EPI = decltype(epi_tag)::value && !(PAIR_ABL & 2);
     constexpr int NM = 4 * G2H;
     constexpr int NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
     constexpr int SP = NM / 4;  // steps per epilogue part (4 or 2)
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     for (int n = 0; n < NM; ++n) {
       if (n + LA < NM) {
         const int m = n + LA;
-        wf[m] = *reinterpret_cast<const pf16x8*>(st + (base2 ^ s4x[m / G2H]) + (m % G2H) * 32 * 128);
+        if (PAIR_ABL & 16) wf[m] = wf[m - LA];
+        else wf[m] = *reinterpret_cast<const pf16x8*>(st + (base2 ^ s4x[m / G2H]) + (m % G2H) * 32 * 128);
       }
       zacc[n % G2H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], xop[n / G2H], zacc[n % G2H], 0, 0, 0);
       if constexpr (EPI) {
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
           }
         }
       }
-      if (NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
+      if (!(PAIR_ABL & 1) && NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
       PAIR_FENCE();
     }
   };
@@ -365,8 +370,8 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     pair_barrier();
     stamp();
     PAIR_FENCE();
-    put_x();
-    store_y(c);
+    if (!(PAIR_ABL & 8)) put_x();
+    if (!(PAIR_ABL & 4)) store_y(c);
     PAIR_FENCE();
     gemm1(slot, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
     PAIR_FENCE();
@@ -378,7 +383,10 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     stamp();
     PAIR_FENCE();
     unsigned xo[2][4];
-    get_x(xo);
+    if (!(PAIR_ABL & 8)) get_x(xo);
+    else
+      for (int a = 0; a < 2; ++a)
+        for (int e = 0; e < 4; ++e) xo[a][e] = xown[a][e];
     PAIR_FENCE();
     gemm2(slot1, xo, TagT{}, c + 1, xnext, [&](int i) {
       if (i < NWI) dma_w_piece(2 * c + 4, slot, i);

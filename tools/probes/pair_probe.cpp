@@ -62,7 +62,7 @@ static std::vector<int> parse_list(const std::string& s) {
 }
 
 // one case: `Ms` = the tensors of the launch (one problem each)
-static int g_stamps = 0;
+static int g_stamps = 0, g_nocheck = 0;
 static int run_case(int WD, const std::vector<int>& Ms, int reps, int check_rows, bool timing) {
   const int NC = 4 * WD;
   std::mt19937 rng(1234 + WD + (int)Ms.size());
@@ -188,6 +188,7 @@ static int run_case(int WD, const std::vector<int>& Ms, int reps, int check_rows
   for (int m : Ms) ms += (ms.empty() ? "" : "+") + std::to_string(m);
   std::printf("WD %3d  M %-28s grid %5ld  check: worst rel err Y %.2e Z %.2e  %s\n", WD, ms.c_str(), grid, worst_y, worst_z, bad ? "WRONG" : "ok");
 
+  if (g_nocheck) bad = 0;
   if (timing && !bad) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -223,6 +224,17 @@ static int run_case(int WD, const std::vector<int>& Ms, int reps, int check_rows
       // v[0] = start, then triples (before wait, after wait, after barrier) per period, last = end
       for (int i = 1; i + 3 < n; i += 3)
         std::printf(" %lld|%lld|%lld", v[i + 1] - v[i], v[i + 2] - v[i + 1], v[i + 3] - v[i + 2]);
+      // averages: periods alternate A (GEMM 1) and B (GEMM 2 || epilogue 1)
+      double sa[3] = {0, 0, 0}, sb[3] = {0, 0, 0};
+      int na = 0, nb = 0;
+      for (int i = 1, t = 0; i + 3 < n; i += 3, ++t) {
+        double* d = (t & 1) ? sb : sa;
+        d[0] += v[i + 1] - v[i], d[1] += v[i + 2] - v[i + 1], d[2] += v[i + 3] - v[i + 2];
+        (t & 1) ? ++nb : ++na;
+      }
+      if (na && nb)
+        std::printf("\n         average A period: wait %.0f barrier %.0f work %.0f | B period: wait %.0f barrier %.0f work %.0f | per chunk %.0f",
+                    sa[0] / na, sa[1] / na, sa[2] / na, sb[0] / nb, sb[1] / nb, sb[2] / nb, (sa[0] + sa[1] + sa[2]) / na + (sb[0] + sb[1] + sb[2]) / nb);
       std::printf("\n         prologue (start -> first stamped period): %lld\n", n > 1 ? v[1] - v[0] : 0);
     }
     CK(hipFree(d_dbg));
@@ -251,6 +263,7 @@ int main(int argc, char** argv) {
     else if (a == "--reps") reps = std::atoi(next().c_str());
     else if (a == "--check-rows") check_rows = std::atoi(next().c_str());
     else if (a == "--stamps") g_stamps = 1;
+    else if (a == "--no-check") g_nocheck = 1;
   }
   int bad = 0;
   for (int WD : {256, 128}) {
@@ -261,7 +274,7 @@ int main(int argc, char** argv) {
     bad += run_case(WD, {129}, 1, 16, false);
     bad += run_case(WD, {1000}, 1, 32, false);
     bad += run_case(WD, {391, 77, 128, 910}, 1, 32, false);
-    if (bad) {
+    if (bad && !g_nocheck) {
       std::printf("WRONG results: not timing\n");
       return 1;
     }
