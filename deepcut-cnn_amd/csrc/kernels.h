@@ -1,5 +1,5 @@
 // kernels.h — launch interface of the gfx950 kernels (kernels.hip).  Plain structs, no HIP types
-// in the signatures except the opaque stream, so net.cpp stays host-only C++.
+// in the signatures except the opaque stream, so the graph runtime (net_*.cpp) stays host-only C++.
 #pragma once
 #include <cstddef>
 #include <cstdint>

@@ -1,6 +1,6 @@
 """Tile selection under the caller's own load.
 
-`Net::autotune` (csrc/net.cpp) times every tile alone — and once more inside whole forward passes —, i.e. for
+`Net::autotune` (csrc/net_tune.cpp) times every tile alone — and once more inside whole forward passes —, i.e. for
 the latency of ONE forward.  A service that keeps several forwards in flight (deepcut_tools.Pipeline, bench.py's `value`) wants
 the tiles that maximise throughput under that load, and the two differ: a one-workgroup-per-CU tile that wins alone leaves the
 other forwards no room.  `tune_in_flight` is a coordinate descent on the real objective: for the busiest GEMM signatures, in
