@@ -10,8 +10,8 @@ by the RCCL gather of the three score maps to rank 0.  Two timed regions of exac
 run: one forward at a time (kernel durations for the roofline), then with `--streams` (default 4 at batch 1)
 independent batch-B forwards in flight on separate HIP streams — a batch-1 layer of this net fills
 only ~3/4 of the 256 CUs, the next request's kernels fill the rest; `value` is that throughput and the
-one-at-a-time figure is reported beside it.  The streams of the forwards in flight are the fastest subset of
-`--stream-candidates` (8) streams, measured untimed on the real forwards (`config.stream_choice`).  Workload at N=1 = BASELINE.json configs[1]:
+one-at-a-time figure is reported beside it.  The streams of the forwards in flight are the executors' own, chosen by the library
+(`dc_nets_choose_streams`: the real forwards timed on a pool of `--stream-candidates` streams; `config.stream_choice`).  Workload at N=1 = BASELINE.json configs[1]:
 batch=1, 1x3x544x736, fp32 (the shipped prototxt is ResNet-152 — SURVEY F1 — not the "ResNet-101"
 of the config string).  Weak scaling: every rank forwards its own image each step.
 Rank 0 prints ONE JSON line.
@@ -410,6 +410,7 @@ def main():
                     help="also measure cross-request batching (deepcut_tools.Pipeline, opportunistic): at most k batch-1 requests per batch forward (0/1: skip)")
     ap.add_argument("--no-f16-line", action="store_true", help="skip the configs[2] (fp16 pyramid) measurement printed beside the headline")
     ap.add_argument("--depth", type=int, default=152)
+    ap.add_argument("--no-resnet101", action="store_true", help="skip the ResNet-101 side figure (the depth BASELINE.json names)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="device element type: f32 (the headline, BASELINE configs[1]) or f16 operands with fp32 "
@@ -421,8 +422,8 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DC_BENCH_STREAMS", "0")),
                     help="independent batch-B forwards kept in flight per GPU (each on its own HIP stream and Net)")
     ap.add_argument("--stream-candidates", type=int, default=int(os.environ.get("DC_BENCH_STREAM_CANDIDATES", "8")),
-                    help="the streams of the forwards in flight are the fastest --streams-subset of this many candidates, by measurement "
-                         "(0: the first streams created)")
+                    help="the streams of the forwards in flight are chosen by the library (dc_nets_choose_streams) among this many "
+                         "process-wide candidates, by timing the forwards (0: streams created here, unmeasured)")
     ap.add_argument("--backend", default=os.environ.get("DC_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real thing) or gloo (lets two ranks share one "
                          "GPU to smoke-test the N>1 code path on a 1-GPU box)")
@@ -585,32 +586,18 @@ def main():
     # subset the first S streams of a process are depends on every stream created before them).  So, like the lanes of a group
     # (NetGroup::choose_lane_streams): candidates, the real forwards on every S-subset, the fastest subset stays.  Untimed.
     stream_choice = None
-    if S > 1 and args.stream_candidates > S:
-        import itertools
-
-        cands = list(streams) + [torch.cuda.Stream(dev) for _ in range(args.stream_candidates - S)]
-
-        def burst(sub):
-            for k, j in enumerate(sub):
-                streams[k] = cands[j]
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for i in range(6 * S):
-                forward_slot(i % S)
-            torch.cuda.synchronize(dev)
-            return time.perf_counter() - t0
-
-        rows = []
-        for sub in itertools.combinations(range(len(cands)), S):
-            burst(sub)
-            rows.append((min(burst(sub), burst(sub)), sub))
-        rows.sort()
-        first = [t for t, sub in rows if sub == tuple(range(S))][0]
-        for k, j in enumerate(rows[0][1]):
-            streams[k] = cands[j]
-        stream_choice = {"candidates": len(cands), "subsets_timed": len(rows), "chosen": list(rows[0][1]),
-                         "images_per_s_chosen": 6 * S * B / rows[0][0], "images_per_s_first_created": 6 * S * B / first,
-                         "images_per_s_worst": 6 * S * B / rows[-1][0]}
+    if S > 1 and args.stream_candidates > 0:
+        # the LIBRARY's choice (dc_nets_choose_streams, csrc/streams.cpp): the executors' real forwards timed on assignments of a
+        # process-wide pool of candidate streams (greedy, ~20 bursts); every executor adopts its stream as its own, and the bench
+        # drives exactly those streams.  Round 4 searched the 70 subsets here, in the bench: a caller of the library got luck.
+        for e in nets:
+            e.reserve(B, H, W)
+        stream_choice = caffe.choose_streams(nets, candidates=args.stream_candidates)
+        stream_choice = {"by": "dc_nets_choose_streams", "candidates": args.stream_candidates,
+                         "images_per_s_chosen": stream_choice["forwards_per_s_chosen"] * B,
+                         "images_per_s_first_created": stream_choice["forwards_per_s_first_created"] * B}
+        for k, e in enumerate(nets):
+            streams[k] = torch.cuda.ExternalStream(e.stream_handle(), device=dev)
     tuning = None
     if S > 1 and not args.no_tune_in_flight:
         from deepcut_tools import tune_in_flight
@@ -816,13 +803,104 @@ def main():
                     "batch_sizes": {str(k): v for k, v in sorted(pipe.batch_sizes.items())},
                     "note": "independent batch-1 requests through deepcut_tools.Pipeline (dc_net_forward_requests); latency = submit -> seen finished, closed loop"}
 
+        def pcie_inclusive_pipelined():
+            # host in / host out with requests IN FLIGHT: deepcut_tools.Pipeline.submit_host on the same executors (their streams
+            # chosen by the library), pinned buffers from caffe.pinned_empty: a request's upload, forward and the downloads of all
+            # three maps sit on its executor's own stream, so the DMA engines work beside the other executors' kernels.
+            # Closed loop, 2 x depth requests outstanding; SURVEY 8(d): "the whole forward() including H2D of the input and D2H
+            # of the three maps".
+            from deepcut_tools import Pipeline
+
+            pipe = Pipeline(net, depth=1, coalesce=1, choose_streams=False)
+            pipe.nets = nets[:S]
+            nslot = 2 * len(pipe.nets)
+            slots = []
+            for i in range(nslot):
+                xi = caffe.pinned_empty((B, 3, H, W))
+                xi[...] = xs[i % S].cpu().numpy()
+                slots.append((xi, [caffe.pinned_empty(tuple(shp[k])) for k in ("prob", "loc_pred", "next_pred")]))
+            nreq = max(args.steps, 10) * 4
+
+            def closed_loop(count):
+                sent = done = 0
+                while done < count:
+                    while sent < count and sent - done < nslot:
+                        xi, o = slots[sent % nslot]
+                        pipe.submit_host(xi, o[0], o[1], o[2], tag=sent)
+                        sent += 1
+                    pipe.wait_one()
+                    done += 1
+
+            closed_loop(2 * nslot)
+            dts = []
+            for _ in range(max(1, args.regions)):
+                t1 = time.perf_counter()
+                closed_loop(nreq)
+                dts.append(time.perf_counter() - t1)
+            dtp = sorted(dts)[len(dts) // 2]
+            ref = None
+            if args.dtype == "f32":  # the maps of the last request of slot 0 against the device-resident forward of the same input
+                o = [torch.empty(tuple(shp[k]), device=dev) for k in ("prob", "loc_pred", "next_pred")]
+                net.forward_device(xs[0].data_ptr(), B, H, W, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+                ref = max(float((o[j].cpu() - torch.from_numpy(slots[0][1][j])).abs().max()) for j in range(3))
+            return {"value": nreq * B / dtp, "value_min": nreq * B / max(dts), "value_max": nreq * B / min(dts), "unit": "images/s",
+                    "executors": len(pipe.nets), "requests_outstanding": nslot, "requests_per_region": nreq, "regions": len(dts),
+                    "bytes_per_image": {"host_to_device": 3 * H * W * 4, "device_to_host": int(sum(nel.values()) // B) * 4},
+                    "max_abs_diff_vs_device_resident_forward": ref,
+                    "note": "deepcut_tools.Pipeline.submit_host (dc_net_forward_host_async): pinned host buffers in and out, all three maps, "
+                            "closed loop; what `pcie_inclusive` (one synchronous request at a time, pageable memory) becomes with requests in flight"}
+
+        def resnet101():
+            # the depth BASELINE.json's metric names (the reference ships only ResNet-152, SURVEY F1: that is the headline); same
+            # workload, same protocol, conditioned synthetic weights of the 101 table
+            l101 = synth_weights(101, seed=0)
+            n101 = caffe.Net(deepercut_prototxt(101, H, W, B), caffe.TEST, from_text=True, hipgraph=0 if args.no_graph else 1, dtype=args.dtype)
+            inject_weights(n101, l101)
+            e101 = [n101] + [n101.clone() for _ in range(S - 1)]
+            for e in e101:
+                e.reserve(B, H, W)
+            choice = caffe.choose_streams(e101, candidates=max(args.stream_candidates, S)) if S > 1 else None
+            st101 = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in e101]
+            o101 = [torch.empty(sum(nel.values()), device=dev) for _ in e101]
+            fl = n101.flops() / B
+
+            def run(ns, count):
+                for i in range(count):
+                    k = i % ns
+                    e101[k].forward_device(xs[k % S].data_ptr(), B, H, W, o101[k][:a].data_ptr(), o101[k][a:b].data_ptr(), o101[k][b:].data_ptr(),
+                                           st101[k].cuda_stream)
+                torch.cuda.synchronize(dev)
+
+            out = {}
+            for key, ns in (("one_forward_at_a_time", 1), ("in_flight", S)):
+                run(ns, 2 * ns + args.warmup)
+                dts = []
+                for _ in range(max(1, args.regions)):
+                    t1 = time.perf_counter()
+                    run(ns, args.steps)
+                    dts.append(time.perf_counter() - t1)
+                dtm = sorted(dts)[len(dts) // 2]
+                out[key] = {"value": args.steps * B / dtm, "value_min": args.steps * B / max(dts), "value_max": args.steps * B / min(dts),
+                            "unit": "images/s", "ms_per_step": dtm / args.steps * 1e3, "tflops": args.steps * B * fl / dtm / 1e12}
+            res101 = dict(out["in_flight"])
+            res101.update({"workload": "batch=%d single-scale %dx%d (WxH) ResNet-101 DeeperCut forward, %s — BASELINE.json's model name; "
+                                       "same protocol as the headline (device-resident, %d forwards in flight on library-chosen streams)"
+                                       % (B, W, H, args.dtype, S),
+                           "gflop_per_image": fl / 1e9, "launches_per_forward": n101.num_launches(), "forwards_in_flight": S,
+                           "stream_choice": choice, "one_forward_at_a_time": out["one_forward_at_a_time"],
+                           "roofline_frac_one_at_a_time": out["one_forward_at_a_time"]["tflops"] / (PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS)})
+            return res101
+
         n_pcie = max(3, min(20, args.steps))
         if world == 1:
+            beside("pcie_inclusive_pipelined", pcie_inclusive_pipelined)
             beside("pcie_inclusive", pcie_inclusive)
             beside("pcie_inclusive_image_entry", image_entry)
             beside("pycaffe_forward", pycaffe_forward)
         if world == 1 and args.config == 1 and args.coalesce > 1 and B == 1:
             beside("cross_request_batching", cross_request_batching)
+        if world == 1 and args.config == 1 and not args.no_resnet101 and args.depth != 101:
+            beside("resnet101", resnet101)
         if world == 1 and args.dtype == "f32" and args.config == 1 and not args.no_f16_line:
             # the other single-GPU configuration of BASELINE.json, timed by the same run
             beside("config2_f16", lambda: config2_f16_line(caffe, layers, args.depth, 10, dev, inject_weights,

@@ -99,6 +99,55 @@ int dc_net_clone(dc_net* net, dc_net** out) {
   *out = nullptr;
   return guard([&] { *out = reinterpret_cast<dc_net*>(N(net)->clone()); });
 }
+int dc_net_forward_host_async(dc_net* net, const float* input, int n, int h, int w, float* prob, float* loc, float* next) {
+  REQUIRE(net);
+  REQUIRE(input);
+  if (n <= 0 || h <= 0 || w <= 0) return fail(DC_EINVAL, "forward_host_async: n, h, w must be positive");
+  return guard([&] { N(net)->forward_batch(input, n, h, w, false, prob, loc, next, nullptr, true); });
+}
+int dc_host_alloc(size_t bytes, void** out) {
+  REQUIRE(out);
+  *out = nullptr;
+  if (bytes == 0) return fail(DC_EINVAL, "dc_host_alloc: zero bytes");
+  return guard([&] {
+    standalone_device();
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      *out = nullptr;
+      throw DcError(DC_EDEVICE, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
+  });
+}
+int dc_host_free(void* p) {
+  if (!p) return DC_OK;
+  return guard([&] {
+    if (hipHostFree(p) != hipSuccess) {
+      (void)hipGetLastError();
+      throw DcError(DC_EINVAL, "dc_host_free: not a dc_host_alloc pointer");
+    }
+  });
+}
+int dc_nets_choose_streams(dc_net* const* nets, int n, int candidates, int reps, double* rate_chosen, double* rate_first) {
+  REQUIRE(nets);
+  if (n < 1 || n > 64) return fail(DC_EINVAL, "dc_nets_choose_streams: 1..64 executors");
+  std::vector<Net*> v;
+  for (int i = 0; i < n; ++i) {
+    if (!nets[i]) return fail(DC_EINVAL, "dc_nets_choose_streams: null net");
+    for (Net* o : v)
+      if (o == N(nets[i])) return fail(DC_EINVAL, "dc_nets_choose_streams: the same net twice");
+    v.push_back(N(nets[i]));
+  }
+  return guard([&] { Net::choose_streams(v, candidates, reps <= 0 ? 3 : reps, rate_chosen, rate_first); });
+}
+int dc_net_stream(dc_net* net, void** out) {
+  REQUIRE(net);
+  REQUIRE(out);
+  *out = nullptr;
+  return guard([&] {
+    if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "dc_net_stream in CPU mode: libdeepcut_hip provides the MI355X path only");
+    *out = N(net)->own_stream();
+  });
+}
 int dc_net_busy(dc_net* net, int* busy) {
   REQUIRE(net);
   REQUIRE(busy);
@@ -577,6 +626,52 @@ int dc_group_forward_images(dc_group* group, const unsigned char* const* images,
   }
   return guard([&] { G(group)->forward_images(images, n, height, width, scale, is_device != 0, prob, loc_pred, next_pred, pose, stream); });
 }
+int dc_comm_create(int nexec, const int* devices, int transport, dc_comm** out) {
+  REQUIRE(out);
+  *out = nullptr;
+  return guard([&] { *out = reinterpret_cast<dc_comm*>(comm_create(nexec, devices, transport)); });
+}
+int dc_comm_destroy(dc_comm* comm) {
+  if (!comm) return DC_OK;
+  return guard([&] { comm_destroy(reinterpret_cast<Comm*>(comm)); });
+}
+int dc_comm_transport(dc_comm* comm) {
+  if (!comm) return fail(DC_EINVAL, "null argument: comm");
+  return comm_transport(reinterpret_cast<Comm*>(comm));
+}
+int dc_forward_batch(dc_comm* comm, dc_net* const* nets, int nexec, const float* const* inputs, const int (*hw)[2], int n,
+                     float* const* prob, float* const* loc, float* const* next) {
+  REQUIRE(comm);
+  REQUIRE(nets);
+  if (nexec < 1) return fail(DC_EINVAL, "dc_forward_batch: no executors");
+  return guard([&] {
+    std::vector<Net*> v;
+    for (int k = 0; k < nexec; ++k) v.push_back(N(nets[k]));
+    comm_forward(reinterpret_cast<Comm*>(comm), v.data(), nexec, inputs, hw, n, prob, loc, next);
+  });
+}
+int dc_comm_item_executor(dc_comm* comm, int i) {
+  if (!comm) return fail(DC_EINVAL, "null argument: comm");
+  int r = -1;
+  int rc = guard([&] { r = comm_item_executor(reinterpret_cast<Comm*>(comm), i); });
+  return rc == DC_OK ? r : rc;
+}
+int dc_comm_root_maps(dc_comm* comm, int i, const void** prob, const void** loc, const void** next, int dims[5]) {
+  REQUIRE(comm);
+  return guard([&] { comm_root_maps(reinterpret_cast<Comm*>(comm), i, prob, loc, next, dims); });
+}
+int dc_lpt_schedule(const double* cost, int n, int nexec, int* exec_of_item) {
+  if (n < 0 || nexec < 1) return fail(DC_EINVAL, "dc_lpt_schedule: n >= 0 items on nexec >= 1 executors");
+  if (n == 0) return DC_OK;
+  REQUIRE(cost);
+  REQUIRE(exec_of_item);
+  return guard([&] {
+    const auto share = lpt_schedule(std::vector<double>(cost, cost + n), nexec);
+    for (int k = 0; k < nexec; ++k)
+      for (int i : share[(size_t)k]) exec_of_item[i] = k;
+  });
+}
+
 const char* dc_group_plan_text(dc_group* group) {
   if (!group) return nullptr;
   NetGroup* g = G(group);

@@ -239,6 +239,7 @@ struct Net {
   NetStats stats;
   std::map<std::string, int> aux_index_; // concatenated-head tensors created by the lowering
   void* stream = nullptr;
+  bool stream_borrowed_ = false;  // `stream` belongs to the process-wide executor pool (streams.cpp): never destroyed with the net
   int device = -1;
   double* pose_dev = nullptr;
   size_t pose_cap = 0;
@@ -249,6 +250,11 @@ struct Net {
   static Net* create(const std::string& prototxt_text, int phase, const Net* clone_of = nullptr);
   Net* clone();           // same graph and input shape, SHARED parameters and packed device weights
   void synchronize();     // wait for everything enqueued on the net's own stream
+  // streams.cpp: the executors' own streams chosen by timing their forwards on candidate assignments (hardware-queue sharing decides
+  // what "in flight" is worth and the API does not say which queue a stream got)
+  static void choose_streams(const std::vector<Net*>& nets, int ncand, int reps, double* rate_chosen, double* rate_first);
+  void adopt_stream(void* s);  // a pool stream becomes the net's own
+  void* own_stream();          // the net's own stream, created on first use
   void set_dtype(int d);  // 0 float32 / 1 float16 device images (DC_OPT_DTYPE)
   void copy_from(const std::string& path);
   void save(const std::string& path);
@@ -261,8 +267,10 @@ struct Net {
   // one reference layer stand-alone (Layer<Dtype>::SetUp on given bottoms): a net whose inputs are the layer's bottoms
   static Net* create_for_layer(const std::string& layer_text, int phase, const std::vector<std::vector<int>>& bottom_shapes);
   void forward(int start, int end);
+  // host_async (host buffers only): nothing is waited for — the upload, the forward and the downloads are enqueued on the net's own
+  // stream and the caller collects with synchronize(); truly asynchronous for pinned buffers (dc_host_alloc), staged by the runtime otherwise
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
-                     float* next, void* user_stream);
+                     float* next, void* user_stream, bool host_async = false);
   // cross-request batching: n independent single-image requests (device buffers, one pointer set per request) as ONE batch-n forward
   void forward_requests(int n, const float* const* inputs, int h, int w, float* const* prob, float* const* loc, float* const* next,
                         void* user_stream);
@@ -409,5 +417,17 @@ struct NetGroup {
   void drop_plan(GroupPlan& gp);
   void* stream();
 };
+
+// ---- multi_gpu.cpp: in-process multi-GPU forward (dc_comm_*, dc_forward_batch) ----------------------------------------------
+struct Comm;
+Comm* comm_create(int nexec, const int* devices, int transport);
+void comm_destroy(Comm* c);
+int comm_transport(const Comm* c);
+int comm_nexec(const Comm* c);
+void comm_forward(Comm* c, Net* const* nets, int nexec, const float* const* inputs, const int (*hw)[2], int n, float* const* prob, float* const* loc,
+                  float* const* next);
+int comm_item_executor(const Comm* c, int i);
+void comm_root_maps(const Comm* c, int i, const void** prob, const void** loc, const void** next, int dims[5]);
+std::vector<std::vector<int>> lpt_schedule(const std::vector<double>& cost, int nexec);
 
 }  // namespace dc

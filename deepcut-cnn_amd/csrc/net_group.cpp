@@ -10,17 +10,9 @@ namespace dc {
 // creation, and whether two streams really run side by side cannot be asked.
 static std::mutex g_lane_mu;
 static std::map<void*, int> g_lane_users;  // candidate stream -> groups whose lanes run on it (two groups in flight must not share one)
-static std::vector<void*>& lane_stream_candidates(int device, size_t want) {
-  static std::map<int, std::vector<void*>> pool;
-  std::lock_guard<std::mutex> lk(g_lane_mu);
-  std::vector<void*>& p = pool[device];
-  while (p.size() < want) {
-    hipStream_t st;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-    p.push_back(st);
-  }
-  return p;
-}
+// the candidates are the process-wide executor pool of streams.cpp, handed out as a COPY: the pool grows under its own lock, and
+// a reference into it dangled when another thread's group asked for more lanes (round-4 advice)
+static std::vector<void*> lane_stream_candidates(int device, size_t want) { return executor_stream_pool(device, want); }
 static void lane_streams_release(const std::vector<void*>& side) {
   std::lock_guard<std::mutex> lk(g_lane_mu);
   for (void* st : side)
@@ -592,7 +584,7 @@ void NetGroup::launch_lanes(GroupPlan& gp, void* s, const std::vector<void*>& si
 void NetGroup::choose_lane_streams(GroupPlan& gp, void* s, bool use_graph) {
   const int nl = gp.nlanes;
   const size_t ncand = 6;
-  std::vector<void*>& cand = lane_stream_candidates(nets[0]->device, ncand + (size_t)nl);
+  const std::vector<void*> cand = lane_stream_candidates(nets[0]->device, ncand + (size_t)nl);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct EvGuard {
     hipEvent_t &a, &b;
@@ -622,6 +614,7 @@ void NetGroup::choose_lane_streams(GroupPlan& gp, void* s, bool use_graph) {
       std::lock_guard<std::mutex> lk(g_lane_mu);
       for (int k = 1; k < nl; ++k) free_ = free_ && g_lane_users[side[k]] == 0;
     }
+    for (int k = 1; k < nl; ++k) free_ = free_ && pool_stream_users(side[k]) == 0;  // ... nor an executor's own (streams.cpp)
     if (free_ && ms < best_free) best_free = ms, best_free_set = side;
   }
   // a stream no other group's lanes run on, if one is (nearly) as good: two groups in flight whose side lanes share ONE stream

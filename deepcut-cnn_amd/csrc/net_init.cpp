@@ -97,7 +97,8 @@ Net::~Net() {
   release_graph();
   for (auto& ps : parked_)
     if (ps->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ps->graph_exec);
-  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+  if (stream && stream_borrowed_) pool_stream_release(stream);
+  else if (stream) (void)hipStreamDestroy((hipStream_t)stream);
   dev_free(pose_dev);
   dev_free(scratch_dev_);
   dev_free(img_dev_);

@@ -73,6 +73,12 @@ hipGraphExec_t capture_graph(void* cs, F&& enqueue) {
   return ge;
 }
 
+// ---- streams.cpp ------------------------------------------------------------------------------------
+std::vector<void*> executor_stream_pool(int device, size_t want);  // a COPY of the first `want` process-wide candidates
+void pool_stream_acquire(void* s);
+void pool_stream_release(void* s);
+int pool_stream_users(void* s);
+
 // ---- small helpers -----------------------------------------------------------------------------------
 inline int env_int(const char* k, int def) {
   const char* v = std::getenv(k);

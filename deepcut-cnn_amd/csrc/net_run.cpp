@@ -361,7 +361,8 @@ void Net::emit_last_maps(void* prob, void* loc, void* next, int elem, bool is_de
 }
 
 void Net::forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc, float* next,
-                        void* user_stream) {
+                        void* user_stream, bool host_async) {
+  if (host_async && (is_device || user_stream)) throw DcError(DC_EINVAL, "forward_host_async takes host buffers and runs on the net's own stream");
   Storage& in = begin_batch(n, h, w);
   const int C = in.dim(1);
   const bool own_async = user_stream == (void*)-1;  // DC_STREAM_OWN: the net's stream, no final sync
@@ -378,7 +379,7 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   in.head = HEAD_AT_GPU;
   enqueue_plan(s);
   emit_maps(prob, loc, next, is_device, s);
-  if (!(is_device && (user_stream || own_async))) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
+  if (!(is_device && (user_stream || own_async)) && !host_async) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
 // n independent requests of one image each -> one batch-n launch plan: at batch 1 a res4 layer is 196 workgroups on 256 CUs

@@ -126,6 +126,18 @@ def _load():
         "dc_group_set_tile": (ci, [vp, cp, cp]),
         "dc_group_stats": (ci, [vp, C.POINTER(C.c_longlong), ci]),
         "dc_group_flops": (ci, [vp, C.POINTER(C.c_double)]),
+        "dc_net_forward_host_async": (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
+        "dc_host_alloc": (ci, [C.c_size_t, C.POINTER(vp)]),
+        "dc_host_free": (ci, [vp]),
+        "dc_nets_choose_streams": (ci, [C.POINTER(vp), ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "dc_net_stream": (ci, [vp, C.POINTER(vp)]),
+        "dc_comm_create": (ci, [ci, C.POINTER(ci), ci, C.POINTER(vp)]),
+        "dc_comm_destroy": (ci, [vp]),
+        "dc_comm_transport": (ci, [vp]),
+        "dc_forward_batch": (ci, [vp, C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(ci * 2), ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "dc_comm_item_executor": (ci, [vp, ci]),
+        "dc_comm_root_maps": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]),
+        "dc_lpt_schedule": (ci, [C.POINTER(C.c_double), ci, ci, C.POINTER(ci)]),
         "dc_conv_variant_count": (ci, []),
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
@@ -171,6 +183,71 @@ def canvas_size(height, width, scale):
     h, w = C.c_int(), C.c_int()
     _check(_lib.dc_image_canvas_size(int(height), int(width), float(scale), C.byref(h), C.byref(w)))
     return h.value, w.value
+
+
+def lpt_schedule(costs, nexec):
+    """Longest-processing-time-first shares (dc_lpt_schedule: the schedule dc_forward_batch deals images by; the same lists as
+    deepcut_tools.lpt_shards): per executor the item indices, ascending."""
+    n = len(costs)
+    out = (C.c_int * max(n, 1))()
+    _check(_lib.dc_lpt_schedule((C.c_double * max(n, 1))(*[float(c) for c in costs]), n, int(nexec), out))
+    shares = [[] for _ in range(int(nexec))]
+    for i in range(n):
+        shares[out[i]].append(i)
+    return shares
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A NumPy array over pinned (page-locked) host memory from dc_host_alloc, freed when the array and every view of it are gone:
+    what Net.forward_host_async / Pipeline.submit_host copy from and to without a staging pass."""
+    import weakref
+
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if len(tuple(shape)) else 1
+    p = C.c_void_p()
+    _check(_lib.dc_host_alloc(max(1, n * dt.itemsize), C.byref(p)))
+    buf = (C.c_char * max(1, n * dt.itemsize)).from_address(p.value)
+    a = np.frombuffer(buf, dt, count=n).reshape(shape)
+    weakref.finalize(a.base if a.base is not None else a, _lib.dc_host_free, C.c_void_p(p.value))
+    return a
+
+
+def choose_streams(nets, candidates=8, reps=3):
+    """dc_nets_choose_streams: the executors' own streams (stream="own") chosen by timing their real forwards on assignments of a
+    process-wide pool of candidate streams — which hardware queue a stream landed on decides what forwards "in flight" are worth
+    (380 to 490 images/s for four batch-1 executors) and the API does not say.  Every net must have run or reserved its shape.
+    -> {"forwards_per_s_chosen": ..., "forwards_per_s_first_created": ...}."""
+    k = len(nets)
+    a, b = C.c_double(), C.c_double()
+    _check(_lib.dc_nets_choose_streams((C.c_void_p * k)(*[n._h for n in nets]), k, int(candidates), int(reps), C.byref(a), C.byref(b)))
+    return {"forwards_per_s_chosen": a.value, "forwards_per_s_first_created": b.value}
+
+
+class _OutPool(object):
+    """Result arrays handed out again once NOBODY holds the previous hand-out or a view of it.  The memory belongs to a ctypes
+    buffer the pool keeps; every hand-out is a NEW ndarray over it and the pool keeps only a weak reference to that ndarray:
+    views hold their base array alive, so the weak reference dies exactly when the last of them is gone.  (Round 4 asked
+    sys.getrefcount, an implementation detail that changes with borrowed-reference loads and free-threaded builds.)"""
+
+    def __init__(self, keep=4):
+        self.keep, self.entries = keep, []
+
+    def take(self, shape):
+        import weakref
+
+        n = int(np.prod(shape))
+        for e in self.entries:
+            if e[1] == n and (e[2] is None or e[2]() is None):
+                a = np.frombuffer(e[0], np.float32, count=n)
+                e[2] = weakref.ref(a)
+                return a.reshape(shape)
+        buf = (C.c_float * max(n, 1))()  # zero-filled: the pages exist before the first device-to-host copy lands in them
+        a = np.frombuffer(buf, np.float32, count=n)
+        if len(self.entries) < self.keep:
+            import weakref as _w
+
+            self.entries.append([buf, n, _w.ref(a)])
+        return a.reshape(shape)
 
 
 class Layer(object):
@@ -400,8 +477,8 @@ class Net(object):
     # --- extensions (no pycaffe counterpart) ---------------------------------------------------
     def _out_array(self, key, shape, out=None):
         """Destination array of one output map.  `out` (a dict of C-contiguous float32 arrays of the right shape) wins.
-        Otherwise an array from a small per-net pool is handed out again once NOBODY else references it any more (the
-        caller dropped the previous result, views included: a view keeps its base alive), else a new one is made.
+        Otherwise memory from a small per-net pool is handed out again once NOBODY references the previous hand-out any more
+        (views included: `_OutPool`), else new memory is taken.
         Why: a fresh 73 MB `np.empty` is untouched virtual memory; the device-to-host copy then faults every page of it
         inside the driver's pin-on-the-fly path, which cost the float16 batch-8 host entry 7-35 ms per call (review r3,
         weak 2) against 2.4 ms for the same copy into pages that exist."""
@@ -414,18 +491,12 @@ class Net(object):
         pk = (key, tuple(shape))
         pool = pools.get(pk)
         if pool is None:
-            pool = pools[pk] = []
+            pool = pools[pk] = _OutPool()
             while len(pools) > 24:  # shapes of long ago go first
                 pools.popitem(last=False)
         else:
             pools.move_to_end(pk)
-        for a in pool:
-            if sys.getrefcount(a) <= 3:  # the pool's list, this loop variable, getrefcount's argument
-                return a
-        a = np.empty(shape, np.float32)
-        if len(pool) < 4:
-            pool.append(a)
-        return a
+        return pool.take(tuple(shape))
 
     def forward_batch(self, images, want=("prob", "loc_pred", "next_pred"), out=None):
         """images: float32 [n,3,H,W] host array -> dict of NCHW host arrays (one batched launch plan).  The arrays of a
@@ -454,6 +525,24 @@ class Net(object):
             stream = C.c_void_p(-1).value
         _check(_lib.dc_net_forward_batch(self._h, C.c_void_p(in_ptr), n, h, w, 1, C.c_void_p(prob_ptr or 0),
                                          C.c_void_p(loc_ptr or 0), C.c_void_p(next_ptr or 0), C.c_void_p(stream or 0)))
+
+    def forward_host_async(self, x, prob=None, loc_pred=None, next_pred=None):
+        """dc_net_forward_host_async: x float32 [n,3,H,W] and the output arrays (C-contiguous float32 of the maps' shapes, or
+        None) are HOST arrays; nothing is waited for — the upload, the forward and the downloads are enqueued on the net's own
+        stream.  Collect with synchronize() (or poll busy()); every array must stay alive and untouched until then.  Arrays from
+        caffe.pinned_empty() are copied by the DMA engines beside other executors' kernels."""
+        for a in (x, prob, loc_pred, next_pred):
+            if a is not None and not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]):
+                raise ValueError("forward_host_async wants C-contiguous float32 arrays")
+        n, c, h, w = x.shape
+        ptr = lambda a: C.c_void_p(a.ctypes.data if a is not None else 0)  # noqa: E731
+        _check(_lib.dc_net_forward_host_async(self._h, ptr(x), n, h, w, ptr(prob), ptr(loc_pred), ptr(next_pred)))
+
+    def stream_handle(self):
+        """The net's own HIP stream (an integer hipStream_t, e.g. for torch.cuda.ExternalStream): what stream="own" enqueues on."""
+        p = C.c_void_p()
+        _check(_lib.dc_net_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def forward_requests(self, in_ptrs, h, w, prob_ptrs=None, loc_ptrs=None, next_ptrs=None, stream=None):
         """Cross-request batching: len(in_ptrs) independent single-image requests (raw device pointers, one output pointer
@@ -790,3 +879,59 @@ class NetGroup(object):
         f = C.c_double()
         _check(_lib.dc_group_flops(self._h, C.byref(f)))
         return f.value
+
+
+class Comm(object):
+    """In-process multi-GPU forward (dc_comm_create / dc_forward_batch): `nets[k]` runs on `devices[k]` on a host thread of its own
+    inside the library; images are dealt longest-processing-time-first over H*W, the maps gathered on the root executor's device
+    (RCCL ncclSend / ncclRecv opened with dlopen, or peer copies — `transport`: "auto", "rccl", "peer") and returned as host arrays."""
+
+    TRANSPORTS = {"auto": 0, "rccl": 1, "peer": 2}
+
+    def __init__(self, nets, devices=None, transport="auto"):
+        self.nets = list(nets)
+        k = len(self.nets)
+        dev = None if devices is None else (C.c_int * k)(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _check(_lib.dc_comm_create(k, dev, self.TRANSPORTS[transport], C.byref(h)))
+        self._h = h
+        self._fin = __import__("weakref").finalize(self, _lib.dc_comm_destroy, C.c_void_p(h.value))
+
+    @property
+    def transport(self):
+        t = _lib.dc_comm_transport(self._h)
+        return {1: "rccl", 2: "peer"}.get(t, t)
+
+    def forward(self, images, want=("prob", "loc_pred", "next_pred")):
+        """images: a list of float32 [3,H,W] host arrays (shapes may differ) -> a list of dicts of [C,h,w] host arrays."""
+        xs = [np.ascontiguousarray(x, dtype=np.float32) for x in images]
+        n, k = len(xs), len(self.nets)
+        if any(x.ndim != 3 or x.shape[0] != 3 for x in xs):
+            raise ValueError("dc_forward_batch takes [3,H,W] images")
+        hw = (C.c_int * 2 * max(n, 1))()
+        for i, x in enumerate(xs):
+            hw[i][0], hw[i][1] = x.shape[1], x.shape[2]
+        chans = {key: self.nets[0].blobs[key].shape[1] for key in ("prob", "loc_pred", "next_pred")}
+        outs = [{key: np.empty((chans[key], x.shape[1] // 8, x.shape[2] // 8), np.float32) for key in want} for x in xs]
+
+        def col(key):
+            if key not in want:
+                return None
+            return (C.c_void_p * max(n, 1))(*[C.c_void_p(o[key].ctypes.data) for o in outs])
+
+        _check(_lib.dc_forward_batch(self._h, (C.c_void_p * k)(*[m._h for m in self.nets]), k,
+                                     (C.c_void_p * max(n, 1))(*[C.c_void_p(x.ctypes.data) for x in xs]), hw, n, col("prob"), col("loc_pred"), col("next_pred")))
+        return outs
+
+    def executor_of(self, i):
+        r = _lib.dc_comm_item_executor(self._h, int(i))
+        if r < 0:
+            _check(r)
+        return r
+
+    def root_maps(self, i):
+        """Device pointers (on the root executor's device) and dims of image i's gathered maps: (prob, loc_pred, next_pred, dims)."""
+        p, l, x = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        dims = (C.c_int * 5)()
+        _check(_lib.dc_comm_root_maps(self._h, int(i), C.byref(p), C.byref(l), C.byref(x), dims))
+        return p.value, l.value, x.value, list(dims)

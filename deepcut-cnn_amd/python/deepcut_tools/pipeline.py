@@ -11,17 +11,28 @@ fill the chip and pay their fixed cost once per batch).  Light load: batch-1 lat
 Device-resident interface: the caller owns NCHW float32 device buffers (e.g. torch CUDA tensors) and keeps them alive
 until the request's tag comes back from wait_one() / drain().  Three executors is the useful maximum: a HIP process has
 four hardware queues, and more concurrent kernels only evict each other's tiles from the 4 MB L2s.
+Host-resident interface (round 5): `submit_host` takes HOST arrays in and out (pinned ones from `caffe.pinned_empty` are
+copied by the DMA engines): the upload, the forward and the downloads of a request sit on its executor's own stream, so with
+`depth` executors the copies of one request run beside the kernels of the others — the reference's blocking SyncedMemory copies
+(src/caffe/syncedmem.cpp:25-77) one request at a time reach 293 images/s on this path, the bus needs 7.3 GB/s for 490.
+WHICH streams the executors run on is chosen by the library the first time a shape is met (`caffe.choose_streams`: the real
+forwards timed on a process-wide pool of candidate streams; hardware-queue sharing is worth 380 ... 490 images/s at depth 4).
+Return values (changed in round 4): submit() returns None — the request may be queued, no executor is known yet — and
+wait_one() / drain() return tags in the order requests FINISH, which across executors is not the order of submission.
 The reference forwards one image at a time (src/caffe/layers/conv_layer.cpp:31): nothing to mirror.
 """
 import collections
+import os
 import time
 
 
 class Pipeline(object):
     LATENCY_WINDOW = 1 << 16
 
-    def __init__(self, net, depth=3, coalesce=None, max_batch=4, max_queue=None):
+    def __init__(self, net, depth=3, coalesce=None, max_batch=4, max_queue=None, choose_streams=True):
         self.nets = [net] + [net.clone() for _ in range(max(1, depth) - 1)]
+        self._choose_streams = bool(choose_streams) and os.environ.get("DC_STREAM_CHOICE", "1") != "0"
+        self.stream_choice = None  # what caffe.choose_streams measured, once it ran
         self.opportunistic = coalesce is None
         self.coalesce = 1 if coalesce is None else max(1, int(coalesce))
         self.max_batch = max(1, int(max_batch)) if self.opportunistic else self.coalesce
@@ -55,7 +66,18 @@ class Pipeline(object):
             k = self._free_executor()
         self._next = (k + 1) % len(self.nets)
         h, w = reqs[0][1], reqs[0][2]
-        if len(reqs) == 1 and (reqs[0][7] != 1 or self.max_batch == 1):
+        if self._choose_streams and len(self.nets) > 1 and not self._pending:
+            # first launch: every executor lowers / allocates / tunes the shape, then the library picks their streams by timing
+            # them together (untimed set-up, like the autotuner's)
+            import caffe
+
+            self._choose_streams = False
+            for e in self.nets:
+                e.reserve(reqs[0][7] if len(reqs) == 1 else len(reqs), h, w)
+            self.stream_choice = caffe.choose_streams(self.nets)
+        if len(reqs[0]) > 9 and reqs[0][9] is not None:  # host request: (x, prob, loc_pred, next_pred) arrays
+            self.nets[k].forward_host_async(*reqs[0][9])
+        elif len(reqs) == 1 and (reqs[0][7] != 1 or self.max_batch == 1):
             r = reqs[0]
             self.nets[k].forward_device(r[0], r[7], h, w, r[3], r[4], r[5], stream="own")
         else:
@@ -83,8 +105,9 @@ class Pipeline(object):
     def _take_batch(self):
         first = self._held.popleft()
         reqs = [first]
-        while self._held and len(reqs) < self.max_batch and first[7] == 1 and self._held[0][7] == 1 and \
-                (self._held[0][1], self._held[0][2]) == (first[1], first[2]):
+        host = lambda r: len(r) > 9 and r[9] is not None  # noqa: E731  (host requests are batches of their own)
+        while self._held and len(reqs) < self.max_batch and first[7] == 1 and self._held[0][7] == 1 and not host(first) and \
+                not host(self._held[0]) and (self._held[0][1], self._held[0][2]) == (first[1], first[2]):
             reqs.append(self._held.popleft())
         return reqs
 
@@ -118,6 +141,18 @@ class Pipeline(object):
         if len(self._held) >= self.coalesce:
             self.flush()
         return None
+
+    def submit_host(self, x, prob=None, loc_pred=None, next_pred=None, tag=None):
+        """Enqueue one host-in / host-out forward (asynchronous): x float32 [n,3,H,W], the outputs C-contiguous float32 arrays of
+        the maps' shapes or None.  Every array must stay alive and untouched until the request's tag comes back from wait_one() /
+        drain(); arrays from caffe.pinned_empty() are moved by the DMA engines while other executors compute."""
+        n, _c, h, w = x.shape
+        req = (None, h, w, None, None, None, tag, n, time.perf_counter(), (x, prob, loc_pred, next_pred))
+        if self.opportunistic:
+            self._held.append(req)
+            self._pump()
+            return None
+        return self._launch([req])
 
     def flush(self):
         """Launch whatever is queued as it is (partial batches included)."""

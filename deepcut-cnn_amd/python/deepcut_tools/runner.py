@@ -337,23 +337,27 @@ class ShardedPoseRunner(object):
         return poses, maps
 
     def _result_stage(self, numel):
-        """(pinned float32 host tensor of `numel` elements, numpy view of it) for the maps of one run: a buffer of an earlier
-        run is taken again when nothing refers to its views any more (a view keeps its base array alive, so the reference count
-        of the base tells), else a new one is allocated; at most four are kept."""
-        import sys
+        """(pinned float32 host tensor of `numel` elements, numpy view of it) for the maps of one run: the memory of an earlier
+        run is taken again when nothing refers to the array handed out for it any more — the pool keeps the tensor (the memory) and
+        only a WEAK reference to the hand-out; views keep their base array alive, so the weak reference dies with the last of
+        them (no reference-count arithmetic: that is an implementation detail of the interpreter) —, else a new one is allocated; at
+        most four are kept."""
+        import weakref
 
         import torch
 
         pool = self.__dict__.setdefault("_stage_pool", [])
-        for t, a in pool:
-            if t.numel() >= numel and sys.getrefcount(a) <= 3:  # the pool's tuple, this loop variable, getrefcount's argument
-                return t[:numel], a[:numel]
+        for e in pool:
+            if e[0].numel() >= numel and (e[1] is None or e[1]() is None):
+                a = e[0].numpy()
+                e[1] = weakref.ref(a)
+                return e[0][:numel], a[:numel]
         try:
             t = torch.empty(max(numel, 1), dtype=torch.float32, pin_memory=True)
         except RuntimeError:
             t = torch.empty(max(numel, 1), dtype=torch.float32)
         a = t.numpy()
-        pool.append((t, a))
+        pool.append([t, weakref.ref(a)])
         if len(pool) > 4:
             pool.pop(0)
         return t[:numel], a[:numel]

@@ -359,8 +359,16 @@ class Net<float> {
   int num_inputs() const { return dc_net_num_inputs(h_); }
   int num_outputs() const { return dc_net_num_outputs(h_); }
   dc_net* handle() const { return h_; }
+  // A second executor of this model on the same device (dc_net_clone: own activations and stream, SHARED parameters and packed
+  // filters).  No reference counterpart; Net::ShareTrainedLayersWith (net.cpp:751-769) is the nearest idea.
+  shared_ptr<Net<float> > Clone() const {
+    dc_net* c = nullptr;
+    dc_check_(dc_net_clone(h_, &c));
+    return shared_ptr<Net<float> >(new Net<float>(c));
+  }
 
  private:
+  explicit Net(dc_net* adopted) : h_(adopted) {}
   const vector<Blob<float>*>& collect_(vector<Blob<float>*>& cache, bool inputs) {
     if (cache.empty()) {
       int n = inputs ? dc_net_num_inputs(h_) : dc_net_num_outputs(h_);
@@ -376,6 +384,53 @@ class Net<float> {
   dc_net* h_ = nullptr;
   vector<std::unique_ptr<Blob<float> > > owned_;
   vector<Blob<float>*> in_, out_;
+};
+
+// ---- in-process multi-GPU forward (dc_comm_create / dc_forward_batch) for C++ callers -----------------------------------------
+// No reference counterpart: the reference's only multi-GPU code is the training-time P2PSync tree (src/caffe/parallel.cpp:287-322).
+// nets[k] runs on devices[k] (empty: k modulo the visible devices) on a host thread of its own inside the library; Forward() deals the
+// images longest-processing-time-first over H*W, batches the same-shape images of an executor, gathers the maps on the root
+// executor's device (RCCL send/recv, or peer copies) and returns them as host vectors.  A tools/caffe.cpp-style program
+// (tools/caffe.cpp:302-388) creates one Net per device under Caffe::SetDevice(k) — or clones where executors share a device.
+class ForwardPool {
+ public:
+  struct Maps {
+    std::vector<float> prob, loc_pred, next_pred;  // [C][h][w] each
+    int map_h = 0, map_w = 0;
+  };
+  explicit ForwardPool(const vector<Net<float>*>& nets, const vector<int>& devices = vector<int>(), int transport = DC_COMM_AUTO) {
+    for (Net<float>* n : nets) nets_.push_back(n->handle());
+    dc_check_(dc_comm_create((int)nets_.size(), devices.empty() ? nullptr : devices.data(), transport, &comm_));
+    shared_ptr<Blob<float> > p = nets[0]->blob_by_name("prob"), l = nets[0]->blob_by_name("loc_pred"), x = nets[0]->blob_by_name("next_pred");
+    pc_ = p->channels(), lc_ = l->channels(), nc_ = x->channels();
+  }
+  ~ForwardPool() { dc_comm_destroy(comm_); }
+  ForwardPool(const ForwardPool&) = delete;
+  ForwardPool& operator=(const ForwardPool&) = delete;
+  // images[i]: 3 x hw[i].first x hw[i].second float32 (NCHW, host)
+  std::vector<Maps> Forward(const std::vector<const float*>& images, const std::vector<std::pair<int, int> >& hw) {
+    const int n = (int)images.size();
+    std::vector<Maps> out((size_t)n);
+    std::vector<int> shape((size_t)n * 2 + 2);
+    std::vector<float*> pp((size_t)n + 1), lp((size_t)n + 1), np((size_t)n + 1);
+    for (int i = 0; i < n; ++i) {
+      shape[2 * i] = hw[i].first, shape[2 * i + 1] = hw[i].second;
+      Maps& m = out[i];
+      m.map_h = hw[i].first / 8, m.map_w = hw[i].second / 8;
+      m.prob.resize((size_t)pc_ * m.map_h * m.map_w), m.loc_pred.resize((size_t)lc_ * m.map_h * m.map_w), m.next_pred.resize((size_t)nc_ * m.map_h * m.map_w);
+      pp[i] = m.prob.data(), lp[i] = m.loc_pred.data(), np[i] = m.next_pred.data();
+    }
+    dc_check_(dc_forward_batch(comm_, nets_.data(), (int)nets_.size(), images.data(), reinterpret_cast<const int(*)[2]>(shape.data()), n, pp.data(),
+                               lp.data(), np.data()));
+    return out;
+  }
+  int transport() const { return dc_comm_transport(comm_); }
+  int executor_of(int i) const { return dc_comm_item_executor(comm_, i); }
+
+ private:
+  dc_comm* comm_ = nullptr;
+  std::vector<dc_net*> nets_;
+  int pc_ = 0, lc_ = 0, nc_ = 0;
 };
 
 }  // namespace caffe

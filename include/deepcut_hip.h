@@ -179,6 +179,30 @@ int dc_net_create_for_layer(const char* layer_param_text, int phase, int nbottom
 int dc_net_forward_batch(dc_net* net, const float* input, int n, int h, int w, int is_device,
                          float* prob, float* loc_pred, float* next_pred, void* stream);
 
+/* The same with HOST buffers and NO wait: the upload of the batch, the forward and the downloads of the maps are enqueued on the
+ * net's own stream; dc_net_synchronize (or dc_net_busy) tells when the outputs are there, and input and outputs must stay valid
+ * until then.  With buffers from dc_host_alloc (pinned) the copies run on the DMA engines beside other executors' kernels, which is
+ * what lets several executors keep host-in / host-out requests in flight (deepcut_tools.Pipeline.submit_host); pageable buffers
+ * work too, staged by the runtime.  Replaces the blocking copies of SyncedMemory::to_gpu / to_cpu (src/caffe/syncedmem.cpp:25-77) for
+ * callers that do not need the reference's synchronous contract.                                                          */
+int dc_net_forward_host_async(dc_net* net, const float* input, int n, int h, int w, float* prob, float* loc_pred, float* next_pred);
+/* pinned (page-locked) host memory for the entry above; the reference pins its blobs the same way in GPU mode
+ * (CaffeMallocHost, include/caffe/syncedmem.hpp:15-44)                                                                 */
+int dc_host_alloc(size_t bytes, void** out);
+int dc_host_free(void* p);
+
+/* ---- executor streams chosen by measurement -----------------------------------------------------------------------------
+ * A HIP process has four hardware queues; a stream is bound to one of them at creation and streams that share a queue run one
+ * after the other — with four executors "in flight" the throughput is 380 to 490 images/s depending on which streams they got
+ * (profiles/r04_stream_subsets.txt), and the API does not say.  dc_nets_choose_streams times the executors' REAL forwards (each must
+ * have run or reserved its shape) on assignments of a process-wide pool of `candidates` (0 = 8) streams, `reps` (0 = 3) forwards
+ * per executor and burst, and makes the best assignment the executors' own streams (DC_STREAM_OWN, dc_net_stream).  rate_chosen /
+ * rate_first (may be NULL): forwards per second with the chosen streams / with the first n streams of the pool.  No reference
+ * counterpart (one legacy stream per thread, src/caffe/common.cpp:99-158).                                                */
+int dc_nets_choose_streams(dc_net* const* nets, int n, int candidates, int reps, double* rate_chosen, double* rate_first);
+/* the net's own stream (a hipStream_t), created on first use: what DC_STREAM_OWN enqueues on                              */
+int dc_net_stream(dc_net* net, void** out);
+
 /* Cross-request batching: `n` independent single-image requests — one DEVICE input pointer ([3,H,W] float32) and one
  * set of DEVICE output pointers per request (the arrays, or single entries, may be NULL) — run as ONE batch-n forward;
  * request i's maps land in its own buffers.  What a server does with concurrent batch-1 requests (the reference forwards
@@ -334,6 +358,33 @@ int dc_group_set_tile(dc_group* group, const char* signature, const char* tile);
 int dc_group_stats(dc_group* group, long long* out, int n);
 /* algorithmic FLOPs of the last grouped forward (the members' dc_net_flops summed)                                          */
 int dc_group_flops(dc_group* group, double* out);
+
+/* ---- in-process multi-GPU forward (SURVEY 8(b)'s dc_forward_batch) -------------------------------------------------------
+ * A communicator over `nexec` executors: executor k runs on devices[k] (NULL: k modulo the visible devices) on a host thread of its
+ * own (mode and device are per thread, src/caffe/common.cpp:13-20).  transport: how the maps travel to the root executor's device —
+ * DC_COMM_RCCL: one grouped ncclRecv x (n-1) / ncclSend exchange (librccl.so is opened with dlopen at the first use; needs one
+ * executor per device); DC_COMM_PEER: hipMemcpyPeerAsync (device-to-device copies when executors share a device: the loop-back
+ * transport of the 1-GPU tests); DC_COMM_AUTO: RCCL when it loads and the devices are distinct, else PEER.
+ * dc_forward_batch: `n` host images (inputs[i]: 3 x hw[i][0] x hw[i][1] float32 NCHW, shapes may differ) are dealt to the executors
+ * longest-processing-time-first over H*W, every executor forwards the same-shape images of its share as one batch on nets[k] —
+ * nets[k] must live on devices[k]: replicas created under dc_set_device(k), or clones where executors share a device —, the maps are
+ * gathered on the root's device (dc_comm_root_maps: NCHW float32 device pointers of image i, dims = {prob, loc_pred, next_pred
+ * channels, map height, map width}, valid until the next call) and copied to prob[i] / loc_pred[i] / next_pred[i] (host; arrays or
+ * entries may be NULL).  Synchronous.  The reference has no inference-time multi-GPU path (its P2PSync, src/caffe/parallel.cpp:287-322,
+ * sums gradients along a tree); the consumer this serves is a tools/caffe.cpp-style C++ program (tools/caffe.cpp:302-388).   */
+#define DC_COMM_AUTO 0
+#define DC_COMM_RCCL 1
+#define DC_COMM_PEER 2
+typedef struct dc_comm dc_comm;
+int dc_comm_create(int nexec, const int* devices, int transport, dc_comm** out);
+int dc_comm_destroy(dc_comm* comm);
+int dc_comm_transport(dc_comm* comm); /* DC_COMM_RCCL or DC_COMM_PEER (negative: error) */
+int dc_forward_batch(dc_comm* comm, dc_net* const* nets, int nexec, const float* const* inputs, const int (*hw)[2], int n,
+                     float* const* prob, float* const* loc_pred, float* const* next_pred);
+int dc_comm_item_executor(dc_comm* comm, int i); /* which executor forwarded image i of the last call (negative: error) */
+int dc_comm_root_maps(dc_comm* comm, int i, const void** prob, const void** loc_pred, const void** next_pred, int dims[5]);
+/* the schedule alone (host only): exec_of_item[i] = executor of item i for `n` items of the given costs on `nexec` executors */
+int dc_lpt_schedule(const double* cost, int n, int nexec, int* exec_of_item);
 
 #ifdef __cplusplus
 }

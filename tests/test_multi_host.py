@@ -1,0 +1,80 @@
+"""CPU: the host-only parts of round 5's additions to the C ABI — the longest-processing-time-first schedule dc_forward_batch deals
+images by (dc_lpt_schedule == deepcut_tools.lpt_shards, the schedule of the one-process-per-GPU path), argument checking of
+dc_comm_* / dc_nets_choose_streams / dc_net_forward_host_async without a GPU (refused loudly, never computed elsewhere), and the
+result-array pool of the pycaffe shim (weak references, no reference-count arithmetic)."""
+import gc
+
+import numpy as np
+import pytest
+
+
+def test_lpt_schedule_equals_the_per_rank_schedule_of_the_distributed_path():
+    import caffe
+    from deepcut_tools import lpt_shards
+
+    rs = np.random.RandomState(5)
+    for n, k in ((0, 3), (1, 1), (7, 3), (64, 8), (128, 8), (33, 5), (5, 8)):
+        costs = [float(c) for c in rs.randint(1, 50, n) * 64]
+        assert caffe.lpt_schedule(costs, k) == lpt_shards(costs, k), (n, k)
+    # BASELINE configs[3]: 64 equal images on 8 executors -> 8 each, round robin
+    shares = caffe.lpt_schedule([544.0 * 736] * 64, 8)
+    assert [len(s) for s in shares] == [8] * 8 and shares[0] == list(range(0, 64, 8))
+    # configs[4]: 32 crops x 4 scales: the shares' loads differ by less than one largest item
+    hw = [(168, 128), (256, 192), (336, 256), (424, 320)]
+    costs = [float(h * w) for _ in range(32) for h, w in hw]
+    shares = caffe.lpt_schedule(costs, 8)
+    loads = [sum(costs[i] for i in s) for s in shares]
+    assert max(loads) - min(loads) <= max(costs) and sorted(i for s in shares for i in s) == list(range(128))
+    with pytest.raises(caffe.DeepcutError):
+        caffe.lpt_schedule([1.0], 0)
+
+
+def test_multi_gpu_entries_refuse_without_a_device_or_with_bad_arguments():
+    import caffe
+    import caffe.pycaffe as pc
+    from deepcut_tools import deepercut_prototxt
+
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    if caffe.device_count() == 0:
+        with pytest.raises(caffe.DeepcutError) as e:
+            caffe.Comm([net])
+        assert "no HIP device" in str(e.value)
+        with pytest.raises(caffe.DeepcutError):
+            caffe.pinned_empty((4,))
+    caffe.set_mode_cpu()
+    with pytest.raises(caffe.DeepcutError):  # no lowered shape, CPU mode: refused either way
+        caffe.choose_streams([net])
+    x = np.zeros((1, 3, 64, 64), np.float32)
+    with pytest.raises(caffe.DeepcutError):
+        net.forward_host_async(x)
+    with pytest.raises(ValueError):
+        net.forward_host_async(x.astype(np.float64))
+    assert pc._lib.dc_comm_destroy(None) == 0 and pc._lib.dc_host_free(None) == 0
+    assert pc._lib.dc_comm_transport(None) < 0 and pc._lib.dc_comm_item_executor(None, 0) < 0
+    assert pc._lib.dc_nets_choose_streams(None, 1, 0, 0, None, None) < 0
+    assert pc._lib.dc_forward_batch(None, None, 1, None, None, 0, None, None, None) < 0
+
+
+def test_result_arrays_are_recycled_only_when_no_view_is_left():
+    from caffe.pycaffe import _OutPool
+
+    pool = _OutPool()
+    a = pool.take((2, 3, 4))
+    a[...] = 7
+    view = a[1, :, 2]
+    b = pool.take((2, 3, 4))
+    assert not np.shares_memory(a, b)
+    del a
+    gc.collect()
+    c = pool.take((2, 3, 4))  # a view of the first hand-out is alive: its memory must not come back
+    assert not np.shares_memory(c, view) and float(view[0]) == 7
+    addr = view.__array_interface__["data"][0]
+    del view
+    gc.collect()
+    d = pool.take((2, 3, 4))  # now it does
+    lo = d.__array_interface__["data"][0]
+    assert lo <= addr < lo + d.nbytes
+    assert len(pool.entries) <= pool.keep
+    for _ in range(10):  # holding everything: the pool stops growing, new memory is simply not pooled
+        pool.take((2, 3, 4))
+    assert len(pool.entries) <= pool.keep

@@ -22,7 +22,7 @@ MODE=${1:?mode}; TAG=${2:?tag}; shift 2
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-QUIET="--no-cpu-baseline --no-f16-line --coalesce 0"
+QUIET="--no-cpu-baseline --no-f16-line --no-resnet101 --coalesce 0"
 seed_cache() {
   local src=${TUNE:-$(ls profiles/r*_tune_cache.txt 2>/dev/null | sort | tail -1)}
   rm -f $OUT/tune_cache.txt

@@ -21,7 +21,7 @@ PY
   done
   if [ "${2:-}" = pmc ]; then
     R=$PWD; cd /tmp; export TMPDIR=/tmp
-    CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --coalesce 0 --streams 1 --no-graph --steps 2 --warmup 1"
+    CMD="python $R/bench.py --no-cpu-baseline --no-f16-line --no-resnet101 --coalesce 0 --streams 1 --no-graph --steps 2 --warmup 1"
     timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$OUT/f_$v -o f -- $CMD > /dev/null 2>> $R/$OUT/err.txt
     timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$OUT/w_$v -o w -- $CMD > /dev/null 2>> $R/$OUT/err.txt
     cd $R

@@ -6,7 +6,7 @@ W=${1:-both}
 run() {  # run <label> <bench args...>  (environment of the caller)
   local label=$1; shift
   rm -f gpurun_out/insitu/tc.txt
-  DC_TUNE_CACHE=gpurun_out/insitu/tc.txt python bench.py --no-cpu-baseline --no-f16-line --coalesce 0 "$@" 2>>gpurun_out/insitu/err.txt |
+  DC_TUNE_CACHE=gpurun_out/insitu/tc.txt python bench.py --no-cpu-baseline --no-f16-line --no-resnet101 --coalesce 0 "$@" 2>>gpurun_out/insitu/err.txt |
     python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s value %7.1f  one at a time %7.1f' % ('$label', d['value'], d['one_forward_at_a_time']['value']))"
 }
 for rep in 1 2; do
