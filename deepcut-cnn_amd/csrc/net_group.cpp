@@ -491,6 +491,20 @@ void NetGroup::autotune(GroupPlan& gp) {
   if (timed_any) {
     ++stats.autotune_runs;
     write_tune_cache_locked(*n0.shared);
+    // the other cached plans of this group follow the table as well (same signatures at other shape sets)
+    for (auto& other : plans_) {
+      if (other.get() == &gp) continue;
+      bool touched = false;
+      for (auto& gl : other->launches) {
+        if (!gl.multi) continue;
+        auto it = cache.find(gl.key);
+        if (it != cache.end() && it->second != gl.variant) {
+          apply_variant(*other, gl, it->second);
+          touched = true;
+        }
+      }
+      if (touched) other->drop_graphs();
+    }
   }
   gp.drop_graphs();
 }
@@ -756,8 +770,17 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
     RuntimeLock rl;
     (void)hipDeviceSynchronize();
   }
-  for (auto& gl : cur_->launches)
-    if (gl.multi && gl.key == key) apply_variant(*cur_, gl, v);
+  // EVERY cached plan that carries the signature (other shape sets of this group share it through the model's table and the
+  // DC_TUNE_CACHE file: re-tiling only the current plan left them on the old tile — round-4 advice)
+  for (auto& gp : plans_) {
+    bool touched = false;
+    for (auto& gl : gp->launches)
+      if (gl.multi && gl.key == key && gl.variant != v) {
+        apply_variant(*gp, gl, v);
+        touched = true;
+      }
+    if (touched) gp->drop_graphs();
+  }
   {
     std::lock_guard<std::mutex> lk(nets[0]->shared->mu);
     auto it = nets[0]->shared->tune_cache.find(key);

@@ -85,6 +85,7 @@ inline int env_int(const char* k, int def) {
   return v ? std::atoi(v) : def;
 }
 uint64_t content_hash(const float* p, size_t n);               // net_lower.cpp
-void write_tune_cache_locked(const ModelShared& shared);      // net_tune.cpp
+void load_tune_cache_locked(ModelShared& shared);        // net_tune.cpp: DC_TUNE_CACHE file -> table (once per model)
+void write_tune_cache_locked(ModelShared& shared);       // net_tune.cpp: table (united with the file) -> file, atomically
 
 }  // namespace dc

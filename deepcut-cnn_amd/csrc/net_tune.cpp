@@ -1,16 +1,57 @@
 // net_tune.cpp — see net_internal.h: tile variants chosen by measurement, the tune-cache file, set_tile / reports.
+#include <unistd.h>
+
 #include "net_internal.h"
 
 namespace dc {
 
-void write_tune_cache_locked(const ModelShared& shared) {
+// DC_TUNE_CACHE=<file>: "<signature> <tile>" per line; group signatures (NetGroup) concatenate their members' and run to several
+// hundred characters, so lines are read whole and cut at the LAST blank.  Entries of the file never overwrite what this process
+// measured or was told (set_tile) since: the in-memory table wins.  Caller holds shared.mu.
+void load_tune_cache_locked(ModelShared& shared) {
+  if (shared.tune_file_loaded) return;
+  shared.tune_file_loaded = true;
   const char* cache_path = std::getenv("DC_TUNE_CACHE");
   if (!cache_path || !*cache_path) return;
-  if (FILE* f = std::fopen(cache_path, "w")) {
-    for (auto& kv : shared.tune_cache)
-      std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
-    std::fclose(f);
+  FILE* f = std::fopen(cache_path, "r");
+  if (!f) return;
+  std::string line;
+  int ch;
+  auto take = [&]() {
+    const size_t sp = line.find_last_of(' ');
+    if (sp != std::string::npos && sp > 0 && sp + 1 < line.size()) {
+      const std::string key = line.substr(0, sp), vname = line.substr(sp + 1);
+      int v = -1;
+      if (vname == "wino_f23") v = kWinoVariant;
+      for (int i = 0; i < conv_num_variants(); ++i)
+        if (vname == conv_variant(i).name) v = i;
+      if (v >= 0 && !shared.tune_cache.count(key)) shared.tune_cache[key] = v;
+    }
+    line.clear();
+  };
+  while ((ch = std::fgetc(f)) != EOF) {
+    if (ch == '\n' || ch == '\r') take();
+    else line.push_back((char)ch);
   }
+  take();
+  std::fclose(f);
+}
+
+// The file is always the union of what it held and what this process knows: it is LOADED first (a process that only ever calls
+// set_tile, or runs with DC_AUTOTUNE=0, used to truncate an existing cache to its one override: round-4 advice), and it is replaced
+// atomically (temporary file + rename: several ranks share one file, a reader must never see half of it).
+void write_tune_cache_locked(ModelShared& shared) {
+  const char* cache_path = std::getenv("DC_TUNE_CACHE");
+  if (!cache_path || !*cache_path) return;
+  load_tune_cache_locked(shared);
+  const std::string tmp = std::string(cache_path) + ".tmp." + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "w");
+  if (!f) return;
+  for (auto& kv : shared.tune_cache)
+    std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
+  const bool ok = std::fflush(f) == 0;
+  std::fclose(f);
+  if (!ok || std::rename(tmp.c_str(), cache_path) != 0) std::remove(tmp.c_str());
 }
 
 void Net::autotune() {
@@ -20,32 +61,7 @@ void Net::autotune() {
   // a service (or a profiling run) starts without the timing launches
   std::lock_guard<std::mutex> tune_lock(shared->mu);  // one executor times a shape, the clones reuse its choices
   std::map<std::string, int>& tune_cache_ = shared->tune_cache;
-  const char* cache_path = std::getenv("DC_TUNE_CACHE");
-  if (cache_path && !shared->tune_file_loaded) {
-    shared->tune_file_loaded = true;
-    if (FILE* f = std::fopen(cache_path, "r")) {
-      // one "<signature> <tile>" per line; group signatures (NetGroup) concatenate their members' and run to several hundred
-      // characters, so lines are read whole and cut at the LAST blank
-      std::string line;
-      int ch;
-      auto take = [&]() {
-        const size_t sp = line.find_last_of(' ');
-        if (sp != std::string::npos && sp > 0 && sp + 1 < line.size()) {
-          const std::string key = line.substr(0, sp), vname = line.substr(sp + 1);
-          if (vname == "wino_f23") tune_cache_[key] = kWinoVariant;
-          for (int v = 0; v < conv_num_variants(); ++v)
-            if (vname == conv_variant(v).name) tune_cache_[key] = v;
-        }
-        line.clear();
-      };
-      while ((ch = std::fgetc(f)) != EOF) {
-        if (ch == '\n' || ch == '\r') take();
-        else line.push_back((char)ch);
-      }
-      take();
-      std::fclose(f);
-    }
-  }
+  load_tune_cache_locked(*shared);
   size_t cached_before = tune_cache_.size();
   bool timed_any = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -203,7 +219,7 @@ void Net::autotune() {
     }
   }
   if (timed_any) ++stats.autotune_runs;
-  if (cache_path && (tune_cache_.size() != cached_before || timed_any)) write_tune_cache_locked(*shared);
+  if (tune_cache_.size() != cached_before || timed_any) write_tune_cache_locked(*shared);
   ++tile_gen_;
   release_graph();
 }

@@ -3,6 +3,7 @@ images by (dc_lpt_schedule == deepcut_tools.lpt_shards, the schedule of the one-
 dc_comm_* / dc_nets_choose_streams / dc_net_forward_host_async without a GPU (refused loudly, never computed elsewhere), and the
 result-array pool of the pycaffe shim (weak references, no reference-count arithmetic)."""
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -78,3 +79,46 @@ def test_result_arrays_are_recycled_only_when_no_view_is_left():
     for _ in range(10):  # holding everything: the pool stops growing, new memory is simply not pooled
         pool.take((2, 3, 4))
     assert len(pool.entries) <= pool.keep
+
+
+def test_set_tile_keeps_what_the_tune_cache_file_already_held(tmp_path, monkeypatch):
+    """Round-4 advice: write_tune_cache rewrote DC_TUNE_CACHE from the in-memory table, and the file was only loaded inside the
+    autotuner — a process that only ever overrides a tile (or runs with DC_AUTOTUNE=0) truncated an existing cache to its one
+    override.  The file is now loaded before any write, united with the table (the table wins) and replaced atomically."""
+    import caffe
+    from deepcut_tools import deepercut_prototxt
+
+    cache = tmp_path / "tune.txt"
+    names = [name for name, _es in caffe.conv_variants()]
+    old = ["f999/64/64/1x1/s1/r0 %s" % names[1], "some/other/model/signature %s" % names[2], "G4:a|b|c|d %s" % names[0], "3x3/eligible wino_f23"]
+    cache.write_text("\n".join(old) + "\n")
+    monkeypatch.setenv("DC_TUNE_CACHE", str(cache))
+    net = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    net.plan_text()  # lower (host only)
+    rep = net.tune_report()
+    tiles = [name for name, esize in caffe.conv_variants() if esize == 4]
+    done = None
+    for r in rep:
+        for t in tiles:
+            if t == r["tile"]:
+                continue
+            try:
+                net.set_tile(r["signature"], t)
+                done = (r["signature"], t)
+                break
+            except caffe.DeepcutError:
+                continue
+        if done:
+            break
+    assert done, "no signature took another tile"
+    lines = [ln for ln in cache.read_text().splitlines() if ln.strip()]
+    for ln in old:
+        assert ln in lines, ln  # nothing the file held was lost
+    assert "%s %s" % done in lines
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]  # the temporary file was renamed into place
+    # a second model in the same process: the file wins only where the process knows nothing
+    net2 = caffe.Net(deepercut_prototxt(152, 64, 64), caffe.TEST, from_text=True)
+    net2.plan_text()
+    net2.set_tile(done[0], [r for r in rep if r["signature"] == done[0]][0]["tile"])
+    lines = [ln for ln in cache.read_text().splitlines() if ln.strip()]
+    assert len([ln for ln in lines if ln.startswith(done[0] + " ")]) == 1 and all(ln in lines for ln in old)
