@@ -64,6 +64,23 @@ __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt
 // PAIR_FENCE (below): nothing is scheduled across it — inline asm orders memory operations only, and the MFMAs of one period
 // would otherwise drift into the next one
 
+// float32 + the low / high half of a packed float16 pair, rounded once (v_fma_mix_f32 h * 1.0 + f): conversion folded into the add
+__device__ __forceinline__ float pair_add_half_lo(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
+}
+__device__ __forceinline__ float pair_add_half_hi(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
+}
+__device__ __forceinline__ unsigned pair_relu_pk(unsigned h2) {  // max(x, 0) on both halves (after rounding: monotone, 0 is exact)
+  unsigned d;
+  asm("v_pk_max_f16 %0, %1, 0" : "=v"(d) : "v"(h2));
+  return d;
+}
+
 // Geometry of the filter image (shared by the kernel and the host packer).  Stage 2c holds chunk c of W2c: 64 rows (the chunk's
 // channels) of WD halves; stage 2c+1 holds chunk c of W2a: WD rows (output channels) of 64 halves in the permuted K order.
 // 16-byte pieces of a row are XOR-swizzled so that the 16 lanes a ds_read_b128 serves together hit 16 distinct bank groups.
@@ -109,6 +126,8 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 8192, KS1 = WD / 16, G2H = WD / 64;
   constexpr int RING = 0, SC = 3 * SB, XB = SC + 2 * 16384, CONSTS = XB + 16384, CONSTS2 = CONSTS + NC * 8;
   constexpr int LA = 4;   // filter fragments read ahead of the MFMA that uses them
+  constexpr int DF = G2H; // MFMAs of a period held back (their fragments are in registers) until the NEXT period's first reads are
+                          // in flight: every wave leaves the barrier with matrix work in hand instead of waiting out the LDS latency
   constexpr int NVM = NWI + 2;  // what every period's wait leaves in flight: the youngest stage's requests + 2 (see the order below)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
@@ -217,17 +236,28 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   pf32x16 sacc;
   unsigned xown[2][4], xnext[2][4];  // this role's two K steps of the chunk GEMM 2 consumes next / of the chunk after it
 
+  pf16x8 dwf1[DF], dwf2[DF], dxop;
+  auto flush1 = [&]() {  // the held-back tail of GEMM 1
+#pragma unroll
+    for (int i = 0; i < DF; ++i) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwf1[i], breg[KS1 - DF + i], sacc, 0, 0, 0);
+  };
+  auto flush2 = [&]() {  // ... of GEMM 2 (the last K step: one MFMA per output fragment of this role)
+#pragma unroll
+    for (int i = 0; i < DF; ++i) zacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwf2[i], dxop, zacc[i], 0, 0, 0);
+  };
   // GEMM 1 of this role's fragment of one chunk from ring slot `slot` -> sacc.  One step = one MFMA, pinned by a sched_barrier:
   // the fragment read LA steps ahead, the MFMA, and every few steps one piece of the period's memory work
-  auto gemm1 = [&](int slot, auto&& piece, auto np_tag) {
-    constexpr int NM = KS1, NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
+  auto gemm1 = [&](int slot, auto&& pre, auto&& piece, auto np_tag) {
+    constexpr int NM = KS1, NP = decltype(np_tag)::value, STRIDE = NP ? (NM - DF) / NP : NM;
     const unsigned char* st = lds + RING + slot * SB;
     pf16x8 wf[NM];
 #pragma unroll
     for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((n & 7) << 5)) + (n >> 3) * 256);
     PAIR_FENCE();
+    pre();  // the previous period's held-back MFMAs cover the latency of the reads above
+    PAIR_FENCE();
 #pragma unroll
-    for (int n = 0; n < NM; ++n) {
+    for (int n = 0; n < NM - DF; ++n) {
       if (n + LA < NM) {
         const int m = n + LA;
         if (PAIR_ABL & 16) wf[m] = wf[m - LA];
@@ -244,27 +274,29 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
       if (!(PAIR_ABL & 1) && NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
       PAIR_FENCE();
     }
+#pragma unroll
+    for (int i = 0; i < DF; ++i) dwf1[i] = wf[NM - DF + i];
   };
   // epilogue 1 of chunk c, this role's fragment, in parts j (4 channels of the lane's pixel each), split into the pieces the
   // pipeline places one by one
-  pf16x4 e_s8[2];
+  pu32x2 e_s8[2];
   pf32x4 e_a4[2], e_b4[2];
   float e_v[4];
   auto epi_load = [&](int c, int j) {  // the part's shortcut values and constants: LDS -> registers (issued one part ahead)
     const unsigned char* sb = lds + SC + (c & 1) * 16384;
     const unsigned char* cb = lds + CONSTS + (c * 64 + 32 * role + 4 * h) * 4;
-    e_s8[j & 1] = *reinterpret_cast<const pf16x4*>(sb + offs[j]);
+    e_s8[j & 1] = *reinterpret_cast<const pu32x2*>(sb + offs[j]);
     e_a4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + 8 * j * 4);
     e_b4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + NC * 4 + 8 * j * 4);
   };
-  auto epi_calc = [&](int j, int half) {  // two of the part's four values
-#pragma unroll
-    for (int r = 2 * half; r < 2 * half + 2; ++r)
-      e_v[r] = fmaxf(sacc[4 * j + r] * e_a4[j & 1][r] + e_b4[j & 1][r] + (float)e_s8[j & 1][r], 0.f);
+  auto epi_calc = [&](int j, int half) {  // two of the part's four values: acc * a + b, + shortcut (conversion folded into the add)
+    const unsigned sh = e_s8[j & 1][half];
+    e_v[2 * half] = pair_add_half_lo(sh, __builtin_fmaf(sacc[4 * j + 2 * half], e_a4[j & 1][2 * half], e_b4[j & 1][2 * half]));
+    e_v[2 * half + 1] = pair_add_half_hi(sh, __builtin_fmaf(sacc[4 * j + 2 * half + 1], e_a4[j & 1][2 * half + 1], e_b4[j & 1][2 * half + 1]));
   };
-  auto epi_store = [&](int c, int j, unsigned (&xn)[2][4]) {  // round, keep (GEMM 2's operand), put back into the shortcut buffer
+  auto epi_store = [&](int c, int j, unsigned (&xn)[2][4]) {  // round, ReLU, keep (GEMM 2's operand), put back into the shortcut buffer
     const pf16x2 lo = {(_Float16)e_v[0], (_Float16)e_v[1]}, hi = {(_Float16)e_v[2], (_Float16)e_v[3]};
-    const unsigned ulo = __builtin_bit_cast(unsigned, lo), uhi = __builtin_bit_cast(unsigned, hi);
+    const unsigned ulo = pair_relu_pk(__builtin_bit_cast(unsigned, lo)), uhi = pair_relu_pk(__builtin_bit_cast(unsigned, hi));
     // accumulator register i = 4j + r  ->  K step (j >> 1) of this role's two, slots t = 4*(j&1) + r
     xn[j >> 1][2 * (j & 1)] = ulo;
     xn[j >> 1][2 * (j & 1) + 1] = uhi;
@@ -272,11 +304,11 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   };
   // GEMM 2 of one chunk from ring slot `slot`: K steps [own 0, own 1, partner 0, partner 1] x this role's G2H output fragments;
   // EPI: epilogue 1 of chunk cn rides in the MFMAs' shadow -> xn
-  auto gemm2 = [&](int slot, const unsigned (&xo)[2][4], auto epi_tag, int cn, unsigned (&xn)[2][4], auto&& piece, auto np_tag) {
+  auto gemm2 = [&](int slot, const unsigned (&xo)[2][4], auto&& pre, auto epi_tag, int cn, unsigned (&xn)[2][4], auto&& piece, auto np_tag) {
     constexpr bool EPI = decltype(epi_tag)::value && !(PAIR_ABL & 2);
     constexpr int NM = 4 * G2H;
-    constexpr int NP = decltype(np_tag)::value, STRIDE = NP ? NM / NP : NM;
-    constexpr int SP = NM / 4;  // steps per epilogue part (4 or 2)
+    constexpr int NP = decltype(np_tag)::value, STRIDE = NP ? (NM - DF) / NP : NM;
+    constexpr int SP = (NM - DF) / 4;  // steps per epilogue part (3 or 1: the period's own steps are NM - DF)
     const unsigned char* st = lds + RING + slot * SB;
     pf16x8 xop[4];
 #pragma unroll
@@ -291,8 +323,10 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + (base2 ^ s4x[n / G2H]) + (n % G2H) * 32 * 128);
     if constexpr (EPI) epi_load(cn, 0);
     PAIR_FENCE();
+    pre();  // GEMM 1's held-back tail: covers the latency of the reads above and completes sacc for the epilogue below
+    PAIR_FENCE();
 #pragma unroll
-    for (int n = 0; n < NM; ++n) {
+    for (int n = 0; n < NM - DF; ++n) {
       if (n + LA < NM) {
         const int m = n + LA;
         if (PAIR_ABL & 16) wf[m] = wf[m - LA];
@@ -301,16 +335,17 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
       zacc[n % G2H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], xop[n / G2H], zacc[n % G2H], 0, 0, 0);
       if constexpr (EPI) {
         const int j = n / SP, q = n % SP;
-        if (SP == 4) {
-          if (q == 0 && j + 1 < 4) epi_load(cn, j + 1);
-          if (q == 1) epi_calc(j, 0);
-          if (q == 2) epi_calc(j, 1);
-          if (q == 3) epi_store(cn, j, xn);
-        } else {
-          if (q == 0) {
+        if (j < 4) {
+          if (SP >= 3) {
+            if (q == 0) {
+              if (j + 1 < 4) epi_load(cn, j + 1);
+              epi_calc(j, 0);
+            }
+            if (q == 1) epi_calc(j, 1);
+            if (q == 2) epi_store(cn, j, xn);
+          } else {  // one step per part
             if (j + 1 < 4) epi_load(cn, j + 1);
             epi_calc(j, 0);
-          } else {
             epi_calc(j, 1);
             epi_store(cn, j, xn);
           }
@@ -319,6 +354,9 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
       if (!(PAIR_ABL & 1) && NP && n % STRIDE == 0 && n / STRIDE < NP) piece(n / STRIDE);
       PAIR_FENCE();
     }
+#pragma unroll
+    for (int i = 0; i < DF; ++i) dwf2[i] = wf[NM - DF + i];
+    dxop = xop[3];
   };
   auto put_x = [&]() {  // this role's half of the chunk -> exchange buffer (behind a barrier: the partner is done with the previous one)
     *reinterpret_cast<pu32x4*>(lds + xb_own) = pu32x4{xown[0][0], xown[0][1], xown[0][2], xown[0][3]};
@@ -348,7 +386,10 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   pair_wait_vm<NVM>();
   pair_barrier();
   PAIR_FENCE();
-  gemm1(0, [&](int i) { dma_w_piece(2, 2, i); }, NP1{});
+  if (role) __builtin_amdgcn_s_setprio(1);  // the younger wave of each SIMD loses every arbitration at equal priority
+  gemm1(0, [] {}, [&](int i) { dma_w_piece(2, 2, i); }, NP1{});
+  PAIR_FENCE();
+  flush1();
   PAIR_FENCE();
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -373,7 +414,8 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     if (!(PAIR_ABL & 8)) put_x();
     if (!(PAIR_ABL & 4)) store_y(c);
     PAIR_FENCE();
-    gemm1(slot, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
+    if (c == 0) gemm1(slot, [] {}, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
+    else gemm1(slot, flush2, [&](int i) { dma_w_piece(2 * c + 3, slot2, i); }, NP1{});
     PAIR_FENCE();
     // ================= t = 2c+2: GEMM 2 of chunk c || epilogue 1 of chunk c+1
     stamp();
@@ -388,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
       for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 4; ++e) xo[a][e] = xown[a][e];
     PAIR_FENCE();
-    gemm2(slot1, xo, TagT{}, c + 1, xnext, [&](int i) {
+    gemm2(slot1, xo, flush1, TagT{}, c + 1, xnext, [&](int i) {
       if (i < NWI) dma_w_piece(2 * c + 4, slot, i);
       else dma_sc_piece(c + 2, i - NWI);
     }, NP2{});
@@ -415,8 +457,10 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
     unsigned xo[2][4];
     get_x(xo);
     PAIR_FENCE();
-    gemm2(slot, xo, TagF{}, 0, xnext, [](int) {}, NP0{});
+    gemm2(slot, xo, flush2, TagF{}, 0, xnext, [](int) {}, NP0{});
   }
+  PAIR_FENCE();
+  flush2();
   PAIR_FENCE();
   stamp();
 
