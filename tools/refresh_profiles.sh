@@ -12,8 +12,10 @@ TAG=${1:-r02p}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+# 0. the line exactly as the driver asks for it (fresh tuning, no cache), with the wall time of the whole command
+( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2> $OUT/bench_driver_style.err ) 2> $OUT/bench_driver_style.time
 export DC_TUNE_CACHE=$OUT/tune_cache.txt
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-f16-line --no-resnet101 --coalesce 0 --streams 1 --breakdown $OUT/per_launch.txt > $OUT/bench_s1.json 2>> $OUT/bench.err
 python tools/breakdown.py $OUT/per_launch.txt > $OUT/per_shape_summary.txt 2>> $OUT/bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-f16-line --no-resnet101 --coalesce 0 --dtype f16 --batch 8 --streams 2 --steps 20 --warmup 3 --breakdown $OUT/per_launch_f16_b8.txt > $OUT/bench_f16_batch8.json 2>> $OUT/bench.err
