@@ -201,3 +201,49 @@ def test_cxx_facade_drives_eight_executors(tmp_path, gpu_caffe, synth152, base_n
         got = np.fromfile(str(tmp_path / ("pool%d.bin" % i)), np.float32)
         ref = np.concatenate([want[k].ravel() for k in ("prob", "loc_pred", "next_pred")])
         assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max())), i
+
+
+def test_communicators_and_pipelines_leave_nothing_behind(gpu_caffe, base_net):
+    """Create / run / destroy cycles of the round-5 objects: 8-executor communicators (threads, communication streams, events, send /
+    receive / pinned buffers), executor sets that adopt pool streams, host pipelines with pinned arrays.  The first cycle pays for
+    what is process-wide by design (the stream pool, librccl.so); from the second on device memory, threads and file descriptors
+    may not grow."""
+    import gc
+    import threading
+
+    import torch
+
+    from deepcut_tools import Pipeline
+
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(3)
+    imgs = [(rs.randn(3, *SHAPES[i % 4]) * 50).astype(np.float32) for i in range(9)]
+
+    def cycle():
+        nets = [base_net] + [base_net.clone() for _ in range(7)]
+        comm = gpu_caffe.Comm(nets, devices=[0] * 8, transport="peer")
+        comm.forward(imgs)
+        c1 = gpu_caffe.Comm([base_net], transport="rccl")
+        c1.forward(imgs[:2])
+        pipe = Pipeline(nets[1], depth=3, coalesce=1)
+        x = gpu_caffe.pinned_empty((1, 3, 64, 80))
+        x[...] = rand_image(1, 64, 80)
+        outs = [gpu_caffe.pinned_empty(base_net.blobs[k].shape) for k in ("prob", "loc_pred", "next_pred")]
+        base_net.blobs["data"].reshape(1, 3, 64, 80)
+        base_net.reshape()
+        outs = [gpu_caffe.pinned_empty(tuple(base_net.blobs[k].shape)) for k in ("prob", "loc_pred", "next_pred")]
+        for i in range(4):
+            pipe.submit_host(x, *outs, tag=i)
+            pipe.drain()
+        del comm, c1, pipe, nets, x, outs
+        gc.collect()
+        torch.cuda.synchronize(dev)
+
+    rows = []
+    for c in range(5):
+        cycle()
+        rows.append((torch.cuda.mem_get_info(dev)[0] / 2 ** 20, threading.active_count(), len(os.listdir("/proc/self/fd")),
+                     len(os.listdir("/proc/self/task"))))
+    assert rows[1][0] - rows[-1][0] <= 2.0, rows      # device memory (MiB)
+    assert rows[-1][2] <= rows[1][2], rows            # file descriptors
+    assert rows[-1][3] <= rows[1][3], rows            # native threads (the communicators' workers are joined)
