@@ -111,21 +111,12 @@ int dc_host_alloc(size_t bytes, void** out) {
   if (bytes == 0) return fail(DC_EINVAL, "dc_host_alloc: zero bytes");
   return guard([&] {
     standalone_device();
-    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      *out = nullptr;
-      throw DcError(DC_EDEVICE, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
-    }
+    *out = host_alloc_pinned(bytes);
   });
 }
 int dc_host_free(void* p) {
   if (!p) return DC_OK;
-  return guard([&] {
-    if (hipHostFree(p) != hipSuccess) {
-      (void)hipGetLastError();
-      throw DcError(DC_EINVAL, "dc_host_free: not a dc_host_alloc pointer");
-    }
-  });
+  return guard([&] { host_free_pinned(p); });
 }
 int dc_nets_choose_streams(dc_net* const* nets, int n, int candidates, int reps, double* rate_chosen, double* rate_first) {
   REQUIRE(nets);

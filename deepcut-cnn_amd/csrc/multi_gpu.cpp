@@ -193,33 +193,42 @@ struct Comm {
 
 Comm::~Comm() {
   workers.clear();  // joins the threads
-  for (size_t k = 0; k < comm_stream.size(); ++k) {
+  for (size_t k = 0; k < devices.size(); ++k) {
     (void)hipSetDevice(devices[k]);
-    if (comm_stream[k]) (void)hipStreamDestroy((hipStream_t)comm_stream[k]);
-    if (fwd_done[k]) (void)hipEventDestroy((hipEvent_t)fwd_done[k]);
-    if (send[k].p) (void)hipFree(send[k].p);
-    if (stage[k].p) (void)hipHostFree(stage[k].p);
+    if (k < comm_stream.size() && comm_stream[k]) (void)hipStreamDestroy((hipStream_t)comm_stream[k]);
+    if (k < fwd_done.size() && fwd_done[k]) (void)hipEventDestroy((hipEvent_t)fwd_done[k]);
+    if (k < send.size()) dev_free(send[k].p);
+    if (k < recv.size()) dev_free(recv[k].p);
+    if (k < stage.size() && stage[k].p) {
+      try {
+        host_free_pinned(stage[k].p);
+      } catch (...) {
+      }
+    }
     if (k < nccl.size() && nccl[k] && rccl().ok()) (void)rccl().CommDestroy(nccl[k]);
   }
   if (!devices.empty()) (void)hipSetDevice(devices[0]);
-  for (auto& b : recv)
-    if (b.p) (void)hipFree(b.p);
-  if (host_out.p) (void)hipHostFree(host_out.p);
+  if (host_out.p) {
+    try {
+      host_free_pinned(host_out.p);
+    } catch (...) {
+    }
+  }
 }
+// device / pinned buffers grow only; allocation and release go through the runtime lock (they exclude graph captures, net_internal.h)
 void Comm::grow_dev(Buf& b, size_t bytes, int device) {
   if (b.cap >= bytes) return;
-  RuntimeLock rl;
   HIPCHECK(hipSetDevice(device));
-  if (b.p) (void)hipFree(b.p);
+  dev_free(b.p);
   b.p = nullptr, b.cap = 0;
-  HIPCHECK(hipMalloc(reinterpret_cast<void**>(&b.p), bytes));
+  dev_alloc(reinterpret_cast<void**>(&b.p), bytes);
   b.cap = bytes;
 }
 void Comm::grow_host(Buf& b, size_t bytes) {
   if (b.cap >= bytes) return;
-  if (b.p) (void)hipHostFree(b.p);
+  if (b.p) host_free_pinned(b.p);
   b.p = nullptr, b.cap = 0;
-  HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&b.p), bytes, hipHostMallocDefault));
+  b.p = reinterpret_cast<unsigned char*>(host_alloc_pinned(bytes));
   b.cap = bytes;
 }
 

@@ -418,6 +418,10 @@ struct NetGroup {
   void* stream();
 };
 
+// ---- runtime.cpp: pinned host memory (dc_host_alloc / dc_host_free) ---------------------------------------------------------
+void* host_alloc_pinned(size_t bytes);
+void host_free_pinned(void* p);
+
 // ---- multi_gpu.cpp: in-process multi-GPU forward (dc_comm_*, dc_forward_batch) ----------------------------------------------
 struct Comm;
 Comm* comm_create(int nexec, const int* devices, int transport);

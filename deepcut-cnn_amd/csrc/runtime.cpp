@@ -63,6 +63,24 @@ void dev_free(void* p) {
   RuntimeLock rl;
   (void)hipFree(p);
 }
+// pinned (page-locked) host memory: allocation and release are device-wide events like hipMalloc / hipFree and exclude graph captures
+void* host_alloc_pinned(size_t bytes) {
+  RuntimeLock rl;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    throw DcError(DC_EDEVICE, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+  }
+  return p;
+}
+void host_free_pinned(void* p) {
+  if (!p) return;
+  RuntimeLock rl;
+  if (hipHostFree(p) != hipSuccess) {
+    (void)hipGetLastError();
+    throw DcError(DC_EINVAL, "not a pinned allocation of this library");
+  }
+}
 void dev_alloc(void** p, size_t bytes) {
   RuntimeLock rl;
   HIPCHECK(hipMalloc(p, bytes));
