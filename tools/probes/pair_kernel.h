@@ -37,5 +37,7 @@ size_t pair_lds_bytes(int WD);
 void pair_pack_filters(const float* w1, const float* w2, int WD, unsigned short* out);
 long pair_grid(PairArgs& a);  // fills prob[].tile0, returns the workgroups
 int launch_pair_gemm(const PairArgs& a, long grid, void* stream);
+// the first layer alone in the same persistent form (Y only; reads the W2c stages of the same filter image)
+int launch_p2c_gemm(const PairArgs& a, long grid, void* stream);
 
 }  // namespace dc

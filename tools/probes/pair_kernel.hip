@@ -488,6 +488,195 @@ __global__ __launch_bounds__(512, 1) void pair_gemm_kernel(const PairArgs ka) {
   }
 }
 
+// =====================================================================================================================
+// The FIRST layer alone in the same persistent form (review item 2 of round 4: "a persistent form of the bandwidth-class layers"):
+//     Y = relu( (B · W2cᵀ) ∘ a1 + b1 + S )
+// A workgroup keeps its 128 pixels of B in registers and walks ALL 4·WD output channels in chunks of 64: per chunk one period —
+// GEMM 1 of chunk c (this role's fragment: WD/16 MFMAs) beside the epilogue of chunk c-1 — with the filter chunk, the shortcut
+// chunk (three buffers: requested two periods ahead) and the stores of Y (chunk c-2, whole 128-byte rows out of the shortcut buffer
+// the epilogue wrote them back into) spread over the period's MFMA steps.  It reads the pair kernel's filter image (the W2c stages).
+template <int WD>
+__global__ __launch_bounds__(512, 1) void p2c_gemm_kernel(const PairArgs ka) {
+  constexpr int NC = 4 * WD, NCH = NC / 64, SB = 128 * WD, NWI = SB / 8192, KS1 = WD / 16;
+  constexpr int RING = 0, SC = 3 * SB, CONSTS = SC + 3 * 16384;
+  constexpr int LA = 4;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pg = wave & 3, role = wave >> 2;
+  const int px = lane & 31, h = lane >> 5;
+  int k = 0;
+  const int tile = blockIdx.x;
+  for (int i = 1; i < kMaxPairProblems; ++i)
+    if (i < ka.nprob && tile >= ka.prob[i].tile0) k = i;
+  const PairProblem pr = ka.prob[k];
+  const int m0 = (tile - pr.tile0) * 128;
+  const int M = pr.M;
+  const int row = m0 + pg * 32 + px;
+  {
+    const pf32x4* src = reinterpret_cast<const pf32x4*>(ka.ab1);
+    pf32x4* dst = reinterpret_cast<pf32x4*>(lds + CONSTS);
+    for (int i = threadIdx.x; i < 2 * NC / 4; i += 512) dst[i] = src[i];
+  }
+  pf16x8 breg[KS1];
+  {
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pr.b), 0, (unsigned)M * WD * 2, 0x00020000);
+    const unsigned vo = (unsigned)row * (WD * 2) + h * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      breg[ks] = __builtin_bit_cast(pf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, row < M ? vo + ks * 32 : kPairOOB, 0, 0));
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" ::"v"(breg[ks]));
+  }
+  pair_wait_vm<0>();
+  __syncthreads();
+
+  const pi32x4 rw = pair_rsrc_words(ka.w, (unsigned)(2 * NCH) * SB);
+  const pi32x4 rs = pair_rsrc_words(pr.s, (unsigned)M * NC * 2);
+  const pi32x4 ryw = pair_rsrc_words(pr.y, (unsigned)M * NC * 2);
+  const unsigned lane16 = lane * 16;
+  unsigned sc_vo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rl = 32 * pg + 16 * role + 8 * i + (lane >> 3);
+    const int piece = (lane & 7) ^ ((rl >> 1) & 7);
+    sc_vo[i] = (m0 + rl < M) ? (unsigned)(m0 + rl) * (NC * 2) + piece * 16 : kPairOOB;
+  }
+  const unsigned sc_row0 = (32 * pg + 16 * role) * 128;
+  // chunk c's filter stage inside the pair image (its order of consumption: W2c[0], then (W2c[c+1], W2a[c]) ...)
+  auto dma_w_piece = [&](int c, int slot, int i) {
+    const int stage = c == 0 ? 0 : 2 * c - 1;
+    const unsigned piece = (unsigned)(wave + 8 * i) * 1024u;
+    pair_dma16(rw, RING + slot * SB + piece, c < NCH ? lane16 : kPairOOB, (unsigned)stage * SB + piece);
+  };
+  auto dma_sc_piece = [&](int c, int buf, int i) {
+    pair_dma16(rs, SC + buf * 16384 + sc_row0 + i * 1024, c < NCH ? sc_vo[i] : kPairOOB, (unsigned)c * 128u);
+  };
+  auto store_y = [&](int c, int buf) {
+    const unsigned char* sb = lds + SC + buf * 16384 + sc_row0 + lane16;
+    const pu32x4 v0 = *reinterpret_cast<const pu32x4*>(sb), v1 = *reinterpret_cast<const pu32x4*>(sb + 1024);
+    asm volatile("s_nop 0\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(v0), "v"(sc_vo[0]), "s"(ryw), "s"((unsigned)c * 128u) : "memory");
+    asm volatile("s_nop 0\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(v1), "v"(sc_vo[1]), "s"(ryw), "s"((unsigned)c * 128u) : "memory");
+  };
+  const unsigned base1 = (unsigned)pair_w1_off(WD, px, h) + role * (32 * WD * 2);
+  unsigned offs[4];
+  {
+    const int rl_own = 32 * pg + px;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offs[j] = rl_own * 128 + (((4 * role + j) ^ ((rl_own >> 1) & 7)) * 16) + h * 8;
+  }
+  pf32x16 sacc[2];
+  pu32x2 e_s8[2];
+  pf32x4 e_a4[2], e_b4[2];
+  float e_v[4];
+  if (role) __builtin_amdgcn_s_setprio(1);
+
+  // order of this wave's vector-memory operations: W(0) | SC(0) W(1) | c=0: SC(1) W(2) | c=1: SC(2) W(3) | c=2: Y(0)x2 SC(3) W(4) | ...
+  // period c needs W(c) and SC(c-1), both requested in period c-2: everything younger is what period c-1 issued (6 operations, 8 from c = 3 on)
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) dma_w_piece(0, 0, i);
+  dma_sc_piece(0, 0, 0);
+  dma_sc_piece(0, 0, 1);
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) dma_w_piece(1, 1, i);
+  int slot = 0, buf = 0;  // ring slot of chunk c's filters; shortcut buffer of chunk c
+  // one period (compile-time shape: with / without GEMM 1, with / without the epilogue of the chunk before)
+  auto run = [&](int c, auto mm_tag, auto epi_tag, pf32x16& acc_mm, const pf32x16& acc_epi) {
+    constexpr bool MM = decltype(mm_tag)::value, EPI = decltype(epi_tag)::value;
+    const int slot2 = slot + 2 >= 3 ? slot - 1 : slot + 2;   // chunk c+2's filters: the slot chunk c-1 sat in
+    const int buf1 = buf + 1 >= 3 ? buf - 2 : buf + 1;       // chunk c+1's shortcut: the buffer chunk c-2 sat in
+    const int bufm1 = buf - 1 < 0 ? buf + 2 : buf - 1;       // chunk c-1's
+    PAIR_FENCE();
+    if (c < 3) pair_wait_vm<NWI + 2>();
+    else pair_wait_vm<NWI + 4>();
+    pair_barrier();
+    PAIR_FENCE();
+    if (c >= 2) store_y(c - 2, buf1);  // finished in place by both roles during period c-1
+    PAIR_FENCE();
+    const unsigned char* st = lds + RING + slot * SB;
+    const unsigned char* sb = lds + SC + bufm1 * 16384;
+    const unsigned char* cb = lds + CONSTS + ((c - 1) * 64 + 32 * role + 4 * h) * 4;
+    pf16x8 wf[KS1];
+    if constexpr (MM) {
+#pragma unroll
+      for (int n = 0; n < LA; ++n) wf[n] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((n & 7) << 5)) + (n >> 3) * 256);
+    }
+    auto epi_load = [&](int j) {
+      e_s8[j & 1] = *reinterpret_cast<const pu32x2*>(sb + offs[j]);
+      e_a4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + 8 * j * 4);
+      e_b4[j & 1] = *reinterpret_cast<const pf32x4*>(cb + NC * 4 + 8 * j * 4);
+    };
+    auto epi_calc = [&](int j, int half) {
+      const unsigned sh = e_s8[j & 1][half];
+      e_v[2 * half] = pair_add_half_lo(sh, __builtin_fmaf(acc_epi[4 * j + 2 * half], e_a4[j & 1][2 * half], e_b4[j & 1][2 * half]));
+      e_v[2 * half + 1] = pair_add_half_hi(sh, __builtin_fmaf(acc_epi[4 * j + 2 * half + 1], e_a4[j & 1][2 * half + 1], e_b4[j & 1][2 * half + 1]));
+    };
+    auto epi_store = [&](int j) {
+      const pf16x2 lo = {(_Float16)e_v[0], (_Float16)e_v[1]}, hi = {(_Float16)e_v[2], (_Float16)e_v[3]};
+      *reinterpret_cast<pu32x2*>(lds + SC + bufm1 * 16384 + offs[j]) =
+          pu32x2{pair_relu_pk(__builtin_bit_cast(unsigned, lo)), pair_relu_pk(__builtin_bit_cast(unsigned, hi))};
+    };
+    if constexpr (EPI) epi_load(0);
+    PAIR_FENCE();
+    constexpr int SP = KS1 / 4;  // steps per epilogue part (4 or 2)
+#pragma unroll
+    for (int n = 0; n < KS1; ++n) {
+      if constexpr (MM) {
+        if (n + LA < KS1) {
+          const int m = n + LA;
+          wf[m] = *reinterpret_cast<const pf16x8*>(st + (base1 ^ ((m & 7) << 5)) + (m >> 3) * 256);
+        }
+        if (n == 0) {
+          pf32x16 zero;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+          acc_mm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n], zero, 0, 0, 0);
+        } else {
+          acc_mm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[n], breg[n], acc_mm, 0, 0, 0);
+        }
+      }
+      if constexpr (EPI) {
+        const int j = n / SP, q = n % SP;
+        if (SP == 4) {
+          if (q == 0 && j + 1 < 4) epi_load(j + 1);
+          if (q == 1) epi_calc(j, 0);
+          if (q == 2) epi_calc(j, 1);
+          if (q == 3) epi_store(j);
+        } else {
+          if (q == 0) {
+            if (j + 1 < 4) epi_load(j + 1);
+            epi_calc(j, 0);
+          } else {
+            epi_calc(j, 1);
+            epi_store(j);
+          }
+        }
+      }
+      // requests: this wave's 2 shortcut pieces of chunk c+1 and NWI filter pieces of chunk c+2, one every other step
+      if ((n & 1) == 0 && n / 2 < NWI + 2) {
+        const int i = n / 2;
+        if (i < 2) dma_sc_piece(c + 1, buf1, i);
+        else dma_w_piece(c + 2, slot2, i - 2);
+      }
+      PAIR_FENCE();
+    }
+    slot = slot + 1 >= 3 ? slot - 2 : slot + 1;
+    buf = buf1;
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+  run(0, TT{}, FF{}, sacc[0], sacc[1]);
+  for (int c = 1; c + 1 < NCH; c += 2) {
+    run(c, TT{}, TT{}, sacc[1], sacc[0]);
+    run(c + 1, TT{}, TT{}, sacc[0], sacc[1]);
+  }
+  run(NCH - 1, TT{}, TT{}, sacc[1], sacc[0]);
+  run(NCH, FF{}, TT{}, sacc[0], sacc[1]);
+  run(NCH + 1, FF{}, FF{}, sacc[0], sacc[1]);
+  pair_wait_vm<0>();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -566,6 +755,23 @@ int launch_pair_gemm(const PairArgs& a, long grid, void* stream) {
     } else {
       hipLaunchKernelGGL(pair_gemm_kernel<128>, dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
     }
+  }
+  return (int)hipGetLastError();
+}
+
+size_t p2c_lds_bytes(int WD) { return 3 * (size_t)pair_stage_bytes(WD) + 3 * 16384 + (size_t)4 * WD * 8; }
+int launch_p2c_gemm(const PairArgs& a, long grid, void* stream) {
+  if (!pair_supported(a.WD) || a.nprob < 1 || a.nprob > kMaxPairProblems || grid <= 0) return (int)hipErrorInvalidValue;
+  const size_t ldsb = p2c_lds_bytes(a.WD);
+  hipError_t e;
+  if (a.WD == 256) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&p2c_gemm_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(p2c_gemm_kernel<256>, dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&p2c_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(p2c_gemm_kernel<128>, dim3((unsigned)grid), dim3(512), ldsb, (hipStream_t)stream, a);
   }
   return (int)hipGetLastError();
 }

@@ -62,7 +62,7 @@ static std::vector<int> parse_list(const std::string& s) {
 }
 
 // one case: `Ms` = the tensors of the launch (one problem each)
-static int g_stamps = 0, g_nocheck = 0;
+static int g_stamps = 0, g_nocheck = 0, g_p2c = 0;
 static int run_case(int WD, const std::vector<int>& Ms, int reps, int check_rows, bool timing) {
   const int NC = 4 * WD;
   std::mt19937 rng(1234 + WD + (int)Ms.size());
@@ -206,6 +206,43 @@ static int run_case(int WD, const std::vector<int>& Ms, int reps, int check_rows
     std::printf("        %.2f us per launch   %.0f TFLOP/s (%.3f of 2.5 PF)   %.2f TB/s of algorithmic bytes (%.1f MB)\n", us, flops / us / 1e6,
                 flops / us / 1e6 / 2500.0, bytes / us / 1e6, bytes / 1e6);
   }
+  if (timing && !bad && g_p2c) {
+    // the first layer alone in the persistent form: Y must equal the pair kernel's Y (same arithmetic), then timing
+    std::vector<std::vector<unsigned short>> ypair(Ms.size());
+    for (size_t k = 0; k < Ms.size(); ++k) {
+      ypair[k].resize((size_t)Ms[k] * NC);
+      CK(hipMemcpy(ypair[k].data(), sets[0][k].y, ypair[k].size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemset(sets[0][k].y, 0xff, ypair[k].size() * 2 + 16));
+    }
+    int rc2 = launch_p2c_gemm(args[0], grid, nullptr);
+    CK(hipDeviceSynchronize());
+    long diff = 0;
+    for (size_t k = 0; k < Ms.size() && !rc2; ++k) {
+      std::vector<unsigned short> y2((size_t)Ms[k] * NC + 8);
+      CK(hipMemcpy(y2.data(), sets[0][k].y, y2.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ypair[k].size(); ++i) diff += y2[i] != ypair[k][i];
+      for (int e = 0; e < 8; ++e) diff += y2[ypair[k].size() + e] != 0xffff;
+    }
+    if (rc2 || diff) {
+      std::printf("        p2c: %s (%ld elements differ from the pair kernel's Y)  WRONG\n", rc2 ? hipGetErrorString((hipError_t)rc2) : "ran", diff);
+      bad++;
+    } else {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      for (int i = 0; i < 4; ++i) launch_p2c_gemm(args[i % nsets], grid, nullptr);
+      CK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < reps; ++i) launch_p2c_gemm(args[i % nsets], grid, nullptr);
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      float msec = 0;
+      CK(hipEventElapsedTime(&msec, e0, e1));
+      const double us = msec * 1e3 / reps;
+      const double bytes = (double)Mtot * (WD + NC + NC) * 2.0;
+      std::printf("        p2c (first layer alone, persistent form): Y identical; %.2f us per launch   %.0f TFLOP/s   %.2f TB/s of algorithmic bytes (%.1f MB)\n", us,
+                  2.0 * Mtot * NC * WD / us / 1e6, bytes / us / 1e6, bytes / 1e6);
+    }
+  }
   if (timing && !bad && g_stamps) {
     long long* d_dbg;
     CK(hipMalloc(&d_dbg, (size_t)grid * 256 * 8));
@@ -264,6 +301,7 @@ int main(int argc, char** argv) {
     else if (a == "--check-rows") check_rows = std::atoi(next().c_str());
     else if (a == "--stamps") g_stamps = 1;
     else if (a == "--no-check") g_nocheck = 1;
+    else if (a == "--p2c") g_p2c = 1;
   }
   int bad = 0;
   for (int WD : {256, 128}) {
