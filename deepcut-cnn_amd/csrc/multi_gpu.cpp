@@ -373,8 +373,10 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   if (transport == DC_COMM_RCCL && nexec > 1) {
     NCCLCHECK(rccl().GroupStart());
     for (int k = 1; k < nexec; ++k)
-      if (payload[(size_t)k]) {
+      if (payload[(size_t)k]) {  // (the device of the communicator a call is made on is made current first: one thread drives all of them)
+        HIPCHECK(hipSetDevice(devices[0]));
         NCCLCHECK(rccl().Recv(recv[(size_t)k].p, payload[(size_t)k], kNcclUint8, k, nccl[0], comm_stream[0]));
+        HIPCHECK(hipSetDevice(devices[(size_t)k]));
         NCCLCHECK(rccl().Send(send[(size_t)k].p, payload[(size_t)k], kNcclUint8, 0, nccl[(size_t)k], comm_stream[(size_t)k]));
       }
     NCCLCHECK(rccl().GroupEnd());
