@@ -911,8 +911,17 @@ class Comm(object):
         hw = (C.c_int * 2 * max(n, 1))()
         for i, x in enumerate(xs):
             hw[i][0], hw[i][1] = x.shape[1], x.shape[2]
-        chans = {key: self.nets[0].blobs[key].shape[1] for key in ("prob", "loc_pred", "next_pred")}
-        outs = [{key: np.empty((chans[key], x.shape[1] // 8, x.shape[2] // 8), np.float32) for key in want} for x in xs]
+        # the maps' shapes come from the net's own shape inference (host only), once per distinct image shape: the library
+        # writes C x h x w floats per map, so the arrays must be exactly that
+        dims = self.__dict__.setdefault("_map_dims", {})
+        for x in xs:
+            hw_ = (x.shape[1], x.shape[2])
+            if hw_ not in dims:
+                m0 = self.nets[0]
+                m0.blobs["data"].reshape(1, 3, *hw_)
+                m0.reshape()
+                dims[hw_] = {key: tuple(m0.blobs[key].shape[1:]) for key in ("prob", "loc_pred", "next_pred")}
+        outs = [{key: np.empty(dims[(x.shape[1], x.shape[2])][key], np.float32) for key in want} for x in xs]
 
         def col(key):
             if key not in want:

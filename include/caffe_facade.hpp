@@ -23,6 +23,7 @@
 #ifndef CAFFE_FACADE_HPP_
 #define CAFFE_FACADE_HPP_
 
+#include <array>
 #include <cctype>
 #include <memory>
 #include <stdexcept>
@@ -416,7 +417,7 @@ class ForwardPool {
     for (int i = 0; i < n; ++i) {
       shape[2 * i] = hw[i].first, shape[2 * i + 1] = hw[i].second;
       Maps& m = out[i];
-      m.map_h = hw[i].first / 8, m.map_w = hw[i].second / 8;
+      map_dims_(hw[i].first, hw[i].second, &m.map_h, &m.map_w);
       m.prob.resize((size_t)pc_ * m.map_h * m.map_w), m.loc_pred.resize((size_t)lc_ * m.map_h * m.map_w), m.next_pred.resize((size_t)nc_ * m.map_h * m.map_w);
       pp[i] = m.prob.data(), lp[i] = m.loc_pred.data(), np[i] = m.next_pred.data();
     }
@@ -428,8 +429,28 @@ class ForwardPool {
   int executor_of(int i) const { return dc_comm_item_executor(comm_, i); }
 
  private:
+  // the maps' height / width for an h x w input: the net's own shape inference (host only), once per distinct shape — the
+  // library writes C x map_h x map_w floats per map, so the vectors must be exactly that
+  void map_dims_(int h, int w, int* mh, int* mw) {
+    for (size_t i = 0; i < seen_.size(); ++i)
+      if (seen_[i][0] == h && seen_[i][1] == w) {
+        *mh = seen_[i][2], *mw = seen_[i][3];
+        return;
+      }
+    dc_blob *in = nullptr, *p = nullptr;
+    dc_check_(dc_net_blob(nets_[0], dc_net_input_name(nets_[0], 0), &in));
+    const int shape[4] = {1, 3, h, w};
+    dc_check_(dc_blob_reshape(in, 4, shape));
+    dc_check_(dc_net_reshape(nets_[0]));
+    dc_check_(dc_net_blob(nets_[0], "prob", &p));
+    int nd = 0, d[32];
+    dc_check_(dc_blob_shape(p, &nd, d));
+    *mh = d[2], *mw = d[3];
+    seen_.push_back({{h, w, d[2], d[3]}});
+  }
   dc_comm* comm_ = nullptr;
   std::vector<dc_net*> nets_;
+  std::vector<std::array<int, 4> > seen_;
   int pc_ = 0, lc_ = 0, nc_ = 0;
 };
 

@@ -96,8 +96,10 @@ SHAPES = [(64, 80), (48, 56), (64, 64), (56, 72)]
 
 def test_in_process_multi_executor_forward(gpu_caffe, base_net):
     rs = np.random.RandomState(9)
-    imgs = [(rs.randn(3, *SHAPES[i % 4]) * 50).astype(np.float32) for i in range(19)]
+    shapes5 = SHAPES + [(60, 76)]  # not a multiple of 8: the maps are 8 x 10 (ceil-mode pooling), not 60 // 8 x 76 // 8
+    imgs = [(rs.randn(3, *shapes5[i % 5]) * 50).astype(np.float32) for i in range(19)]
     want = [_maps(base_net, x[None]) for x in imgs]
+    assert want[4]["prob"].shape == (1, 14, 8, 10)
     # one executor, RCCL transport: dlopen + ncclCommInitAll on the one device; nothing to exchange
     c1 = gpu_caffe.Comm([base_net], transport="rccl")
     assert c1.transport == "rccl"
@@ -120,6 +122,7 @@ def test_in_process_multi_executor_forward(gpu_caffe, base_net):
         assert all(c8.executor_of(i) == kx for i in share)
     p, l, x, dims = c8.root_maps(3)
     assert p and l and x and dims == [14, 28, 364, SHAPES[3][0] // 8, SHAPES[3][1] // 8]
+    assert c8.root_maps(4)[3] == [14, 28, 364, 8, 10] and got[4]["next_pred"].shape == (364, 8, 10)
     assert c8.forward([]) == []
     with pytest.raises(gpu_caffe.DeepcutError):
         gpu_caffe.Comm([base_net, base_net], devices=[0, 0], transport="peer").forward(imgs[:2])  # one net, two executors
@@ -187,7 +190,8 @@ def test_cxx_facade_drives_eight_executors(tmp_path, gpu_caffe, synth152, base_n
     proto.write_text(deepercut_prototxt(152, 64, 80))
     rs = np.random.RandomState(12)
     n = 11
-    imgs = [(rs.randn(3, *SHAPES[i % 3]) * 50).astype(np.float32) for i in range(n)]
+    shapes = SHAPES[:3] + [(60, 76)]
+    imgs = [(rs.randn(3, *shapes[i % 4]) * 50).astype(np.float32) for i in range(n)]
     with open(str(tmp_path / "shapes.txt"), "w") as f:
         for i, x in enumerate(imgs):
             f.write("%d %d\n" % x.shape[1:])
