@@ -16,7 +16,8 @@
 //           way the 8-executor path is tested on a 1-GPU box);
 // on a communication stream per executor, ordered behind that executor's forwards by an event, so an executor that finishes early
 // sends while the others still compute.  The gathered maps stay on the root device until the next call (dc_comm_root_maps: the
-// decode kernels can consume them there) and are copied to the caller's host buffers if it gave any.
+// decode kernels can consume them there); the caller's host arrays, if it gave any, are filled by every executor for its own share,
+// from its own device over its own host link, on its own thread.
 #include <dlfcn.h>
 
 #include <condition_variable>
@@ -170,7 +171,7 @@ struct Comm {
   };
   std::vector<Buf> send, recv;  // send[k] on executor k's device; recv[k] on the root's (recv[0] unused: the root's maps are in send[0])
   std::vector<Buf> stage;       // pinned host: executor k's input batch
-  Buf host_out;                 // pinned host: the gathered maps on their way to the caller
+  std::vector<Buf> hout;        // pinned host: executor k's maps on their way to the caller's arrays
   // the last forward: what every executor ran (its same-shape groups, in order) and where every image's maps are
   struct Group {
     std::vector<int> idx;  // images of the group, batch position = position here
@@ -208,12 +209,13 @@ Comm::~Comm() {
     if (k < nccl.size() && nccl[k] && rccl().ok()) (void)rccl().CommDestroy(nccl[k]);
   }
   if (!devices.empty()) (void)hipSetDevice(devices[0]);
-  if (host_out.p) {
-    try {
-      host_free_pinned(host_out.p);
-    } catch (...) {
+  for (auto& b : hout)
+    if (b.p) {
+      try {
+        host_free_pinned(b.p);
+      } catch (...) {
+      }
     }
-  }
 }
 // device / pinned buffers grow only; allocation and release go through the runtime lock (they exclude graph captures, net_internal.h)
 void Comm::grow_dev(Buf& b, size_t bytes, int device) {
@@ -254,7 +256,7 @@ Comm* comm_create(int nexec, const int* devices, int transport) {
     NCCLCHECK(rccl().CommInitAll(c->nccl.data(), nexec, c->devices.data()));
   }
   c->transport = transport;
-  c->send.resize((size_t)nexec), c->recv.resize((size_t)nexec), c->stage.resize((size_t)nexec);
+  c->send.resize((size_t)nexec), c->recv.resize((size_t)nexec), c->stage.resize((size_t)nexec), c->hout.resize((size_t)nexec);
   c->comm_stream.assign((size_t)nexec, nullptr), c->fwd_done.assign((size_t)nexec, nullptr);
   for (int k = 0; k < nexec; ++k) {
     HIPCHECK(hipSetDevice(c->devices[(size_t)k]));
@@ -317,7 +319,7 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   // ---- every executor on its own thread: each group as one batch; the maps as NCHW float32 into its send buffer
   std::vector<size_t> payload((size_t)nexec, 0);
   for (int k = 0; k < nexec; ++k) {
-    workers[(size_t)k]->start([this, k, nets, inputs, &payload] {
+    workers[(size_t)k]->start([this, k, nets, inputs, &payload, prob, loc, next] {
       Net* net = nets[k];
       std::vector<Group>& gs = plan[(size_t)k];
       if (gs.empty()) return;
@@ -353,6 +355,26 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
       }
       payload[(size_t)k] = total;
       HIPCHECK(hipEventRecord((hipEvent_t)fwd_done[(size_t)k], (hipStream_t)net->stream));
+      // the caller's HOST arrays are filled here, by every executor for its own share and from its own device: the downloads use
+      // each GPU's own host link and the scatter runs on n threads (the gather below serves device-side consumers on the root)
+      if (prob || loc || next) {
+        grow_host(hout[(size_t)k], total);
+        HIPCHECK(hipMemcpyAsync(hout[(size_t)k].p, send[(size_t)k].p, total, hipMemcpyDeviceToHost, (hipStream_t)net->stream));
+        HIPCHECK(hipStreamSynchronize((hipStream_t)net->stream));
+        for (const Group& g : gs) {
+          const int nb = (int)g.idx.size();
+          const size_t cell = (size_t)g.mh * g.mw;
+          const float* pp = reinterpret_cast<const float*>(hout[(size_t)k].p + g.off);
+          const float* lp = pp + (size_t)nb * g.pc * cell;
+          const float* np = lp + (size_t)nb * g.lc * cell;
+          for (int b = 0; b < nb; ++b) {
+            const int i = g.idx[(size_t)b];
+            if (prob && prob[i]) std::memcpy(prob[i], pp + (size_t)b * g.pc * cell, (size_t)g.pc * cell * sizeof(float));
+            if (loc && loc[i]) std::memcpy(loc[i], lp + (size_t)b * g.lc * cell, (size_t)g.lc * cell * sizeof(float));
+            if (next && next[i]) std::memcpy(next[i], np + (size_t)b * g.nc * cell, (size_t)g.nc * cell * sizeof(float));
+          }
+        }
+      }
     });
   }
   std::string err;
@@ -396,27 +418,6 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   }
   HIPCHECK(hipSetDevice(devices[0]));
 
-  // ---- to the caller's host buffers, if it gave any: one device -> pinned host copy per executor payload, then per image
-  if (!(prob || loc || next)) return;
-  for (int k = 0; k < nexec; ++k) {
-    if (!payload[(size_t)k]) continue;
-    grow_host(host_out, payload[(size_t)k]);
-    HIPCHECK(hipMemcpyAsync(host_out.p, root_base(k), payload[(size_t)k], hipMemcpyDeviceToHost, (hipStream_t)comm_stream[0]));
-    HIPCHECK(hipStreamSynchronize((hipStream_t)comm_stream[0]));
-    for (const Group& g : plan[(size_t)k]) {
-      const int nb = (int)g.idx.size();
-      const size_t cell = (size_t)g.mh * g.mw;
-      const float* pp = reinterpret_cast<const float*>(host_out.p + g.off);
-      const float* lp = pp + (size_t)nb * g.pc * cell;
-      const float* np = lp + (size_t)nb * g.lc * cell;
-      for (int b = 0; b < nb; ++b) {
-        const int i = g.idx[(size_t)b];
-        if (prob && prob[i]) std::memcpy(prob[i], pp + (size_t)b * g.pc * cell, (size_t)g.pc * cell * sizeof(float));
-        if (loc && loc[i]) std::memcpy(loc[i], lp + (size_t)b * g.lc * cell, (size_t)g.lc * cell * sizeof(float));
-        if (next && next[i]) std::memcpy(next[i], np + (size_t)b * g.nc * cell, (size_t)g.nc * cell * sizeof(float));
-      }
-    }
-  }
 }
 
 void comm_forward(Comm* c, Net* const* nets, int nexec, const float* const* inputs, const int (*hw)[2], int n, float* const* prob, float* const* loc,
