@@ -184,6 +184,7 @@ struct Comm {
     int exec = -1, group = 0, pos = 0;
   };
   std::vector<Item> items;
+  std::mutex call_mu;  // one forward at a time per communicator (its buffers and workers are the call's)
 
   ~Comm();
   void grow_dev(Buf& b, size_t bytes, int device);
@@ -296,9 +297,11 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   }
   for (int i = 0; i < n; ++i)
     if (!inputs || !inputs[i] || hw[i][0] <= 0 || hw[i][1] <= 0) throw DcError(DC_EINVAL, "dc_forward_batch: image " + std::to_string(i) + ": null input or empty shape");
-  items.assign((size_t)n, Item());
+  std::lock_guard<std::mutex> one_call(call_mu);
+  items.clear();  // (a call that fails leaves no "last forward" behind: dc_comm_root_maps refuses)
   plan.assign((size_t)nexec, {});
   if (n == 0) return;
+  std::vector<Item> placed((size_t)n);
   // ---- the schedule (host only, deterministic): LPT over H*W, then per executor its same-shape groups in order of first appearance
   std::vector<double> cost((size_t)n);
   for (int i = 0; i < n; ++i) cost[(size_t)i] = (double)hw[i][0] * hw[i][1];
@@ -312,7 +315,7 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
         gs.emplace_back();
         gs[g].h = hw[i][0], gs[g].w = hw[i][1];
       }
-      items[(size_t)i].exec = k, items[(size_t)i].group = (int)g, items[(size_t)i].pos = (int)gs[g].idx.size();
+      placed[(size_t)i].exec = k, placed[(size_t)i].group = (int)g, placed[(size_t)i].pos = (int)gs[g].idx.size();
       gs[g].idx.push_back(i);
     }
 
@@ -343,7 +346,7 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
       grow_dev(send[(size_t)k], total, devices[(size_t)k]);
       for (Group& g : gs) {
         const int nb = (int)g.idx.size();
-        const size_t img = (size_t)3 * g.h * g.w, cell = (size_t)g.mh * g.mw;
+        const size_t img = (size_t)net->blobs[net->inputs[0]]->st->dim(1) * g.h * g.w, cell = (size_t)g.mh * g.mw;
         grow_host(stage[(size_t)k], nb * img * sizeof(float));
         float* st = reinterpret_cast<float*>(stage[(size_t)k].p);
         for (int b = 0; b < nb; ++b) std::memcpy(st + b * img, inputs[g.idx[(size_t)b]], img * sizeof(float));
@@ -394,13 +397,18 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
     }
   if (transport == DC_COMM_RCCL && nexec > 1) {
     NCCLCHECK(rccl().GroupStart());
-    for (int k = 1; k < nexec; ++k)
-      if (payload[(size_t)k]) {  // (the device of the communicator a call is made on is made current first: one thread drives all of them)
-        HIPCHECK(hipSetDevice(devices[0]));
-        NCCLCHECK(rccl().Recv(recv[(size_t)k].p, payload[(size_t)k], kNcclUint8, k, nccl[0], comm_stream[0]));
-        HIPCHECK(hipSetDevice(devices[(size_t)k]));
-        NCCLCHECK(rccl().Send(send[(size_t)k].p, payload[(size_t)k], kNcclUint8, 0, nccl[(size_t)k], comm_stream[(size_t)k]));
-      }
+    try {
+      for (int k = 1; k < nexec; ++k)
+        if (payload[(size_t)k]) {  // (the device of the communicator a call is made on is made current first: one thread drives all of them)
+          HIPCHECK(hipSetDevice(devices[0]));
+          NCCLCHECK(rccl().Recv(recv[(size_t)k].p, payload[(size_t)k], kNcclUint8, k, nccl[0], comm_stream[0]));
+          HIPCHECK(hipSetDevice(devices[(size_t)k]));
+          NCCLCHECK(rccl().Send(send[(size_t)k].p, payload[(size_t)k], kNcclUint8, 0, nccl[(size_t)k], comm_stream[(size_t)k]));
+        }
+    } catch (...) {
+      (void)rccl().GroupEnd();  // the group is never left open behind an error
+      throw;
+    }
     NCCLCHECK(rccl().GroupEnd());
   } else {
     for (int k = 1; k < nexec; ++k)
@@ -417,7 +425,7 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
     HIPCHECK(hipStreamSynchronize((hipStream_t)comm_stream[(size_t)k]));
   }
   HIPCHECK(hipSetDevice(devices[0]));
-
+  items = std::move(placed);  // only a forward that went through is "the last forward"
 }
 
 void comm_forward(Comm* c, Net* const* nets, int nexec, const float* const* inputs, const int (*hw)[2], int n, float* const* prob, float* const* loc,

@@ -123,7 +123,26 @@ def test_in_process_multi_executor_forward(gpu_caffe, base_net):
     p, l, x, dims = c8.root_maps(3)
     assert p and l and x and dims == [14, 28, 364, SHAPES[3][0] // 8, SHAPES[3][1] // 8]
     assert c8.root_maps(4)[3] == [14, 28, 364, 8, 10] and got[4]["next_pred"].shape == (364, 8, 10)
+    # two host threads on ONE communicator: the calls are serialised inside the library (ctypes drops the GIL), both complete
+    import threading
+
+    res = [None, None]
+
+    def call(j):
+        res[j] = c8.forward(imgs[j::2])
+
+    ths = [threading.Thread(target=call, args=(j,)) for j in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for j in range(2):
+        for got_i, i in zip(res[j], range(j, len(imgs), 2)):
+            for k in want[i]:
+                assert float(np.abs(got_i[k] - want[i][k][0]).max()) <= 1e-5 * max(1.0, float(np.abs(want[i][k]).max())), (j, i, k)
     assert c8.forward([]) == []
+    with pytest.raises(gpu_caffe.DeepcutError):
+        c8.root_maps(0)  # an empty call is the last forward now: nothing to point at
     with pytest.raises(gpu_caffe.DeepcutError):
         gpu_caffe.Comm([base_net, base_net], devices=[0, 0], transport="peer").forward(imgs[:2])  # one net, two executors
     with pytest.raises(gpu_caffe.DeepcutError):
