@@ -32,10 +32,15 @@ outs = [[torch.empty(1, c, H // 8, W // 8, device=dev) for c in (14, 28, 364)] f
 print("background load: %d executors ready" % S, flush=True)
 open(os.environ.get("DC_LOAD_READY", "/tmp/dc_load_ready"), "w").write("1")
 t_end, n = time.time() + secs, 0
+t_mark, n_mark = time.time(), 0
 while time.time() < t_end:
     for k, e in enumerate(nets):
         e.forward_device(x.data_ptr(), 1, H, W, outs[k][0].data_ptr(), outs[k][1].data_ptr(), outs[k][2].data_ptr(), stream="own")
     for e in nets:
         e.synchronize()
     n += S
+    now = time.time()
+    if now - t_mark >= 3.0:  # a line every 3 s (the caller may kill this process: what it did is on record)
+        print("background load: t=%.1f  %.1f images/s over the last %.1f s" % (now, (n - n_mark) / (now - t_mark), now - t_mark), flush=True)
+        t_mark, n_mark = now, n
 print("background load: %d forwards in %.0f s = %.1f images/s" % (n, secs, n / secs), flush=True)

@@ -17,7 +17,10 @@ rm -f /tmp/dc_load_ready
 python $R/tools/background_load.py 3 150 > $OUT/load.txt 2>&1 &
 LOAD=$!
 for i in $(seq 1 120); do [ -f /tmp/dc_load_ready ] && break; sleep 1; done
+sleep 7   # the neighbours alone: their own rate is on record before the profiled pass starts
+echo "profiled pass starts t=$(date +%s.%N)" >> $OUT/load_marks.txt
 timeout 300 rocprofv3 --kernel-trace --pmc $MF -d $OUT/loaded -o m -- $CMD > /dev/null 2> $OUT/loaded.err
+echo "profiled pass ends   t=$(date +%s.%N)" >> $OUT/load_marks.txt
 kill $LOAD 2>/dev/null; wait $LOAD 2>/dev/null
 cd $R
 for w in alone loaded; do
@@ -25,5 +28,5 @@ for w in alone loaded; do
   python tools/pmc_mfma_util.py $DB "rocprofv3 --kernel-trace --pmc $MF over one executor (bench.py --streams 1 --no-graph --steps 3), $w$( [ $w = loaded ] && echo ': three more executors of ANOTHER, unprofiled process keep batch-1 forwards in flight on the same GPU')" > $OUT/pmc_mfma_util_$w.txt 2> $OUT/post_$w.err
   tail -12 $OUT/pmc_mfma_util_$w.txt
 done
-cat $OUT/load.txt | tail -2
+cat $OUT/load_marks.txt; grep -c . $OUT/load.txt; head -4 $OUT/load.txt; tail -3 $OUT/load.txt
 rm -rf $OUT/alone $OUT/loaded
