@@ -5,6 +5,7 @@
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build container; the
 resulting .so travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,6 +16,59 @@ OUT = os.path.join(HERE, "lib", "libdeepcut_hip.so")
 SOURCES = ["formats.cpp", "hdf5_reader.cpp", "runtime.cpp", "net_init.cpp", "net_lower.cpp", "net_tune.cpp", "net_run.cpp", "net_image.cpp",
            "net_group.cpp", "streams.cpp", "multi_gpu.cpp", "c_api.cpp", "kernels.hip"]
 HEADERS = ["formats.h", "net.h", "net_internal.h", "kernels.h", os.path.join("..", "..", "include", "deepcut_hip.h")]
+
+
+KERNEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm"]
+ASM = os.path.join(HERE, "lib", "kernels.gfx950.s")
+
+
+def _asm_key():
+    """What the device assembly of kernels.hip depends on: the two sources, the flags, the compiler."""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(KERNEL_FLAGS).encode())
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    try:
+        h.update(subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout)
+    except OSError:
+        pass
+    return h.hexdigest()
+
+
+def _asm_fresh():
+    try:
+        return os.path.getsize(ASM) > 0 and open(ASM + ".key").read().strip() == _asm_key()
+    except OSError:
+        return False
+
+
+def _asm_job():
+    """The gfx950 assembly of kernels.hip (device side only, the library's own flags), as a process: what
+    tools/check_asm_hazards.py reads.  Started beside the object compile of build_lib so that the CPU test suite
+    (tests/test_asm_hazards.py) finds it ready instead of compiling the 2 300-line translation unit a second time."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(ASM), exist_ok=True)
+    for f in (ASM, ASM + ".key"):
+        if os.path.exists(f):
+            os.remove(f)
+    return subprocess.Popen([hipcc] + KERNEL_FLAGS + ["--offload-device-only", "-S", os.path.join(CSRC, "kernels.hip"), "-o", ASM + ".tmp"])
+
+
+def _asm_finish(proc, key):
+    if proc.wait() != 0:
+        raise RuntimeError("device assembly of kernels.hip failed")
+    os.replace(ASM + ".tmp", ASM)
+    with open(ASM + ".key", "w") as f:
+        f.write(key + "\n")
+
+
+def device_asm():
+    """Path of the gfx950 assembly of kernels.hip, compiled now unless the cached one matches the sources."""
+    if not _asm_fresh():
+        key = _asm_key()
+        _asm_finish(_asm_job(), key)
+    return ASM
 
 
 def _stale():
@@ -36,20 +90,22 @@ def build_lib(force=False, verbose=True):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     objs, jobs = [], []
+    asm = None
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src + ".o")
         objs.append(obj)
         sp = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_t, os.path.getmtime(sp)):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
-               "-c", sp, "-o", obj]
+        cmd = [hipcc] + KERNEL_FLAGS + ["-Wall", "-Wno-unused-function", "-c", sp, "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")
             cmd.insert(2, "hip")
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((src, subprocess.Popen(cmd)))
+        if src == "kernels.hip" and not _asm_fresh():
+            asm = (_asm_job(), _asm_key())
     failed = [src for src, p in jobs if p.wait() != 0]
     if failed:
         raise RuntimeError("compilation failed: %s" % ", ".join(failed))
@@ -57,6 +113,8 @@ def build_lib(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if asm:
+        _asm_finish(*asm)
     return OUT
 
 
