@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Inline-asm VMEM statements are invisible to the compiler's hazard recogniser.  On gfx950 a VALU instruction that writes an
 SGPR (v_readlane / v_readfirstlane / v_cmp ... to an SGPR pair) must be followed by 5 wait states before a VMEM instruction
-reads that SGPR.  This script scans the device assembly of kernels.hip (hipcc ... -save-temps) for inline-asm blocks
+reads that SGPR.  This script scans the device assembly of kernels.hip (hipcc --offload-device-only -S) for inline-asm blocks
 (;;#ASMSTART ... ;;#ASMEND) containing buffer_load and reports those whose scalar operands were written by a VALU
 instruction fewer than 5 wait states earlier (s_nop N counts N+1, every other instruction 1).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -c deepcut-cnn_amd/csrc/kernels.hip -save-temps=obj -o /tmp/k.o
-    python tools/check_asm_hazards.py /tmp/kernels-hip-amdgcn-amd-amdhsa-gfx950.s
+    python deepcut-cnn_amd/build.py            # leaves deepcut-cnn_amd/lib/kernels.gfx950.s (build.device_asm() makes it on demand)
+    python tools/check_asm_hazards.py deepcut-cnn_amd/lib/kernels.gfx950.s
 """
 import re
 import sys
