@@ -156,14 +156,19 @@ int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stre
 // ---- Winograd F(2x2, 3x3) for the stride-1, dilation-1, pad-1 3x3 convolutions (float32) -------------------------
 // Same ConvGemmParams as the gather-GEMM (x/y/resid/scale/shift/relu, NB, OH, OW, Cout, strides; klen = input channels,
 // x_rows = H, x_rowlen = W*klen); `w` is the transformed-filter image made by wino_pack_filters().
-constexpr int kWinoVariant = 1000;             // Launch::variant value that selects this kernel
+constexpr int kWinoVariant = 1000;             // Launch::variant value that selects this kernel: 8 waves per workgroup ("wino_f23")
+constexpr int kWinoVariant16 = 1001;           // ... its 16-wave form ("wino_f23_w16": launches of at most one workgroup per CU, kernels.hip)
+inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16; }
+const char* wino_variant_name(int variant);    // the tile name of tune caches / reports / set_tile
+const char* wino_kernel_label(int variant);    // the kernel column of plan texts
+int wino_variant_by_name(const char* name);    // -1: not a Winograd tile name
 bool wino_eligible(const ConvGemmParams& p);   // geometry / type the kernel takes
 long wino_grid(const ConvGemmParams& p);
 size_t wino_packed_floats(int Cout, int Cin);
 // g: [Cout][Cin][3][3] (Caffe order) -> U = G g G^T per (co, ci), laid out so that one wave's B-operand load is 1 KB
 // contiguous: [Cout/16][4 i][Cin/16][4 j][64 lanes][4]
 void wino_pack_filters(const float* g, int Cout, int Cin, float* out);
-int launch_wino_conv(const ConvGemmParams& p, void* stream);
+int launch_wino_conv(const ConvGemmParams& p, void* stream, int variant = kWinoVariant);
 
 // The remaining kernels take `esize` = bytes per device element (4 float / 2 _Float16); host-side tensors
 // and the per-channel affine vectors are always float.

@@ -201,7 +201,7 @@ void NetGroup::merge(GroupPlan& gp) {
       const size_t c = (size_t)mem[cc];
       const Launch& l = nets[c]->plan[i];
       const ConvGemmParams &g = l.cg, &g0 = l0.cg;
-      if (l.kind != Launch::CONV || l.variant == kWinoVariant || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift || l.c_off != l0.c_off ||
+      if (l.kind != Launch::CONV || is_wino_variant(l.variant) || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift || l.c_off != l0.c_off ||
           l.w_off != l0.w_off ||
           (l.in2 >= 0) != (l0.in2 >= 0) || g.esize != g0.esize || g.klen != g0.klen || g.sy != g0.sy || g.sx != g0.sx || g.Cout != g0.Cout ||
           g.relu != g0.relu || g.sigmoid_ch != g0.sigmoid_ch)
@@ -328,7 +328,7 @@ void NetGroup::merge(GroupPlan& gp) {
     if (!gl.multi) continue;
     int v = gl.variant;
     auto usable = [&](int cand) {
-      if (cand < 0 || cand >= conv_num_variants() || cand == kWinoVariant) return false;
+      if (cand < 0 || cand >= conv_num_variants() || is_wino_variant(cand)) return false;
       ConvGemmParams p = gl.p;
       ConvMultiTable t = gl.table;
       return prepare_conv_multi(p, t, gl.nprob, cand) > 0;

@@ -473,7 +473,8 @@ void Net::build_plan() {
       for (int c = 0; c < OC; ++c) h[c] = (float)((op.a.empty() ? 1.0 : op.a[c]) * (double)rs->row_scale[c]);
     });
   };
-  const int wino_mode = env_int("DC_WINOGRAD", -1);  // -1: where measured faster (autotune); 0: never; 1: wherever eligible
+  // -1: where measured faster (autotune); 0: never; 1: wherever eligible, 8 waves per workgroup; 2: wherever eligible, the 16-wave form
+  const int wino_mode = env_int("DC_WINOGRAD", -1);
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
     double bc = 0;
@@ -495,9 +496,9 @@ void Net::build_plan() {
     l.kernel = std::string("conv_gemm<") + conv_variant(best).name + ">";
     l.grid = conv_grid(l.cg, best);
   };
-  auto use_wino = [&](Launch& l) {
-    l.variant = kWinoVariant;
-    l.kernel = "wino_f23<4x8x16>";
+  auto use_wino = [&](Launch& l, int wv) {
+    l.variant = wv;
+    l.kernel = wino_kernel_label(wv);
     l.grid = wino_grid(l.cg);
   };
 
@@ -659,7 +660,7 @@ void Net::build_plan() {
           h.assign(wino_packed_floats(c.num_output, C), 0.f);
           wino_pack_filters(L.params[0]->st->host_ptr(), c.num_output, C, h.data());
         });
-        if (wino_mode == 1 && (force_variant < 0 || force_variant == kWinoVariant)) use_wino(l);
+        if (wino_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, wino_mode == 2 ? kWinoVariant16 : kWinoVariant);
       }
       if (l.wino_w || rowtap) plan.push_back(std::move(l));
       else push_split(std::move(l), kgcd);

@@ -97,7 +97,7 @@ void Net::run_launch(const Launch& l, void* s) {
       g.w = reinterpret_cast<const unsigned char*>(l.w->dev) + (size_t)l.w_off * (size_t)g.esize;
       g.scale = l.scale ? l.scale->dev + l.c_off : nullptr;
       g.shift = l.shift ? l.shift->dev + l.c_off : nullptr;
-      const bool wino = l.variant == kWinoVariant;  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer
+      const bool wino = is_wino_variant(l.variant);  // Winograd F(2x2,3x3) form of a stride-1 3x3 layer (8 or 16 waves per workgroup)
       if (wino) {
         if (!l.wino_w) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
         g.w = l.wino_w->dev;
@@ -110,7 +110,7 @@ void Net::run_launch(const Launch& l, void* s) {
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
         // device-side phase timestamps of ONE launch (diagnostics only): per wave the shader cycle counter at up to 8 phase
         // boundaries (slots 0..7) and the chip-wide 100 MHz clock at start / end (slots 8, 9)
-        const int nwv = wino ? 8 : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
+        const int nwv = wino ? (l.variant == kWinoVariant16 ? 16 : 8) : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
         const long n = (l.grid * 2 + 64) * nwv * 12;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         dev_alloc((void**)&d, n * sizeof(long long));
@@ -118,7 +118,7 @@ void Net::run_launch(const Launch& l, void* s) {
         for (int rep = 0; rep < 3; ++rep) {
           g.dbg = d;
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
-          if (wino) KCHECK(launch_wino_conv(g, s));
+          if (wino) KCHECK(launch_wino_conv(g, s, l.variant));
           else KCHECK(launch_conv_gemm(g, l.variant, s));
           HIPCHECK(hipStreamSynchronize((hipStream_t)s));
         }
@@ -158,7 +158,7 @@ void Net::run_launch(const Launch& l, void* s) {
         g.dbg = nullptr;
       }
       if (wino) {
-        KCHECK(launch_wino_conv(g, s));
+        KCHECK(launch_wino_conv(g, s, l.variant));
         break;
       }
       {

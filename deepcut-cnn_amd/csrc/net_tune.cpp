@@ -22,8 +22,8 @@ void load_tune_cache_locked(ModelShared& shared) {
     if (sp != std::string::npos && sp > 0 && sp + 1 < line.size()) {
       const std::string key = line.substr(0, sp), vname = line.substr(sp + 1);
       int v = -1;
-      if (vname == "wino_f23") v = kWinoVariant;
-      for (int i = 0; i < conv_num_variants(); ++i)
+      v = wino_variant_by_name(vname.c_str());
+      for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
         if (vname == conv_variant(i).name) v = i;
       if (v >= 0 && !shared.tune_cache.count(key)) shared.tune_cache[key] = v;
     }
@@ -48,7 +48,7 @@ void write_tune_cache_locked(ModelShared& shared) {
   FILE* f = std::fopen(tmp.c_str(), "w");
   if (!f) return;
   for (auto& kv : shared.tune_cache)
-    std::fprintf(f, "%s %s\n", kv.first.c_str(), kv.second == kWinoVariant ? "wino_f23" : conv_variant(kv.second).name);
+    std::fprintf(f, "%s %s\n", kv.first.c_str(), is_wino_variant(kv.second) ? wino_variant_name(kv.second) : conv_variant(kv.second).name);
   const bool ok = std::fflush(f) == 0;
   std::fclose(f);
   if (!ok || std::rename(tmp.c_str(), cache_path) != 0) std::remove(tmp.c_str());
@@ -106,11 +106,12 @@ void Net::autotune() {
       trial.variant = v;
       c.push_back({burst_ms(trial), v});
     }
-    if (l.wino_w) {  // the Winograd form of this layer competes with the direct tiles
-      Launch trial = l;
-      trial.variant = kWinoVariant;
-      c.push_back({burst_ms(trial), kWinoVariant});
-    }
+    if (l.wino_w)  // the Winograd forms of this layer (8 and 16 waves per workgroup) compete with the direct tiles
+      for (int wv : {kWinoVariant, kWinoVariant16}) {
+        Launch trial = l;
+        trial.variant = wv;
+        c.push_back({burst_ms(trial), wv});
+      }
     std::sort(c.begin(), c.end());
     tune_cache_[key] = c.empty() ? l.variant : c.front().second;
     shared->tune_timings[key] = c;
@@ -201,17 +202,67 @@ void Net::autotune() {
       }
     }
   }
+  // (2b) the two Winograd forms against each other, by whole passes over the plan.  They differ in how well a workgroup hides
+  // its own latencies (16 waves per workgroup: four per SIMD on launches of at most one workgroup per CU), which shows where a
+  // launch starts behind another kernel's tail on cold caches and hardly at all in a burst of identical launches or between
+  // hipEvents (res4 3x3 at 544x736, batch 1: 15.6 against 15.8 us timed alone, 1.25 us per launch inside the forward): where one
+  // of them was chosen and the other is eligible, both run in whole passes (no events inside) and the faster pass stays.
+  if (timed_any && env_int("DC_TUNE_INSITU", 1) != 0) {
+    std::vector<Launch> saved = plan;
+    struct Restore {
+      std::vector<Launch>& plan;
+      std::vector<Launch>& saved;
+      ~Restore() { plan = saved; }
+    } restore{plan, saved};
+    for (auto& l : plan) {  // the passes run with the tiles chosen so far (what (3) will put into the plan)
+      if (l.kind != Launch::CONV) continue;
+      auto it = tune_cache_.find(key_of(l));
+      if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.wino_w) &&
+          !(l.cg.ncls > 1 && (is_wino_variant(it->second) || !conv_variant_multiclass(it->second))))
+        l.variant = it->second;
+    }
+    auto pass_ms = [&]() {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {  // (the first pass warms)
+        HIPCHECK(hipEventRecord(e0, (hipStream_t)stream));
+        for (auto& l : plan) run_launch(l, stream);
+        HIPCHECK(hipEventRecord(e1, (hipStream_t)stream));
+        HIPCHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) best = std::min(best, ms);
+      }
+      return best;
+    };
+    for (auto& kv : timed) {
+      auto it = tune_cache_.find(kv.first);
+      if (it == tune_cache_.end() || !is_wino_variant(it->second)) continue;
+      bool both = false;
+      for (auto& c : kv.second) both = both || (is_wino_variant(c.second) && c.second != it->second);
+      if (!both) continue;
+      float ms[2];
+      const int forms[2] = {kWinoVariant, kWinoVariant16};
+      for (int f = 0; f < 2; ++f) {
+        for (auto& l : plan)
+          if (l.kind == Launch::CONV && l.wino_w && key_of(l) == kv.first) l.variant = forms[f];
+        ms[f] = pass_ms();
+      }
+      it->second = ms[1] < ms[0] ? kWinoVariant16 : kWinoVariant;
+      for (auto& l : plan)  // (later signatures are compared with this one's choice in place)
+        if (l.kind == Launch::CONV && l.wino_w && key_of(l) == kv.first) l.variant = it->second;
+    }
+  }
   // (3) the choices go into the plan
   for (auto& l : plan) {
     if (l.kind != Launch::CONV) continue;
     const ConvGemmParams& g = l.cg;
     auto it = tune_cache_.find(key_of(l));
     // a cache line naming the Winograd form while it is switched off (or not eligible any more): keep the cost model's tile
-    if (it != tune_cache_.end() && !(it->second == kWinoVariant && !l.wino_w) &&
-        !(g.ncls > 1 && (it->second == kWinoVariant || !conv_variant_multiclass(it->second))))
+    if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.wino_w) &&
+        !(g.ncls > 1 && (is_wino_variant(it->second) || !conv_variant_multiclass(it->second))))
       l.variant = it->second;
-    if (l.variant == kWinoVariant) {
-      l.kernel = "wino_f23<4x8x16>";
+    if (is_wino_variant(l.variant)) {
+      l.kernel = wino_kernel_label(l.variant);
       l.grid = wino_grid(l.cg);
     } else {
       l.kernel = std::string("conv_gemm<") + conv_variant(l.variant).name + ">";
@@ -253,7 +304,7 @@ std::string Net::tune_report_text() {
     if (it == seen.end()) order.push_back(k), seen[k] = {l.variant, 1};
     else ++it->second.second;
   }
-  auto vname = [](int v) { return std::string(v == kWinoVariant ? "wino_f23" : conv_variant(v).name); };
+  auto vname = [](int v) { return std::string(is_wino_variant(v) ? wino_variant_name(v) : conv_variant(v).name); };
   std::string out;
   for (auto& k : order) {
     out += k + "\t" + vname(seen[k].first) + "\t" + std::to_string(seen[k].second) + "\t";
@@ -273,8 +324,7 @@ std::string Net::tune_report_text() {
 // current plan that has the signature, recorded in the shared choice table (clones pick it up at their next lowering; call
 // set_tile on each executor to change their current plans), and the captured graph is dropped.
 void Net::set_tile(const std::string& key, const std::string& tile) {
-  int v = -1;
-  if (tile == "wino_f23") v = kWinoVariant;
+  int v = wino_variant_by_name(tile.c_str());
   for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
     if (tile == conv_variant(i).name) v = i;
   if (v < 0) throw DcError(DC_EINVAL, "no tile variant named '" + tile + "'");
@@ -282,7 +332,7 @@ void Net::set_tile(const std::string& key, const std::string& tile) {
   for (auto& l : plan) {
     if (l.kind != Launch::CONV || tune_key(l) != key) continue;
     const ConvGemmParams& g = l.cg;
-    const bool ok = v == kWinoVariant ? (bool)l.wino_w && g.ncls <= 1
+    const bool ok = is_wino_variant(v) ? (bool)l.wino_w && g.ncls <= 1
                                       : g.klen % conv_variant_bk(v) == 0 && conv_variant_esize(v) == g.esize && (g.ncls <= 1 || conv_variant_multiclass(v));
     if (!ok) throw DcError(DC_EUNSUP, "tile '" + tile + "' cannot take launch '" + l.label + "' (" + key + ")");
     any = true;
@@ -291,8 +341,8 @@ void Net::set_tile(const std::string& key, const std::string& tile) {
   for (auto& l : plan) {
     if (l.kind != Launch::CONV || tune_key(l) != key) continue;
     l.variant = v;
-    if (v == kWinoVariant) {
-      l.kernel = "wino_f23<4x8x16>";
+    if (is_wino_variant(v)) {
+      l.kernel = wino_kernel_label(v);
       l.grid = wino_grid(l.cg);
     } else {
       l.kernel = std::string("conv_gemm<") + conv_variant(v).name + ">";

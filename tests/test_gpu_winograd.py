@@ -1,5 +1,6 @@
 """-m gpu: the Winograd F(2x2,3x3) form of the stride-1 3x3 convolutions (kernels.hip wino_f23_kernel), forced with
-DC_WINOGRAD=1 (by default it is used only where the per-shape timing finds it faster), against the CPU oracle.
+DC_WINOGRAD=1 (8 waves per workgroup) and DC_WINOGRAD=2 (the 16-wave form, tile name wino_f23_w16); by default either is used
+only where the per-shape timing finds it faster.  Against the CPU oracle.
 Winograd changes the rounding (transforms in fp32), not the mathematics: the bound stays the path's 1e-3, measured ~1e-5."""
 import os
 
@@ -11,10 +12,11 @@ from conftest import rand_image
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _force(monkeypatch):
-    monkeypatch.setenv("DC_WINOGRAD", "1")
+@pytest.fixture(autouse=True, params=["1", "2"], ids=["w8", "w16"])
+def _force(monkeypatch, request):
+    monkeypatch.setenv("DC_WINOGRAD", request.param)
     monkeypatch.setenv("DC_AUTOTUNE", "0")
+    return "wino_f23<4x8x16_w16>" if request.param == "2" else "wino_f23<4x8x16>"
 
 
 def _oracle(proto, layers, img):
@@ -52,7 +54,7 @@ CASES = [  # n, cin, cout, h, w, dilation, relu, residual
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_single_layers_match_oracle(gpu_caffe, case):
+def test_single_layers_match_oracle(gpu_caffe, case, _force):
     n, cin, cout, h, w, dil, relu, resid = case
     if resid and cin != cout:
         pytest.skip("residual needs equal channel counts")
@@ -69,7 +71,7 @@ def test_single_layers_match_oracle(gpu_caffe, case):
     x = rs.randn(n, cin, h, w).astype(np.float32)
     net.blobs["data"].data[...] = x
     net.forward()
-    assert "wino_f23" in net.plan_text(), "the layer was not lowered to the Winograd kernel"
+    assert _force in net.plan_text(), "the layer was not lowered to the Winograd kernel"
     ref = _oracle(proto, weights, x)[out]
     got = net.blobs[out].data
     assert got.shape == ref.shape
@@ -78,7 +80,7 @@ def test_single_layers_match_oracle(gpu_caffe, case):
 
 
 @pytest.mark.parametrize("hw", [(104, 136), (240, 320)])
-def test_full_net_with_every_eligible_layer_in_winograd_form(gpu_caffe, synth152, hw):
+def test_full_net_with_every_eligible_layer_in_winograd_form(gpu_caffe, synth152, hw, _force):
     from deepcut_tools import deepercut_prototxt
 
     path, layers = synth152
@@ -88,7 +90,7 @@ def test_full_net_with_every_eligible_layer_in_winograd_form(gpu_caffe, synth152
     img = rand_image(3, h, w)
     net.blobs["data"].data[...] = img
     net.forward()
-    assert sum("wino_f23" in ln for ln in net.plan_text().splitlines()) == 50  # 47 plain + 3 dilated 3x3 layers
+    assert sum(_force in ln for ln in net.plan_text().splitlines()) == 50  # 47 plain + 3 dilated 3x3 layers
     ref = _oracle(proto, layers, img)
     for k in ("prob", "loc_pred", "next_pred"):
         assert float(np.abs(net.blobs[k].data - ref[k]).max()) <= 1e-3, k
@@ -101,6 +103,33 @@ def test_off_switch_and_float16_keep_the_direct_kernel(gpu_caffe, synth152, monk
     monkeypatch.setenv("DC_WINOGRAD", "0")
     net = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True)
     assert "wino" not in net.plan_text()
-    monkeypatch.setenv("DC_WINOGRAD", "1")
+    monkeypatch.setenv("DC_WINOGRAD", "2")
     half = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True, dtype="f16")
     assert "wino" not in half.plan_text()  # float32 only
+
+
+def test_the_two_forms_agree_and_are_deterministic(gpu_caffe, monkeypatch):
+    """The 16-wave form splits the channel sum of every staged step between two wave groups and adds the groups' partial sums in a
+    fixed order: run twice it gives the same bits, and it differs from the 8-wave form by float32 rounding only."""
+    proto, out = _conv_net(2, 256, 256, 34, 46, 1, True, False)
+    rs = np.random.RandomState(5)
+    wts = (rs.randn(256, 256, 3, 3) / np.sqrt(9.0 * 256)).astype(np.float32)
+    x = rs.randn(2, 256, 34, 46).astype(np.float32)
+    res = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("DC_WINOGRAD", mode)
+        net = gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True)
+        net.params["c"][0].data[...] = wts
+        net.params["bn"][0].data[...] = 0.0
+        net.params["bn"][1].data[...] = 1.0
+        net.params["bn"][2].data[...] = 1.0
+        net.params["sc"][0].data[...] = 1.0
+        net.params["sc"][1].data[...] = 0.0
+        net.blobs["data"].data[...] = x
+        net.forward()
+        a = net.blobs[out].data.copy()
+        net.blobs["data"].data[...] = x
+        net.forward()
+        assert np.array_equal(a, net.blobs[out].data), mode
+        res[mode] = a
+    assert float(np.abs(res["1"] - res["2"]).max()) <= 1e-5 * max(1.0, float(np.abs(res["1"]).max()))
