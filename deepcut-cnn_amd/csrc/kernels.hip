@@ -1528,6 +1528,7 @@ constexpr int WPITCH = 672;                              // floats per staged pi
 constexpr int WSTAGE = WRH * WPITCH + 8;                 // + the dump slot of the staging threads past the block
 constexpr int WNTH = 512;
 static_assert(WPITCH >= WRW * WPSTR && (2 * WPITCH) % 64 == 0 && WPSTR == 36, "conflict-free ds_read_b128 layout (see above)");
+static_assert(WPITCH % 4 == 0 && WPSTR % 4 == 0 && WSTAGE % 4 == 0, "16-byte units");
 __device__ __forceinline__ int wino_rowbase(int row) { return row * WPITCH; }
 __device__ __forceinline__ f32x2 wlo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 whi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
     const int iy = phy + d * (oy0 + py), ix = phx + d * (ox0 + px);
     const bool ok = pix < WRH * WRW && oy0 + py >= 0 && ox0 + px >= 0 && iy < H && ix < W;
     gofs[q] = ok ? (unsigned)(iy * p.x_row_stride + ix * C + cq * 4) * 4u : kOOB;
-    sofs[q] = pix < WRH * WRW ? wino_rowbase(py) + px * WPSTR + cq * 4 : WSTAGE - 8 + (t & 1) * 4;  // (past the block: the dump slot)
+    sofs[q] = (pix < WRH * WRW ? wino_rowbase(py) + px * WPSTR + cq * 4 : WSTAGE - 8 + (t & 1) * 4) >> 2;  // in float4 units (past the block: the dump slot)
   }
   const int r = (lane & 15) >> 3, c = lane & 7;
   const int ofs_a = wino_rowbase(2 * (2 * tf + r) + ra) + 2 * c * WPSTR + kg * 4;
@@ -1616,9 +1617,11 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
 #pragma unroll
     for (int q = 0; q < WNLD; ++q) g[q] = dc_bload4(xr, gofs[q], (unsigned)(K * WKC * 4));
   };
+  // (the stage is indexed in 16-byte units: the compiler cannot prove the alignment of a float index and would split every store
+  // into two ds_write2_b32, whose lanes — 16 bytes apart — collide four ways on the 32 write banks)
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < WNLD; ++q) *reinterpret_cast<f32x4*>(&stage[buf][sofs[q]]) = g[q];
+    for (int q = 0; q < WNLD; ++q) reinterpret_cast<f32x4*>(&stage[buf][0])[sofs[q]] = g[q];
   };
   auto bload = [&](int slot, int k16) {
 #pragma unroll
@@ -1655,6 +1658,10 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vh[j][1], b[bslot][j][3], acc[j], 0, 0, 0);
   };
   const int NS = C / WKC;
+  // the epilogue's per-channel constants are requested here (two registers carried through the K loop) instead of behind it,
+  // where their round trip was exposed
+  const int co = nt * WBN + (lane & 15);
+  const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
   stamp(1);
   // pipeline: global -> registers (3 steps ahead) -> LDS ring of 3 (2 steps ahead) -> MFMA; filters one sub-step ahead
   // the first two stages are requested together (a second register set, dead after the prologue) so that their
@@ -1671,7 +1678,7 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
   if (NS > 2) gload(2);
   if (NS > 1) {
 #pragma unroll
-    for (int q = 0; q < WNLD; ++q) *reinterpret_cast<f32x4*>(&stage[1][sofs[q]]) = g1[q];
+    for (int q = 0; q < WNLD; ++q) reinterpret_cast<f32x4*>(&stage[1][0])[sofs[q]] = g1[q];
   }
   stamp(3);
   if constexpr (NG == 1) {
@@ -1725,8 +1732,6 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
   __syncthreads();
   stamp(5);
   const int a = (wave >> 1) & 1, bq = wave & 1;  // this wave finalises output pixel (a, bq) of the tiles of fragment tf
-  const int co = nt * WBN + (lane & 15);
-  const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
   float* yb = reinterpret_cast<float*>(p.y);
   const float* rbp = reinterpret_cast<const float*>(p.resid);
   stamp(6);

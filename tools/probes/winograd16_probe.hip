@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v
 
 // NG = 1: the library's kernel (8 waves, both sub-steps per wave).  NG = 2: 16 waves, group g takes sub-step g of every staged step.
 // up: packed transformed filters [K/16][4 i][C/16][4 j][64 lanes][4]
-template <int NG, int LAY, int BUF>
+template <int NG, int LAY, int BUF, int PF = 0>
 __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restrict__ x, const float* __restrict__ up, float* __restrict__ y,
                                                                         long long* dbg) {
   constexpr int NTH = 512 * NG;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ub = up + ((long)(nt * 4 + i) * (C / 16)) * (4 * 64 * 4) + lane * 4;
-  f32x4 g[NLD], b[2][4], da[4], db[4];
+  f32x4 g[NLD], b[2][4], da[1 + PF][4], db[1 + PF][4];
   const __amdgpu_buffer_rsrc_t xr = mk_rsrc(x), ur = mk_rsrc(up);
   const unsigned uvo = (unsigned)(((nt * 4 + i) * (C / 16)) * (4 * 64 * 4) + lane * 4) * 4u;
   auto gload = [&](int Kk) {
@@ -110,7 +110,10 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NLD; ++q)
-      if (BUF || sofs[q] >= 0) *reinterpret_cast<f32x4*>(&stage[buf][sofs[q]]) = g[q];
+      if (BUF || sofs[q] >= 0) {
+        if (BUF) reinterpret_cast<f32x4*>(&stage[buf][0])[sofs[q] >> 2] = g[q];  // (indexed in 16-byte units: the compiler cannot prove the
+        else *reinterpret_cast<f32x4*>(&stage[buf][sofs[q]]) = g[q];              //  alignment of a float index and splits the store in two ds_write2_b32)
+      }
   };
   auto bload = [&](int slot, int k16) {
 #pragma unroll
@@ -119,20 +122,20 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
       else b[slot][j] = *reinterpret_cast<const f32x4*>(ub + ((long)k16 * 4 + j) * 256);
     }
   };
-  auto lread = [&](int buf, int h) {
+  auto lread = [&](int buf, int h, int slot = 0) {
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      da[c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_a + c4 * PSTR + h * 16]);
-      db[c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_b + c4 * PSTR + h * 16]);
+      da[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_a + c4 * PSTR + h * 16]);
+      db[slot][c4] = *reinterpret_cast<const f32x4*>(&stage[buf][ofs_b + c4 * PSTR + h * 16]);
     }
   };
-  auto compute = [&](int bslot) {
+  auto compute = [&](int bslot, int slot = 0) {
     f32x2 tl[4], th[4];
     const f32x2 sb2 = {sb, sb};
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
-      tl[c4] = lo2(da[c4]) + sb2 * lo2(db[c4]);
-      th[c4] = hi2(da[c4]) + sb2 * hi2(db[c4]);
+      tl[c4] = lo2(da[slot][c4]) + sb2 * lo2(db[slot][c4]);
+      th[c4] = hi2(da[slot][c4]) + sb2 * hi2(db[slot][c4]);
     }
     f32x2 vl[4], vh[4];
     vl[0] = tl[0] - tl[2], vh[0] = th[0] - th[2];
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
   if (NS > 1) {
 #pragma unroll
     for (int q = 0; q < NLD; ++q)
-      if (BUF || sofs[q] >= 0) *reinterpret_cast<f32x4*>(&stage[1][sofs[q]]) = g1[q];
+      if (BUF) reinterpret_cast<f32x4*>(&stage[1][0])[sofs[q] >> 2] = g1[q];
+      else if (sofs[q] >= 0) *reinterpret_cast<f32x4*>(&stage[1][sofs[q]]) = g1[q];
   }
   stamp(1);
   if constexpr (NG == 1) {
@@ -187,12 +191,22 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
     }
   } else {
     // group g computes sub-step g of every staged step; its filter fragments of the NEXT step are requested before the MFMAs
+    if (PF) {  // the first step's operands: stage 0 must be complete
+      __syncthreads();
+      lread(0, grp, 0);
+    }
     auto step = [&](int Kk, auto u_tag, auto s_tag) {
       constexpr int U = decltype(u_tag)::value, S = decltype(s_tag)::value;
       __syncthreads();
-      lread(U, grp);
-      bload(S ^ 1, Kk + 1 < NS ? 2 * (Kk + 1) + grp : 0);
-      compute(S);
+      if (PF) {  // this step's patch rows were read during the previous step; the next step's stage is complete behind this barrier
+        if (Kk + 1 < NS) lread((U + 1) % 3, grp, S ^ 1);
+        bload(S ^ 1, Kk + 1 < NS ? 2 * (Kk + 1) + grp : 0);
+        compute(S, S);
+      } else {
+        lread(U, grp);
+        bload(S ^ 1, Kk + 1 < NS ? 2 * (Kk + 1) + grp : 0);
+        compute(S);
+      }
       if (Kk + 2 < NS) sstore((U + 2) % 3);
       if (Kk + 3 < NS) gload(Kk + 3);
     };
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(512 * NG, 4) void wino_kernel(const float* __restri
   stamp(3);
 }
 
-template <int NG, int LAY, int BUF>
+template <int NG, int LAY, int BUF, int PF = 0>
 static void run(const char* name, const float* dx, const float* du, float* dy, const std::vector<float>& hx, const std::vector<float>& hw, int nsets,
                 size_t xs, size_t us, size_t ys) {
   const int grid = NBY * NBX * (K / BN);
@@ -240,9 +254,9 @@ static void run(const char* name, const float* dx, const float* du, float* dy, c
   long long* dd;
   CK(hipMalloc(&dd, (size_t)grid * NW * 4 * 8));
   CK(hipMemset(dy, 0, ys * 4));
-  hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF>), dim3(grid), dim3(512 * NG), 0, 0, dx, du, dy, dd);
+  hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF, PF>), dim3(grid), dim3(512 * NG), 0, 0, dx, du, dy, dd);
   CK(hipDeviceSynchronize());
-  hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF>), dim3(grid), dim3(512 * NG), 0, 0, dx, du, dy, dd);
+  hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF, PF>), dim3(grid), dim3(512 * NG), 0, 0, dx, du, dy, dd);
   CK(hipDeviceSynchronize());
   {
     std::vector<long long> hd((size_t)grid * NW * 4);
@@ -270,7 +284,7 @@ static void run(const char* name, const float* dx, const float* du, float* dy, c
     maxref = std::max(maxref, std::fabs(ref));
   }
   int occ = 0;
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wino_kernel<NG, LAY, BUF>, 512 * NG, 0));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wino_kernel<NG, LAY, BUF, PF>, 512 * NG, 0));
   printf("%s: grid %d x %d waves; max |err| %.3g (max |ref| %.3g); workgroups per CU %d\n", name, grid, NW, maxerr, maxref, occ);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -280,7 +294,7 @@ static void run(const char* name, const float* dx, const float* du, float* dy, c
     // operand sets rotated (as tools/probes/conv_probe does): inputs and filters come from the memory side, not from a warm L2
     for (int it = 0; it < 60; ++it) {
       const int s = it % nsets;
-      hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF>), dim3(grid), dim3(512 * NG), 0, 0, dx + s * xs, du + s * us, dy + s * ys, (long long*)nullptr);
+      hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF, PF>), dim3(grid), dim3(512 * NG), 0, 0, dx + s * xs, du + s * us, dy + s * ys, (long long*)nullptr);
     }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
@@ -293,7 +307,7 @@ static void run(const char* name, const float* dx, const float* du, float* dy, c
     CK(hipEventRecord(e0, 0));
     for (int it = 0; it < 20; ++it) {
       const int s = it % nsets;
-      hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF>), dim3(grid * mult), dim3(512 * NG), 0, 0, dx + s * xs, du + s * us, dy + s * ys, (long long*)nullptr);
+      hipLaunchKernelGGL((wino_kernel<NG, LAY, BUF, PF>), dim3(grid * mult), dim3(512 * NG), 0, 0, dx + s * xs, du + s * us, dy + s * ys, (long long*)nullptr);
     }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
@@ -338,10 +352,9 @@ int main() {
   }
   for (int round = 0; round < 1; ++round) {
     run<1, 0, 0>("8 waves, library layout     ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-    run<1, 1, 0>("8 waves, row pitch 672      ", dx, du, dy, hx, hw, nsets, xs, us, ys);
     run<1, 1, 1>("8 waves, pitch 672, buffer  ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-    run<2, 1, 0>("16 waves, row pitch 672     ", dx, du, dy, hx, hw, nsets, xs, us, ys);
     run<2, 1, 1>("16 waves, pitch 672, buffer ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+    run<2, 1, 1, 1>("16 waves, ..., LDS prefetch ", dx, du, dy, hx, hw, nsets, xs, us, ys);
   }
 
   return 0;
