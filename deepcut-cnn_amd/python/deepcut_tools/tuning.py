@@ -13,6 +13,12 @@ is set (dc_net_set_tile rewrites it); the reference has nothing to mirror here (
 """
 
 
+# the two forms of the Winograd kernel (8 / 16 waves per workgroup, csrc/kernels.hip): wherever one is in use the other is eligible, and
+# which one is faster is exactly a question of load (16 waves win a launch of at most one workgroup per CU running alone, 8 waves win as
+# soon as workgroups share CUs) — so the sibling is tried even for a signature whose choice came from a cache file, without timings
+_WINO_SIBLING = {"wino_f23": "wino_f23_w16", "wino_f23_w16": "wino_f23"}
+
+
 def tune_in_flight(nets, run, top=6, margin=1.20, min_gain=0.01, reps=3, max_candidates=2, log=None):
     """nets: the executors of ONE model (a net and its clones), all at the shape to tune, each having run a forward.
     run(): enqueue the representative load on the executors, synchronise, return the wall seconds.
@@ -30,6 +36,8 @@ def tune_in_flight(nets, run, top=6, margin=1.20, min_gain=0.01, reps=3, max_can
     have = [set(s["signature"] for s in n.tune_report()) for n in nets[1:]]
     ranked, skipped = [], 0
     for sig in report:
+        if len(sig["timed"]) < 2 and sig["tile"] in _WINO_SIBLING:
+            sig = dict(sig, timed=[(sig["tile"], 15.0), (_WINO_SIBLING[sig["tile"]], 15.0)])  # (nominal microseconds: ranking only)
         if len(sig["timed"]) < 2:
             skipped += 1  # the choice came from a cache file (no timings) or there is nothing to choose from
             continue

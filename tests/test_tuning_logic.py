@@ -65,6 +65,26 @@ def test_top_limits_the_signatures_walked():
     assert set(s for s, _ in log) == {"busy"} and len(res["changed"]) == 1
 
 
+def test_the_winograd_sibling_is_tried_even_without_isolated_timings():
+    """A choice read from a DC_TUNE_CACHE file carries no timings, and such signatures are left alone — except that the two forms of
+    the Winograd kernel (8 / 16 waves per workgroup) are each other's candidate by construction: which one wins IS a question of load."""
+    class Wino(FakeNet):
+        def set_tile(self, signature, tile):
+            for r in self.report:
+                if r["signature"] == signature:
+                    assert tile in ("wino_f23", "wino_f23_w16")
+                    r["tile"] = tile
+                    self.log.append((signature, tile))
+
+    log = []
+    rep = [{"signature": "res4 3x3+w", "tile": "wino_f23_w16", "launches": 36, "timed": []},
+           {"signature": "cached", "tile": "z", "launches": 50, "timed": []}]
+    nets = [Wino(rep, log), Wino(rep, log)]
+    res = tune_in_flight(nets, lambda: 1.0 if nets[0].report[0]["tile"] == "wino_f23_w16" else 0.95, reps=1)
+    assert [c[:3] for c in res["changed"]] == [("res4 3x3+w", "wino_f23_w16", "wino_f23")] and res["skipped"] == 1
+    assert all(n.report[0]["tile"] == "wino_f23" and n.report[1]["tile"] == "z" for n in nets)
+
+
 def test_nothing_to_tune_is_not_an_error():
     log = []
     nets = [FakeNet([REPORT[2], REPORT[3]], log)]

@@ -56,6 +56,7 @@ bench)
 check)
   export DC_TUNE_CACHE=$OUT/tune_cache.txt
   timeout 1100 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -5 $OUT/pytest.log
+  rm -f $DC_TUNE_CACHE  # (the driver's bench starts without a cache: tiles tuned in the process, tune_in_flight with isolated timings)
   timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json
   timeout 300 python bench.py $QUIET --streams 1 --breakdown $OUT/per_launch.txt > $OUT/bench_s1.json 2>> $OUT/bench.err; tail -3 $OUT/bench.err ;;
 probe)
