@@ -350,12 +350,13 @@ int main() {
     CK(hipMemcpy(dx + s * xs, hx.data(), xs * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(du + s * us, up.data(), us * 4, hipMemcpyHostToDevice));
   }
-  for (int round = 0; round < 1; ++round) {
-    run<1, 0, 0>("8 waves, library layout     ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-    run<1, 1, 1>("8 waves, pitch 672, buffer  ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-    run<2, 1, 1>("16 waves, pitch 672, buffer ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-    run<2, 1, 1, 1>("16 waves, ..., LDS prefetch ", dx, du, dy, hx, hw, nsets, xs, us, ys);
-  }
-
+  // <waves / 8, layout, buffer addressing, LDS reads ahead of the barrier>
+  run<1, 0, 0>("8 waves, round-1 layout, flat loads   ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<1, 1, 0>("8 waves, row pitch 672                ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<1, 1, 1>("8 waves, pitch 672, buffer (wino_f23) ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<2, 0, 0>("16 waves, round-1 layout              ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<2, 1, 0>("16 waves, row pitch 672               ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<2, 1, 1>("16 waves, pitch 672, buffer (_w16)    ", dx, du, dy, hx, hw, nsets, xs, us, ys);
+  run<2, 1, 1, 1>("16 waves, ..., reads ahead of barrier ", dx, du, dy, hx, hw, nsets, xs, us, ys);
   return 0;
 }
