@@ -1,0 +1,32 @@
+"""CPU: the Winograd kernel's LDS layout constants (kernels.hip: WPSTR, WPITCH) against the LDS bank model of MI355X_MICROARCH.md
+(tools/lds_bank_model.py): the patch-row reads must stay at 4 LDS cycles per ds_read_b128.  Round 1's layout paid 8 (two-way
+conflicts in every lane group) for four rounds; the PMC side of the same fact is tools/pmc_lds_conflicts.py."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import lds_bank_model as M  # noqa: E402
+
+
+def _constants():
+    src = open(os.path.join(ROOT, "deepcut-cnn_amd", "csrc", "kernels.hip")).read()
+    wkc = int(re.search(r"constexpr int WBTY = \d+, WBTX = \d+, WBN = \d+, WKC = (\d+);", src).group(1))
+    pad = int(re.search(r"constexpr int WPSTR = WKC \+ (\d+);", src).group(1))
+    pitch = int(re.search(r"constexpr int WPITCH = (\d+);", src).group(1))
+    return wkc + pad, pitch
+
+
+def test_the_winograd_patch_row_reads_are_conflict_free():
+    pixel_pitch, row_pitch = _constants()
+    assert row_pitch >= 18 * pixel_pitch and row_pitch % 4 == 0 and pixel_pitch % 4 == 0
+    assert M.wino_layout_cycles(pixel_pitch, row_pitch) == 4
+
+
+def test_the_model_sees_the_round_1_layout_as_two_way_conflicts():
+    assert M.wino_layout_cycles(36, 648, lambda row: 4 * ((row >> 1) & 1)) == 8
+    assert M.wino_layout_cycles(36, 648) == 8  # the skew was never the issue: the pitch of two rows must be a multiple of 64 floats
+    # the gather-GEMM's register-ring stage (rows of BK + 4 floats, lane -> row lane & 31, k offset 4 * (lane >> 5)): conflict-free
+    for bk in (32, 64):
+        assert M.ds_read_b128_cycles([(lane & 31) * (bk + 4) + 4 * (lane >> 5) for lane in range(64)]) == 4
