@@ -30,3 +30,17 @@ def test_the_model_sees_the_round_1_layout_as_two_way_conflicts():
     # the gather-GEMM's register-ring stage (rows of BK + 4 floats, lane -> row lane & 31, k offset 4 * (lane >> 5)): conflict-free
     for bk in (32, 64):
         assert M.ds_read_b128_cycles([(lane & 31) * (bk + 4) + 4 * (lane >> 5) for lane in range(64)]) == 4
+
+
+def test_the_lds_dma_swizzles_are_conflict_free_in_the_model_too():
+    """kernels.hip, LDS-DMA stages: 16-byte chunk c of row r sits at position c ^ swz(r), swz(r) = (r >> 1) & 7 for 128-byte rows and
+    r & 15 for 256-byte rows; the fragment reader (lane -> row lane & 31, chunk 2 q + (lane >> 5)) XORs the same term back.  The PMC
+    counters read 0.0 % conflicts for every such tile (profiles/r05_pmc_lds_conflicts*.txt): model and counters agree."""
+    for q in range(4):
+        addr = [((lane & 31) * 128 + ((2 * q + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) * 16) // 4 for lane in range(64)]
+        assert M.ds_read_b128_cycles(addr) == 4, q
+    for q in range(8):
+        addr = [((lane & 31) * 256 + ((2 * q + (lane >> 5)) ^ ((lane & 31) & 15)) * 16) // 4 for lane in range(64)]
+        assert M.ds_read_b128_cycles(addr) == 4, q
+    # without the swizzle a 128-byte-pitch stage collides: 32 rows on 2 distinct bank offsets
+    assert M.ds_read_b128_cycles([((lane & 31) * 128 + (lane >> 5) * 16) // 4 for lane in range(64)]) > 4
