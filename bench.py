@@ -338,6 +338,9 @@ def dry_run(args):
     gloo): process group, rank identities, the gather of payloads of exactly the size the real run sends (shapes from the
     prototxt, host only), barriers and the max-over-ranks timing, one JSON line marked `dry_run`.  `value` is null: nothing
     was forwarded."""
+    # (the host driver of these boxes supports dmabuf IPC only: without this RCCL's peer buffers fail with hipIpcGetMemHandle: invalid
+    # argument; the environment exports it already — kept here for a launcher that builds its own)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
