@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# The host driver of these boxes supports dmabuf IPC only: without this RCCL's peer buffers (and CUDA-tensor sharing across processes)
+# fail with `hipIpcGetMemHandle: invalid argument`.  Set before torch / the HIP runtime is loaded, in every process of the bench —
+# the launcher's children inherit it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "deepcut-cnn_amd")
 for p in (ROOT, PKG, os.path.join(PKG, "python")):
@@ -338,9 +343,6 @@ def dry_run(args):
     gloo): process group, rank identities, the gather of payloads of exactly the size the real run sends (shapes from the
     prototxt, host only), barriers and the max-over-ranks timing, one JSON line marked `dry_run`.  `value` is null: nothing
     was forwarded."""
-    # (the host driver of these boxes supports dmabuf IPC only: without this RCCL's peer buffers fail with hipIpcGetMemHandle: invalid
-    # argument; the environment exports it already — kept here for a launcher that builds its own)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -395,6 +397,26 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the run the way
+    the contract describes it — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>`, one rank per GPU — and hand its exit code back.  Rank 0's JSON line goes to
+    this process's stdout (the children inherit it)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -435,6 +457,8 @@ def main():
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = 8 if args.config == 3 else 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # started like the N=1 line: become the launcher
     if args.dry_run:
         return dry_run(args)
     if args.streams <= 0:  # forwards kept in flight: 4 at batch 1 (one per hardware queue of a HIP process), 2 at batch 8
@@ -450,7 +474,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("--gpus %d but WORLD_SIZE=1" % args.gpus)
     if args.backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())  # smoke test: ranks may share a device
     torch.cuda.set_device(local_rank)

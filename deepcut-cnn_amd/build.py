@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libdeepcut_hip.so")
 SOURCES = ["formats.cpp", "hdf5_reader.cpp", "runtime.cpp", "net_init.cpp", "net_lower.cpp", "net_tune.cpp", "net_run.cpp", "net_image.cpp",
-           "net_group.cpp", "streams.cpp", "multi_gpu.cpp", "c_api.cpp", "kernels.hip"]
+           "net_group.cpp", "streams.cpp", "multi_gpu.cpp", "c_api.cpp", "kernels.hip", "wino_f16.hip"]
 HEADERS = ["formats.h", "net.h", "net_internal.h", "kernels.h", os.path.join("..", "..", "include", "deepcut_hip.h")]
 
 
@@ -71,48 +71,95 @@ def device_asm():
     return ASM
 
 
+_HIPCC_VERSION = None
+
+
+def _hipcc_version():
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        try:
+            _HIPCC_VERSION = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        except OSError:
+            _HIPCC_VERSION = b""
+    return _HIPCC_VERSION
+
+
+def _obj_key(src):
+    """What an object depends on, by CONTENT: its source, every header, the flags, the compiler.  (Round 5 compared mtimes: a checkout
+    that rewinds sources under a newer .so shipped a stale library silently — the .so travels prebuilt to the GPU box.)"""
+    h = hashlib.sha256()
+    for f in [src] + HEADERS:
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(KERNEL_FLAGS).encode())
+    h.update(_hipcc_version())
+    return h.hexdigest()
+
+
+def _lib_key(keys):
+    return hashlib.sha256("\n".join(keys).encode()).hexdigest()
+
+
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    return _read(OUT + ".key") != _lib_key([_obj_key(s) for s in SOURCES])
 
 
 def build_lib(force=False, verbose=True):
-    """Per-file incremental: an object is rebuilt when its source or any header is newer (kernels.hip takes minutes, the host
-    translation units seconds each — they compile in parallel)."""
+    """Per-file incremental, keyed by content hashes (kernels.hip takes a minute, the host translation units seconds each — they
+    compile in parallel): an object is rebuilt when the hash of its source + the headers + the flags + the compiler differs from
+    the one recorded beside it, the library is re-linked when any object's key changed."""
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
-    objs, jobs = [], []
+    objs, jobs, keys = [], [], []
     asm = None
     for src in SOURCES:
         obj = os.path.join(HERE, "lib", src + ".o")
         objs.append(obj)
+        key = _obj_key(src)
+        keys.append(key)
         sp = os.path.join(CSRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_t, os.path.getmtime(sp)):
+        if not force and os.path.exists(obj) and _read(obj + ".key") == key:
             continue
+        if os.path.exists(obj + ".key"):
+            os.remove(obj + ".key")
         cmd = [hipcc] + KERNEL_FLAGS + ["-Wall", "-Wno-unused-function", "-c", sp, "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")
             cmd.insert(2, "hip")
         if verbose:
             print(" ".join(cmd), flush=True)
-        jobs.append((src, subprocess.Popen(cmd)))
+        jobs.append((src, obj, key, subprocess.Popen(cmd)))
         if src == "kernels.hip" and not _asm_fresh():
             asm = (_asm_job(), _asm_key())
-    failed = [src for src, p in jobs if p.wait() != 0]
+    failed = []
+    for src, obj, key, p in jobs:
+        if p.wait() != 0:
+            failed.append(src)
+        else:
+            with open(obj + ".key", "w") as f:
+                f.write(key + "\n")
     if failed:
         raise RuntimeError("compilation failed: %s" % ", ".join(failed))
+    if os.path.exists(OUT + ".key"):
+        os.remove(OUT + ".key")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(OUT + ".key", "w") as f:
+        f.write(_lib_key(keys) + "\n")
     if asm:
         _asm_finish(*asm)
     return OUT

@@ -158,7 +158,9 @@ int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stre
 // x_rows = H, x_rowlen = W*klen); `w` is the transformed-filter image made by wino_pack_filters().
 constexpr int kWinoVariant = 1000;             // Launch::variant value that selects this kernel: 8 waves per workgroup ("wino_f23")
 constexpr int kWinoVariant16 = 1001;           // ... its 16-wave form ("wino_f23_w16": launches of at most one workgroup per CU, kernels.hip)
-inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16; }
+constexpr int kWinoHalf = 1002;                // the float16 kernel (wino_f16.hip, "wino_h23"): fp16 operands, fp32 accumulate
+inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf; }
+inline int wino_variant_esize(int v) { return v == kWinoHalf ? 2 : 4; }  // element size of the nets the form serves
 const char* wino_variant_name(int variant);    // the tile name of tune caches / reports / set_tile
 const char* wino_kernel_label(int variant);    // the kernel column of plan texts
 int wino_variant_by_name(const char* name);    // -1: not a Winograd tile name
@@ -169,6 +171,13 @@ size_t wino_packed_floats(int Cout, int Cin);
 // contiguous: [Cout/16][4 i][Cin/16][4 j][64 lanes][4]
 void wino_pack_filters(const float* g, int Cout, int Cin, float* out);
 int launch_wino_conv(const ConvGemmParams& p, void* stream, int variant = kWinoVariant);
+// ---- the same for a float16 net (wino_f16.hip): `w` is the image made by wino_half_pack_filters() uploaded as _Float16, `scale`
+// must carry the extra factors 4 (the staged pixels are pre-multiplied by 1/4) and row_scale[co]; no shortcut operand
+bool wino_half_eligible(const ConvGemmParams& p);
+long wino_half_grid(const ConvGemmParams& p);
+size_t wino_half_packed_elems(int Cout, int Cin);
+void wino_half_pack_filters(const float* g, int Cout, int Cin, bool rowscale, float* out, float* row_scale);
+int launch_wino_half(const ConvGemmParams& p, void* stream);
 
 // The remaining kernels take `esize` = bytes per device element (4 float / 2 _Float16); host-side tensors
 // and the per-channel affine vectors are always float.

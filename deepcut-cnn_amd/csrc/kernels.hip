@@ -1761,6 +1761,7 @@ __global__ __launch_bounds__(WNTH * NG, 4) void wino_f23_kernel(const ConvGemmPa
 }
 
 bool wino_eligible(const ConvGemmParams& p) {
+  if (p.esize == 2) return wino_half_eligible(p);  // the float16 kernel (wino_f16.hip)
   const int d = p.ddy;  // dilation (1 or more), the same along x and y, with pad = dilation ("same" convolution)
   if (p.esize != 4 || p.nty != 3 || p.ntx != 3 || p.sy != 1 || d < 1 || d > 4 || p.dy0 != -d) return false;
   const int C = p.klen;
@@ -1774,6 +1775,7 @@ bool wino_eligible(const ConvGemmParams& p) {
 }
 
 long wino_grid(const ConvGemmParams& p) {
+  if (p.esize == 2) return wino_half_grid(p);
   const int d = p.ddy;
   const int TY = ((p.OH + d - 1) / d + 1) / 2, TX = ((p.OW + d - 1) / d + 1) / 2;
   return (long)p.NB * d * d * ((TY + WBTY - 1) / WBTY) * ((TX + WBTX - 1) / WBTX) * (p.Cout / WBN);
@@ -1799,16 +1801,19 @@ void wino_pack_filters(const float* g, int Cout, int Cin, float* out) {
     }
 }
 
-const char* wino_variant_name(int variant) { return variant == kWinoVariant16 ? "wino_f23_w16" : "wino_f23"; }
-const char* wino_kernel_label(int variant) { return variant == kWinoVariant16 ? "wino_f23<4x8x16_w16>" : "wino_f23<4x8x16>"; }
+const char* wino_variant_name(int variant) { return variant == kWinoHalf ? "wino_h23" : variant == kWinoVariant16 ? "wino_f23_w16" : "wino_f23"; }
+const char* wino_kernel_label(int variant) {
+  return variant == kWinoHalf ? "wino_h23<2x4x8x64>" : variant == kWinoVariant16 ? "wino_f23<4x8x16_w16>" : "wino_f23<4x8x16>";
+}
 int wino_variant_by_name(const char* name) {
-  for (int v : {kWinoVariant, kWinoVariant16})
+  for (int v : {kWinoVariant, kWinoVariant16, kWinoHalf})
     if (name && std::strcmp(name, wino_variant_name(v)) == 0) return v;
   return -1;
 }
 
 int launch_wino_conv(const ConvGemmParams& p, void* stream, int variant) {
-  if (!wino_eligible(p) || !is_wino_variant(variant)) return (int)hipErrorInvalidValue;
+  if (variant == kWinoHalf) return launch_wino_half(p, stream);
+  if (p.esize != 4 || !wino_eligible(p) || !is_wino_variant(variant)) return (int)hipErrorInvalidValue;
   const long grid = wino_grid(p);
   if (grid <= 0) return 0;
   if (grid > 0x7fffffffL) return (int)hipErrorInvalidValue;

@@ -655,12 +655,32 @@ void Net::build_plan() {
       choose_variant(l, kgcd);
       // stride-1 3x3 layers can also run as Winograd F(2x2,3x3): keep the transformed filters next to the direct ones
       // and let the per-shape timing decide (kernels.hip, wino_f23_kernel)
-      if (!rowtap && wino_mode != 0 && op.wls.empty() && wino_eligible(g)) {
+      if (!rowtap && wino_mode != 0 && op.wls.empty() && wino_eligible(g) && dtype == 0) {
         l.wino_w = get_vec(dkey + "wino:" + std::to_string(op.wl), [&](std::vector<float>& h) {
           h.assign(wino_packed_floats(c.num_output, C), 0.f);
           wino_pack_filters(L.params[0]->st->host_ptr(), c.num_output, C, h.data());
         });
         if (wino_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, wino_mode == 2 ? kWinoVariant16 : kWinoVariant);
+      } else if (!rowtap && wino_mode != 0 && op.wls.empty() && dtype == 1 && op.in2 < 0 && wino_eligible(g)) {
+        // float16 (wino_f16.hip): the image is packed in MFMA fragment order with its own per-channel power-of-two row scale
+        // (DevVec::row_scale: G g G^T has other maxima than g); the form's epilogue scale = folded affine x row scale x 4 (the
+        // kernel stages the pixels pre-multiplied by 1/4 so that B^T d B cannot overflow float16)
+        std::vector<float> rs_made;  // filled only if the image is packed now (else the DevVec found in the cache carries its row scale)
+        l.wino_w = get_vec(dkey + "wino:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          h.assign(wino_half_packed_elems(c.num_output, C), 0.f);
+          rs_made.assign(c.num_output, 1.f);
+          wino_half_pack_filters(L.params[0]->st->host_ptr(), c.num_output, C, half_rowscale, h.data(), rs_made.data());
+        });
+        if (!rs_made.empty()) l.wino_w->row_scale = std::move(rs_made);
+        l.wino_w->as_half = true;
+        std::shared_ptr<DevVec> ws = l.wino_w;
+        char wkey[40];
+        std::snprintf(wkey, sizeof wkey, "%p", (void*)ws.get());
+        l.wino_scale = get_vec(std::string("hwa:") + wkey + ":" + std::to_string(op.lids.front()) + ":" + std::to_string(op.lids.size()), [&](std::vector<float>& h) {
+          h.resize(OC);
+          for (int q = 0; q < OC; ++q) h[q] = (float)((op.a.empty() ? 1.0 : op.a[q]) * 4.0 * (double)(ws->row_scale.empty() ? 1.f : ws->row_scale[q]));
+        });
+        if (wino_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kWinoHalf);
       }
       if (l.wino_w || rowtap) plan.push_back(std::move(l));
       else push_split(std::move(l), kgcd);

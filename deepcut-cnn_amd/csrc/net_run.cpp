@@ -22,7 +22,7 @@ void Net::upload_vecs() {
   std::lock_guard<std::mutex> lk(shared->mu);  // an image may be shared with a clone that uploads at the same moment
   std::vector<DevVec*> todo;
   for (auto& l : plan)
-    for (const std::shared_ptr<DevVec>* vp : {&l.w, &l.scale, &l.shift, &l.wino_w})
+    for (const std::shared_ptr<DevVec>* vp : {&l.w, &l.scale, &l.shift, &l.wino_w, &l.wino_scale})
       if (*vp && !(*vp)->dev && !(*vp)->host.empty()) todo.push_back(vp->get());
   for (DevVec* vq : todo) {
     DevVec& v = *vq;
@@ -101,6 +101,10 @@ void Net::run_launch(const Launch& l, void* s) {
       if (wino) {
         if (!l.wino_w) throw DcError(DC_EINVAL, "launch '" + l.label + "' has no Winograd filter image");
         g.w = l.wino_w->dev;
+        if (l.variant == kWinoHalf) {  // float16: the form's own epilogue scale (row scale of ITS image, the 1/4 of the staged pixels)
+          if (!l.wino_scale || l.in2 >= 0) throw DcError(DC_EINVAL, "launch '" + l.label + "' cannot run as the float16 Winograd form");
+          g.scale = l.wino_scale->dev + l.c_off;
+        }
       }
       static const int dbg_idx = env_int("DC_DEBUG_TIMING", -1);
       // index of this launch in the plan (autotuning passes copies, which have none)

@@ -107,7 +107,8 @@ void Net::autotune() {
       c.push_back({burst_ms(trial), v});
     }
     if (l.wino_w)  // the Winograd forms of this layer (8 and 16 waves per workgroup) compete with the direct tiles
-      for (int wv : {kWinoVariant, kWinoVariant16}) {
+      for (int wv : {kWinoVariant, kWinoVariant16, kWinoHalf}) {
+        if (!l.takes_wino(wv)) continue;
         Launch trial = l;
         trial.variant = wv;
         c.push_back({burst_ms(trial), wv});
@@ -217,7 +218,7 @@ void Net::autotune() {
     for (auto& l : plan) {  // the passes run with the tiles chosen so far (what (3) will put into the plan)
       if (l.kind != Launch::CONV) continue;
       auto it = tune_cache_.find(key_of(l));
-      if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.wino_w) &&
+      if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.takes_wino(it->second)) &&
           !(l.cg.ncls > 1 && (is_wino_variant(it->second) || !conv_variant_multiclass(it->second))))
         l.variant = it->second;
     }
@@ -236,7 +237,7 @@ void Net::autotune() {
     };
     for (auto& kv : timed) {
       auto it = tune_cache_.find(kv.first);
-      if (it == tune_cache_.end() || !is_wino_variant(it->second)) continue;
+      if (it == tune_cache_.end() || !is_wino_variant(it->second) || it->second == kWinoHalf) continue;
       bool both = false;
       for (auto& c : kv.second) both = both || (is_wino_variant(c.second) && c.second != it->second);
       if (!both) continue;
@@ -258,7 +259,7 @@ void Net::autotune() {
     const ConvGemmParams& g = l.cg;
     auto it = tune_cache_.find(key_of(l));
     // a cache line naming the Winograd form while it is switched off (or not eligible any more): keep the cost model's tile
-    if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.wino_w) &&
+    if (it != tune_cache_.end() && !(is_wino_variant(it->second) && !l.takes_wino(it->second)) &&
         !(g.ncls > 1 && (is_wino_variant(it->second) || !conv_variant_multiclass(it->second))))
       l.variant = it->second;
     if (is_wino_variant(l.variant)) {
@@ -332,7 +333,7 @@ void Net::set_tile(const std::string& key, const std::string& tile) {
   for (auto& l : plan) {
     if (l.kind != Launch::CONV || tune_key(l) != key) continue;
     const ConvGemmParams& g = l.cg;
-    const bool ok = is_wino_variant(v) ? (bool)l.wino_w && g.ncls <= 1
+    const bool ok = is_wino_variant(v) ? l.takes_wino(v)
                                       : g.klen % conv_variant_bk(v) == 0 && conv_variant_esize(v) == g.esize && (g.ncls <= 1 || conv_variant_multiclass(v));
     if (!ok) throw DcError(DC_EUNSUP, "tile '" + tile + "' cannot take launch '" + l.label + "' (" + key + ")");
     any = true;

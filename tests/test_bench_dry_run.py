@@ -52,3 +52,31 @@ def test_two_ranks_on_one_gpu_are_refused_under_nccl():
         bench.one_gpu_per_rank([a, dict(a, rank=1)], "nccl")
     with pytest.raises(SystemExit):
         bench.one_gpu_per_rank([dict(a, uuid=""), dict(a, uuid="", rank=1)], "nccl")  # no uuid: the PCI address decides
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bench_starts_itself_when_invoked_like_the_n1_line():
+    """`python3 bench.py --gpus 8 ...` with no launcher around it (no WORLD_SIZE): bench.py becomes the launcher
+    (torch.distributed.run, one rank per GPU, 127.0.0.1) instead of exiting; rank 0 prints ONE JSON line, rc 0."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8
+    rep = d["config"]["distributed"]
+    assert rep["ranks_seen"] == 8 and len(set(i["pid"] for i in rep["ranks"])) == 8
+
+
+def test_self_launch_hands_back_a_failing_rank():
+    """a child that dies (here: a net input no layer stack survives) makes the launcher's exit code non-zero"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--height", "-8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -96,7 +96,7 @@ def test_full_net_with_every_eligible_layer_in_winograd_form(gpu_caffe, synth152
         assert float(np.abs(net.blobs[k].data - ref[k]).max()) <= 1e-3, k
 
 
-def test_off_switch_and_float16_keep_the_direct_kernel(gpu_caffe, synth152, monkeypatch):
+def test_off_switch_and_the_float16_form(gpu_caffe, synth152, monkeypatch):
     from deepcut_tools import deepercut_prototxt
 
     path, _ = synth152
@@ -105,7 +105,10 @@ def test_off_switch_and_float16_keep_the_direct_kernel(gpu_caffe, synth152, monk
     assert "wino" not in net.plan_text()
     monkeypatch.setenv("DC_WINOGRAD", "2")
     half = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True, dtype="f16")
-    assert "wino" not in half.plan_text()  # float32 only
+    assert "wino_f23" not in half.plan_text() and "wino_h23<" in half.plan_text()  # float16 nets have a form of their own (wino_f16.hip)
+    monkeypatch.setenv("DC_WINOGRAD", "0")
+    half = gpu_caffe.Net(deepercut_prototxt(152, 64, 64), path, gpu_caffe.TEST, from_text=True, dtype="f16")
+    assert "wino" not in half.plan_text()
 
 
 def test_the_two_forms_agree_and_are_deterministic(gpu_caffe, monkeypatch):

@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp
+run() { # name, counters...
+  n=$1; shift
+  rm -rf /tmp/p_$n
+  DC_WINO_NOSKEW=${NOSKEW:-1} DC_WINO_HALF_PK=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/p_$n -o l -- python $GRAFT_REPO_ROOT/tools/wino_f16_probe.py --stamps --shapes res4 > /dev/null 2>&1
+  python - <<PY
+import sqlite3,glob
+c=sqlite3.connect(glob.glob("/tmp/p_$n/**/*.db",recursive=True)[0])
+for r in c.execute("select counter_name, sum(value) from counters_collection where kernel_name like '%wino_h23%' group by counter_name"): print("%-32s %14.0f" % r)
+PY
+}
+run a SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
+run b SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_ACTIVE_INST_MISC
+run c SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE
