@@ -267,6 +267,7 @@ struct Net {
   void invalidate_plans();  // drop every cached plan and graph (option / weight change)
   void mark_weights_changed();  // parameter content changed: every executor re-packs and re-lowers before its next run
   void reserve(int n, int h, int w);  // lower + allocate + tune for a shape without running it
+  void prepare_to_run();              // the same for the current input shape (no reshape)
   // one reference layer stand-alone (Layer<Dtype>::SetUp on given bottoms): a net whose inputs are the layer's bottoms
   static Net* create_for_layer(const std::string& layer_text, int phase, const std::vector<std::vector<int>>& bottom_shapes);
   void forward(int start, int end);

@@ -215,6 +215,18 @@ static void prepare_buffers(Net& n, bool& grew) {
   }
 }
 
+// Everything a launch sequence of the CURRENT input shape needs, without running it and without touching the inputs: the plan of
+// that shape active (re-derived if a blob was reshaped since the last forward), images uploaded, every buffer of the plan allocated at
+// its present size, tiles chosen.  (plan_text() / dc_net_flops only lower: plan_valid alone does not mean buffers exist.)
+void Net::prepare_to_run() {
+  ensure_plan();
+  ensure_device();
+  upload_vecs();
+  bool grew;
+  prepare_buffers(*this, grew);
+  if (!tuned) autotune();
+}
+
 void Net::forward(int start, int end) {
   if (Context::get().mode != DC_MODE_GPU)
     throw DcError(DC_ENOCPU, "forward() in CPU mode: libdeepcut_hip provides the MI355X path only — call set_mode_gpu() "

@@ -86,10 +86,10 @@ void Net::choose_streams(const std::vector<Net*>& nets, int ncand, int reps, dou
     if (!e) throw DcError(DC_EINVAL, "choose_streams: null net");
     if (Context::get().mode != DC_MODE_GPU) throw DcError(DC_ENOCPU, "choose_streams() in CPU mode: libdeepcut_hip provides the MI355X path only");
     if (!e->plan_valid) throw DcError(DC_EINVAL, "choose_streams: every executor needs a lowered shape first (a forward, or dc_net_reserve)");
-    e->ensure_device();
+    // plan_valid alone proves nothing about buffers (plan_text() / dc_net_flops lower without allocating; a blob may have been
+    // reshaped since the last forward): the timed forwards below must find every buffer of the current shape in place
+    e->prepare_to_run();
     if (e->device != nets[0]->device) throw DcError(DC_EINVAL, "choose_streams: the executors must sit on one device");
-    e->upload_vecs();
-    if (!e->tuned) e->autotune();
   }
   if (ncand <= 0) ncand = 8;
   ncand = std::max(ncand, n);

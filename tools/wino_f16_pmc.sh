@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   n=$1; shift
   rm -rf /tmp/p_$n
-  DC_WINO_NOSKEW=${NOSKEW:-1} DC_WINO_HALF_PK=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/p_$n -o l -- python $GRAFT_REPO_ROOT/tools/wino_f16_probe.py --stamps --shapes res4 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/p_$n -o l -- python $GRAFT_REPO_ROOT/tools/wino_f16_probe.py --stamps --shapes res4 > /dev/null 2>&1
   python - <<PY
 import sqlite3,glob
 c=sqlite3.connect(glob.glob("/tmp/p_$n/**/*.db",recursive=True)[0])
