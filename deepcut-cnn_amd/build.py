@@ -28,11 +28,7 @@ def _asm_key():
     for f in ("kernels.hip", "kernels.h"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(" ".join(KERNEL_FLAGS).encode())
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    try:
-        h.update(subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout)
-    except OSError:
-        pass
+    h.update(_hipcc_version())
     return h.hexdigest()
 
 
@@ -79,7 +75,10 @@ def _hipcc_version():
     if _HIPCC_VERSION is None:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         try:
-            _HIPCC_VERSION = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            out = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            # the compiler's identity only: the version lines.  (The rest of the output names the host — `InstalledDir`, configuration
+            # files, on a GPU box the detected agents — and would make the prebuilt library look stale on the box it travels to.)
+            _HIPCC_VERSION = b"\n".join(ln for ln in out.splitlines() if b"version" in ln.lower())
         except OSError:
             _HIPCC_VERSION = b""
     return _HIPCC_VERSION

@@ -171,6 +171,8 @@ int dc_net_set_option(dc_net* net, int key, int value) {
       n->use_graph = value;
     } else if (key == DC_OPT_DTYPE) {
       n->set_dtype(value);
+    } else if (key == DC_OPT_OUTPUTS) {
+      n->set_outputs_mask(value);
     } else {
       throw DcError(DC_EINVAL, "unknown option " + std::to_string(key));
     }
@@ -183,6 +185,7 @@ int dc_net_get_option(dc_net* net, int key, int* value) {
   if (key == DC_OPT_FUSE) *value = n->fuse;
   else if (key == DC_OPT_HIPGRAPH) *value = n->use_graph;
   else if (key == DC_OPT_DTYPE) *value = n->dtype;
+  else if (key == DC_OPT_OUTPUTS) *value = n->outputs_mask;
   else return fail(DC_EINVAL, "unknown option " + std::to_string(key));
   return DC_OK;
 }
@@ -291,8 +294,8 @@ static int blob_host(dc_blob* b, float** out, bool mut) {
   return guard([&] {
     Storage& s = *B(b)->st;
     if (s.elided && !s.is_param)
-      throw DcError(DC_EUNSUP, "blob '" + B(b)->name + "' is folded into a fused kernel in the current plan and never "
-                                "materialised; create the net with DC_OPT_FUSE 0 to observe it");
+      throw DcError(DC_EUNSUP, "blob '" + B(b)->name + "' is folded into a fused kernel in the current plan (or feeds only outputs that "
+                                "DC_OPT_OUTPUTS leaves out) and never materialised; create the net with DC_OPT_FUSE 0 / all outputs to observe it");
     if (s.head == HEAD_AT_GPU) {
       if (s.owner) s.owner->sync_to_host(s);
       else standalone_device(), storage_to_host(s, nullptr, nullptr);

@@ -223,6 +223,7 @@ struct Net {
   int fuse = 2;
   int dtype = 0;  // 0: float activations/filters; 1: _Float16 activations/filters, fp32 accumulate + epilogue
   int use_graph = 0;
+  int outputs_mask = -1;  // DC_OPT_OUTPUTS: bit i = output i (order of `outputs`) is wanted
   std::shared_ptr<ModelShared> shared;   // joint with every clone
   uint64_t seen_weights_gen = 0;         // generation the cached plans were lowered from
   // the ACTIVE plan (the fields below are swapped with a parked PlanState when the input shape changes)
@@ -259,6 +260,7 @@ struct Net {
   void adopt_stream(void* s);  // a pool stream becomes the net's own
   void* own_stream();          // the net's own stream, created on first use
   void set_dtype(int d);  // 0 float32 / 1 float16 device images (DC_OPT_DTYPE)
+  void set_outputs_mask(int mask);  // DC_OPT_OUTPUTS
   void copy_from(const std::string& path);
   void save(const std::string& path);
   void reshape();         // propagate input shapes through every layer (Net::Reshape)

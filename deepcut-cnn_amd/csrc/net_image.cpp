@@ -205,6 +205,8 @@ Net::MapRef Net::map_ref(const char* blob_name) {
   auto it = blob_index.find(blob_name);
   if (it == blob_index.end()) throw DcError(DC_EINVAL, std::string("net has no '") + blob_name + "' blob");
   Storage& s = *blobs[it->second]->st;
+  if (s.elided && s.view_of < 0)
+    throw DcError(DC_EUNSUP, std::string("'") + blob_name + "' is not computed in the current plan (DC_OPT_OUTPUTS leaves it out, or it is folded into a fused kernel)");
   if (s.head == UNINITIALIZED) throw DcError(DC_EINVAL, std::string("'") + blob_name + "': run forward() first");
   if (s.shape.size() != 4) throw DcError(DC_ESHAPE, std::string("'") + blob_name + "' is not a 4-D map");
   MapRef r{};

@@ -129,6 +129,7 @@ Net* Net::clone() {
   for (size_t i = 0; i < inputs.size(); ++i) c->blobs[c->inputs[i]]->st->reshape(blobs[inputs[i]]->st->shape);
   c->fuse = fuse;
   c->use_graph = use_graph;
+  c->outputs_mask = outputs_mask;
   if (dtype != c->dtype) {
     c->dtype = dtype;
     for (auto& st : c->storages)
@@ -141,6 +142,19 @@ Net* Net::clone() {
 
 // Device element type of activations and packed filters (host blobs stay float32 NCHW; accumulation and
 // the epilogue stay float32).  Switching re-creates the device images and re-packs the filters.
+void Net::set_outputs_mask(int mask) {
+  const int n = (int)outputs.size();
+  const int all = n >= 31 ? -1 : (1 << n) - 1;
+  if (mask != -1 && n < 31) {
+    if (mask & ~all) throw DcError(DC_EINVAL, "DC_OPT_OUTPUTS: the net has " + std::to_string(n) + " outputs");
+    if (mask == 0) throw DcError(DC_EINVAL, "DC_OPT_OUTPUTS: at least one output must be wanted");
+    if (mask == all) mask = -1;
+  }
+  if (mask == outputs_mask) return;
+  outputs_mask = mask;
+  invalidate_plans();
+}
+
 void Net::set_dtype(int d) {
   if (d != 0 && d != 1) throw DcError(DC_EINVAL, "dtype must be 0 (float32) or 1 (float16)");
   if (d == dtype) return;

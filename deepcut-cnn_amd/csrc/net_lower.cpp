@@ -147,6 +147,24 @@ void Net::build_plan() {
     ops.push_back(std::move(op));
   }
 
+  // pass 1b (DC_OPT_OUTPUTS): ops that only feed unwanted net outputs are dropped — a backward walk over the op list: an op is live
+  // if the tensor it writes is a wanted output or is read by a live op further down (in-place ops keep their tensor needed)
+  if (outputs_mask != -1) {
+    std::vector<char> needed(storages.size(), 0);
+    for (size_t i = 0; i < outputs.size(); ++i)
+      if (i >= 31 || ((outputs_mask >> i) & 1)) needed[sid(outputs[i])] = 1;
+    for (int k = (int)ops.size() - 1; k >= 0; --k) {
+      LOp& op = ops[k];
+      if (!needed[op.out]) {
+        op.dead = true;
+        continue;
+      }
+      if (op.in != op.out && op.in2 != op.out) needed[op.out] = 0;  // produced here: nothing above needs to
+      needed[op.in] = 1;
+      if (op.in2 >= 0) needed[op.in2] = 1;
+    }
+  }
+
   // pass 2: residual-add and deconvolution-head fusion
   if (fuse >= 1) {
     const int nS = (int)storages.size();

@@ -354,6 +354,8 @@ class Net(object):
             self.set_option(3, {"f32": 0, "float32": 0, "f16": 1, "float16": 1}[kw["dtype"]])
         self._blobs = None
         self._params = None
+        if kw.get("want") is not None:
+            self.set_outputs(kw["want"])
 
     def set_option(self, key, value):
         _check(_lib.dc_net_set_option(self._h, int(key), int(value)))
@@ -362,6 +364,28 @@ class Net(object):
         v = C.c_int()
         _check(_lib.dc_net_get_option(self._h, int(key), C.byref(v)))
         return v.value
+
+    def set_outputs(self, names=None):
+        """DC_OPT_OUTPUTS: the output blobs the forward has to produce (None = all).  The lowering drops every launch that only feeds
+        the others — the demo reads `prob` and `loc_pred` only (python/pose/estimate_pose.py:231-241), and without `next_pred` the
+        merged heads shrink from 406 to 42 channels.  The wanted maps equal the full forward's (bit for bit under the same tile); `forward()` returns
+        the wanted outputs only, and `.data` on a left-out blob raises."""
+        outs = self.outputs
+        if names is None:
+            mask = -1
+        else:
+            unknown = [n for n in names if n not in outs]
+            if unknown:
+                raise ValueError("not output blobs of this net: %r (outputs: %r)" % (unknown, outs))
+            mask = 0
+            for n in names:
+                mask |= 1 << outs.index(n)
+        self.set_option(4, mask)
+
+    @property
+    def wanted_outputs(self):
+        mask = self.get_option(4)
+        return [n for i, n in enumerate(self.outputs) if mask == -1 or (mask >> i) & 1]
 
     @property
     def dtype(self):
@@ -445,7 +469,7 @@ class Net(object):
             blobs = []
         if start is None and end is None:
             start_ind, end_ind = 0, _lib.dc_net_num_layers(self._h) - 1
-            outputs = set(self.outputs + blobs)
+            outputs = set(self.wanted_outputs + blobs)
         else:
             names = self._layer_names
             start_ind = names.index(start) if start is not None else 0
@@ -454,7 +478,7 @@ class Net(object):
                 outputs = set([end] + blobs)
             else:
                 end_ind = len(names) - 1
-                outputs = set(self.outputs + blobs)
+                outputs = set(self.wanted_outputs + blobs)
         if kwargs:
             if set(kwargs.keys()) != set(self.inputs):
                 raise Exception("Input blob arguments do not match net inputs.")

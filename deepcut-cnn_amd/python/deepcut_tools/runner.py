@@ -409,6 +409,24 @@ class ShardedPoseRunner(object):
         except Exception:
             return False
 
+    def _select_outputs(self, want_maps):
+        """DC_OPT_OUTPUTS on every executor of this runner: poses need `prob` and `loc_pred` only (python/pose/estimate_pose.py:231-241),
+        so without the maps the 364-channel `next_pred` head — 23.3 of the 241 GFLOP of a 544x736 forward — is not computed at all."""
+        if not hasattr(self.net, "set_outputs"):
+            return
+        names = None if want_maps else [n for n in self.net.outputs if n in ("prob", "loc_pred")]
+        if names is not None and len(names) != 2:
+            names = None
+        nets = [self.net] + [m for grp in (self._members or []) for m in grp] + list(self._execs or [])
+        seen = set()
+        for n in nets:
+            if id(n) in seen:
+                continue
+            seen.add(id(n))
+            want = sorted(n.outputs) if names is None else sorted(names)
+            if sorted(n.wanted_outputs) != want:
+                n.set_outputs(names)
+
     def run(self, images, scales, want_maps=False):
         """images: list of HxWx3 BGR uint8 (the same list on every rank).  Returns on rank 0 a dict
         {"poses": [5xJ or None per image], "best_scale": [...], "items": [...], "item_poses": array,
@@ -421,6 +439,7 @@ class ShardedPoseRunner(object):
         shapes = [im.shape[:2] for im in images]
         items, shards = plan_work(shapes, scales, world)
         mine = shards[rank]
+        self._select_outputs(want_maps)
         on_device = self._use_device_pipeline()
         if on_device:
             batches_of = [rank_batches(shapes, items, shards[r], self.max_batch, interleave=self.group_size > 1) for r in range(world)]

@@ -234,18 +234,31 @@ def _scale_group(net, n):
 _MAX_SCALE_GROUPS = 4
 
 
-def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None, on_device=True, grouped=None):
+def _read_outputs_only(net):
+    """The demo reads `prob` and `loc_pred` (estimate_pose.py:231-241 of the reference) and never `next_pred`: tell the net once
+    (DC_OPT_OUTPUTS) — without the 364-channel pairwise head the merged heads shrink from 406 to 42 channels, 23.3 GFLOP less per
+    544x736 forward; the two maps equal the full forward's (bit for bit under the same head tile).  `net.set_outputs(None)` brings every output back."""
+    for n in [net] + list(getattr(net, "__dict__", {}).get("_scale_clones", [])):  # (the scale-group clones follow their net)
+        if hasattr(n, "set_outputs") and "next_pred" in n.wanted_outputs and {"prob", "loc_pred"} <= set(n.outputs):
+            n.set_outputs(["loc_pred", "prob"])
+
+
+def estimate_pose(image, model_def, model_bin, scales=None, net=None, tiling=None, on_device=True, grouped=None, all_outputs=False):
     """image: HxWx3 BGR uint8.  Returns the 5x14 pose of the best scale (see module docstring).
     tiling: None (one forward per scale), "exact" or "reference" (see `forward_maps_tiled`).
     on_device: without tiling, pre-process and decode on the GPU (`Net.forward_images`: the same canvas bit
     for bit, the same forward, 70 doubles back instead of the maps); False keeps every step where the
     reference has it (Pillow + NumPy on the host around `net.forward()`).
     grouped: None = several scales on the device run as ONE grouped forward (`caffe.NetGroup`); False = the
-    reference's loop, one forward per scale (bit-identical to the host route's forwards)."""
+    reference's loop, one forward per scale (bit-identical to the host route's forwards).
+    all_outputs: False (default) = the net computes only what is read here, `prob` and `loc_pred` (see `_read_outputs_only`); True
+    leaves the net's output selection alone (a caller that also reads `net.blobs['next_pred']` afterwards)."""
     if scales is None:
         scales = [1.0]
     if net is None:
         net = _get_model(model_def, model_bin)
+    if not all_outputs:
+        _read_outputs_only(net)
     poses = []
     if (grouped is None or grouped) and tiling is None and on_device and len(scales) > 1 and hasattr(net, "clone") \
             and _np.asarray(image).dtype == _np.uint8:

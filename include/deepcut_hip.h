@@ -53,6 +53,13 @@ extern "C" {
                                1: float16 activations and filters, v_mfma_f32_32x32x16_f16 with float32
                                accumulation and epilogue (BASELINE configs[2]); host blobs stay float32 */
 
+#define DC_OPT_OUTPUTS 4    /* bit i set = the i-th output blob of the net (dc_net_num_outputs order: alphabetical, net.cpp:268-273) is wanted;
+                               default -1 = all.  The lowering drops every launch that only feeds unwanted outputs (the demo reads `prob`
+                               and `loc_pred` only, python/pose/estimate_pose.py:231-241, and the 364-channel `next_pred` head is 23.3 of the
+                               241 GFLOP of a 544x736 forward); an unwanted output blob is elided: reading it is DC_EUNSUP.  The wanted
+                               maps equal the full forward's up to the summation order of the tile chosen for the narrower head GEMM
+                               (bit for bit under the same tile, tests/test_gpu_outputs.py) */
+
 typedef struct dc_net dc_net;
 typedef struct dc_blob dc_blob;
 
