@@ -14,10 +14,14 @@
 //           src/caffe/parallel.cpp:287-322, is a training-time tree of gradient sums and not a model for this);
 //   PEER    hipMemcpyPeerAsync from each executor's device (also the loop-back transport when several executors share ONE device: the
 //           way the 8-executor path is tested on a 1-GPU box);
-// on a communication stream per executor, ordered behind that executor's forwards by an event, so an executor that finishes early
-// sends while the others still compute.  The gathered maps stay on the root device until the next call (dc_comm_root_maps: the
-// decode kernels can consume them there); the caller's host arrays, if it gave any, are filled by every executor for its own share,
-// from its own device over its own host link, on its own thread.
+// on a communication stream per executor, ordered behind that executor's forwards by events.  Inside an executor's share the work is a
+// PIPELINE (round 6): every same-shape group of 8 (float16: 16) or more images is cut into two sub-batches, and while sub-batch j computes, the
+// images of j + 1 are staged into the other half of the pinned staging buffer and the maps of j - 1 travel to the host on a copy
+// stream and are scattered into the caller's arrays; with the PEER transport each sub-batch's maps also leave for the root device as
+// soon as they exist (behind the sub-batch's event), with RCCL the exchange stays ONE grouped send / recv behind the last forward (all
+// RCCL calls of a call come from one thread, in one group).  The gathered maps stay on the root device until the next call
+// (dc_comm_root_maps: the decode kernels can consume them there); the caller's host arrays, if it gave any, are filled by every
+// executor for its own share, from its own device over its own host link, on its own thread.
 #include <dlfcn.h>
 
 #include <condition_variable>
@@ -165,6 +169,8 @@ struct Comm {
   std::vector<void*> nccl;  // one communicator per executor (RCCL transport)
   std::vector<std::unique_ptr<Worker>> workers;
   std::vector<void*> comm_stream, fwd_done;  // per executor: its communication stream, the event behind its forwards
+  std::vector<void*> copy_stream;            // per executor: the stream its maps travel to the host on, beside the next sub-batch's forward
+  std::vector<std::vector<void*>> sub_ev;    // per executor: two events per sub-batch (forward + emit done, download done), reused across calls
   struct Buf {
     unsigned char* p = nullptr;
     size_t cap = 0;
@@ -198,6 +204,10 @@ Comm::~Comm() {
   for (size_t k = 0; k < devices.size(); ++k) {
     (void)hipSetDevice(devices[k]);
     if (k < comm_stream.size() && comm_stream[k]) (void)hipStreamDestroy((hipStream_t)comm_stream[k]);
+    if (k < copy_stream.size() && copy_stream[k]) (void)hipStreamDestroy((hipStream_t)copy_stream[k]);
+    if (k < sub_ev.size())
+      for (void* e : sub_ev[k])
+        if (e) (void)hipEventDestroy((hipEvent_t)e);
     if (k < fwd_done.size() && fwd_done[k]) (void)hipEventDestroy((hipEvent_t)fwd_done[k]);
     if (k < send.size()) dev_free(send[k].p);
     if (k < recv.size()) dev_free(recv[k].p);
@@ -235,10 +245,58 @@ void Comm::grow_host(Buf& b, size_t bytes) {
   b.cap = bytes;
 }
 
+namespace {
+// the thread's current HIP device is the caller's business: dc_comm_create / dc_forward_batch switch devices to reach every executor
+// and put back what they found
+struct DeviceRestore {
+  int dev = -1;
+  DeviceRestore() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1, (void)hipGetLastError();
+  }
+  ~DeviceRestore() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
+}  // namespace
+
+// One byte from every peer to the root through the communicators just made: the whole transport (peer buffers, IPC handles, the
+// grouped send / recv) exercised once before a forward depends on it.  Throws what RCCL or the runtime reports.
+static void rccl_probe(Comm& c) {
+  std::vector<unsigned char*> buf((size_t)c.nexec, nullptr);
+  struct Free {
+    std::vector<unsigned char*>& b;
+    ~Free() {
+      for (unsigned char* p : b) dev_free(p);
+    }
+  } guard{buf};
+  for (int k = 0; k < c.nexec; ++k) {
+    HIPCHECK(hipSetDevice(c.devices[(size_t)(k == 0 ? 0 : k)]));
+    dev_alloc(reinterpret_cast<void**>(&buf[(size_t)k]), 256 * (size_t)(k == 0 ? c.nexec : 1));
+  }
+  NCCLCHECK(rccl().GroupStart());
+  try {
+    for (int k = 1; k < c.nexec; ++k) {
+      HIPCHECK(hipSetDevice(c.devices[0]));
+      NCCLCHECK(rccl().Recv(buf[0] + 256 * (size_t)k, 1, kNcclUint8, k, c.nccl[0], c.comm_stream[0]));
+      HIPCHECK(hipSetDevice(c.devices[(size_t)k]));
+      NCCLCHECK(rccl().Send(buf[(size_t)k], 1, kNcclUint8, 0, c.nccl[(size_t)k], c.comm_stream[(size_t)k]));
+    }
+  } catch (...) {
+    (void)rccl().GroupEnd();
+    throw;
+  }
+  NCCLCHECK(rccl().GroupEnd());
+  for (int k = 0; k < c.nexec; ++k) {
+    HIPCHECK(hipSetDevice(c.devices[(size_t)k]));
+    HIPCHECK(hipStreamSynchronize((hipStream_t)c.comm_stream[(size_t)k]));
+  }
+}
+
 Comm* comm_create(int nexec, const int* devices, int transport) {
   if (nexec < 1 || nexec > 64) throw DcError(DC_EINVAL, "dc_comm_create: 1..64 executors");
   const int ndev = device_count();
   if (ndev <= 0) throw DcError(DC_EDEVICE, "no HIP device visible: libdeepcut_hip has no CPU compute path");
+  DeviceRestore restore;
   std::unique_ptr<Comm> c(new Comm());
   c->nexec = nexec;
   bool distinct = true;
@@ -248,25 +306,47 @@ Comm* comm_create(int nexec, const int* devices, int transport) {
     for (int o : c->devices) distinct = distinct && o != d;
     c->devices.push_back(d);
   }
-  if (transport == DC_COMM_AUTO) transport = (distinct && nexec > 1 && rccl().ok()) ? DC_COMM_RCCL : DC_COMM_PEER;
+  const bool automatic = transport == DC_COMM_AUTO;
+  if (automatic) transport = (distinct && nexec > 1 && rccl().ok()) ? DC_COMM_RCCL : DC_COMM_PEER;
   if (transport != DC_COMM_RCCL && transport != DC_COMM_PEER) throw DcError(DC_EINVAL, "dc_comm_create: transport must be DC_COMM_AUTO, DC_COMM_RCCL or DC_COMM_PEER");
   if (transport == DC_COMM_RCCL) {
     if (!rccl().ok()) throw DcError(DC_EDEVICE, "DC_COMM_RCCL: " + rccl().why);
     if (!distinct) throw DcError(DC_EINVAL, "DC_COMM_RCCL needs one executor per device (executors sharing a device use DC_COMM_PEER)");
-    c->nccl.assign((size_t)nexec, nullptr);
-    NCCLCHECK(rccl().CommInitAll(c->nccl.data(), nexec, c->devices.data()));
   }
-  c->transport = transport;
   c->send.resize((size_t)nexec), c->recv.resize((size_t)nexec), c->stage.resize((size_t)nexec), c->hout.resize((size_t)nexec);
-  c->comm_stream.assign((size_t)nexec, nullptr), c->fwd_done.assign((size_t)nexec, nullptr);
+  c->comm_stream.assign((size_t)nexec, nullptr), c->fwd_done.assign((size_t)nexec, nullptr), c->copy_stream.assign((size_t)nexec, nullptr);
+  c->sub_ev.assign((size_t)nexec, {});
   for (int k = 0; k < nexec; ++k) {
     HIPCHECK(hipSetDevice(c->devices[(size_t)k]));
     hipStream_t st;
     HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     c->comm_stream[(size_t)k] = st;
+    HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->copy_stream[(size_t)k] = st;
     hipEvent_t ev;
     HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     c->fwd_done[(size_t)k] = ev;
+  }
+  if (transport == DC_COMM_RCCL) {
+    // DC_COMM_AUTO must not leave the caller with a communicator that cannot move a byte: RCCL's peer buffers need dmabuf IPC on
+    // hosts whose driver has no legacy IPC (HSA_ENABLE_IPC_MODE_LEGACY=0, include/deepcut_hip.h), and whatever else the node's RCCL
+    // dislikes shows up at the first collective — so the communicators are made AND used once here; on any failure the automatic
+    // choice falls back to peer copies, an explicit DC_COMM_RCCL reports the error
+    try {
+      c->nccl.assign((size_t)nexec, nullptr);
+      NCCLCHECK(rccl().CommInitAll(c->nccl.data(), nexec, c->devices.data()));
+      if (nexec > 1) rccl_probe(*c);
+    } catch (const DcError& e) {
+      for (void*& cm : c->nccl)
+        if (cm) (void)rccl().CommDestroy(cm), cm = nullptr;
+      c->nccl.clear();
+      (void)hipGetLastError();
+      if (!automatic) throw DcError(e.code, std::string("DC_COMM_RCCL: ") + e.what() + " (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported? see deepcut_hip.h)");
+      transport = DC_COMM_PEER;
+    }
+  }
+  c->transport = transport;
+  for (int k = 0; k < nexec; ++k) {
     if (transport == DC_COMM_PEER && c->devices[(size_t)k] != c->devices[0]) {
       int can = 0;
       (void)hipDeviceCanAccessPeer(&can, c->devices[0], c->devices[(size_t)k]);
@@ -278,7 +358,6 @@ Comm* comm_create(int nexec, const int* devices, int transport) {
     }
     c->workers.emplace_back(new Worker(c->devices[(size_t)k]));
   }
-  HIPCHECK(hipSetDevice(c->devices[0]));
   return c.release();
 }
 void comm_destroy(Comm* c) { delete c; }
@@ -298,37 +377,60 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   for (int i = 0; i < n; ++i)
     if (!inputs || !inputs[i] || hw[i][0] <= 0 || hw[i][1] <= 0) throw DcError(DC_EINVAL, "dc_forward_batch: image " + std::to_string(i) + ": null input or empty shape");
   std::lock_guard<std::mutex> one_call(call_mu);
+  DeviceRestore restore;
   items.clear();  // (a call that fails leaves no "last forward" behind: dc_comm_root_maps refuses)
   plan.assign((size_t)nexec, {});
   if (n == 0) return;
   std::vector<Item> placed((size_t)n);
-  // ---- the schedule (host only, deterministic): LPT over H*W, then per executor its same-shape groups in order of first appearance
+  // ---- the schedule (host only, deterministic): LPT over H*W, then per executor its same-shape groups in order of first appearance,
+  //      every group large enough cut into two sub-batches (the units of the executor's pipeline below)
   std::vector<double> cost((size_t)n);
   for (int i = 0; i < n; ++i) cost[(size_t)i] = (double)hw[i][0] * hw[i][1];
   const std::vector<std::vector<int>> share = lpt_schedule(cost, nexec);
-  for (int k = 0; k < nexec; ++k)
-    for (int i : share[(size_t)k]) {
-      std::vector<Group>& gs = plan[(size_t)k];
-      size_t g = 0;
-      while (g < gs.size() && !(gs[g].h == hw[i][0] && gs[g].w == hw[i][1])) ++g;
-      if (g == gs.size()) {
-        gs.emplace_back();
-        gs[g].h = hw[i][0], gs[g].w = hw[i][1];
-      }
-      placed[(size_t)i].exec = k, placed[(size_t)i].group = (int)g, placed[(size_t)i].pos = (int)gs[g].idx.size();
-      gs[g].idx.push_back(i);
-    }
-
-  // ---- every executor on its own thread: each group as one batch; the maps as NCHW float32 into its send buffer
-  std::vector<size_t> payload((size_t)nexec, 0);
   for (int k = 0; k < nexec; ++k) {
-    workers[(size_t)k]->start([this, k, nets, inputs, &payload, prob, loc, next] {
+    std::vector<Group> whole;
+    for (int i : share[(size_t)k]) {
+      size_t g = 0;
+      while (g < whole.size() && !(whole[g].h == hw[i][0] && whole[g].w == hw[i][1])) ++g;
+      if (g == whole.size()) {
+        whole.emplace_back();
+        whole[g].h = hw[i][0], whole[g].w = hw[i][1];
+      }
+      whole[g].idx.push_back(i);
+    }
+    std::vector<Group>& gs = plan[(size_t)k];
+    // a sub-batch must stay a batch the kernels run well on: halves of at least 4 images in float32, 8 in float16 (measured on one GPU,
+    // 8 executors x 8 images of 544x736: float16 halves of 4 ran 624 images/s where whole batches of 8 run 803; float32 halves of 4
+    // 357 against 333) — smaller groups go as one batch, still pipelined against the executor's other groups
+    const size_t min_half = nets[k]->dtype == 1 ? 8 : 4;
+    for (const Group& g : whole) {
+      const size_t nb = g.idx.size(), first = nb >= 2 * min_half ? (nb + 1) / 2 : nb;
+      for (size_t b0 = 0; b0 < nb; b0 += (b0 == 0 ? first : nb - first)) {
+        Group sub;
+        sub.h = g.h, sub.w = g.w;
+        sub.idx.assign(g.idx.begin() + (long)b0, g.idx.begin() + (long)(b0 == 0 ? first : nb));
+        for (size_t q = 0; q < sub.idx.size(); ++q) placed[(size_t)sub.idx[q]] = Item{k, (int)gs.size(), (int)q};
+        gs.push_back(std::move(sub));
+      }
+    }
+  }
+
+  // ---- every executor on its own thread, its sub-batches as a pipeline: while sub-batch j computes (upload, forward and the maps as
+  //      NCHW float32 into the send buffer, all enqueued on the net's own stream without a wait), the images of j + 1 are staged in
+  //      the other half of the pinned staging buffer and the maps of j - 1 are downloaded on the copy stream and scattered into the
+  //      caller's arrays.  PEER transport: each sub-batch's maps leave for the root device behind the sub-batch's event.
+  std::vector<size_t> payload((size_t)nexec, 0);
+  const bool to_host = prob || loc || next;
+  for (int k = 0; k < nexec; ++k) {
+    workers[(size_t)k]->start([this, k, nets, inputs, &payload, prob, loc, next, to_host] {
       Net* net = nets[k];
       std::vector<Group>& gs = plan[(size_t)k];
       if (gs.empty()) return;
-      HIPCHECK(hipSetDevice(devices[(size_t)k]));
-      // sizes first (shape inference, host only): the send buffer must not move once maps are being written into it
-      size_t total = 0;
+      const int dev = devices[(size_t)k];
+      HIPCHECK(hipSetDevice(dev));
+      // sizes first (shape inference, host only): the buffers must not move once maps are being written into them
+      size_t total = 0, stage_bytes = 0;
+      const size_t in_c = (size_t)net->blobs[net->inputs[0]]->st->dim(1);
       for (Group& g : gs) {
         Storage& in = *net->blobs[net->inputs[0]]->st;
         in.reshape({(int)g.idx.size(), in.dim(1), g.h, g.w});
@@ -342,42 +444,71 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
         g.pc = p.dim(1), g.lc = l.dim(1), g.nc = x.dim(1), g.mh = p.dim(2), g.mw = p.dim(3);
         g.off = total;
         total += g.idx.size() * (size_t)(g.pc + g.lc + g.nc) * g.mh * g.mw * sizeof(float);
+        stage_bytes = std::max(stage_bytes, g.idx.size() * in_c * g.h * g.w * sizeof(float));
       }
-      grow_dev(send[(size_t)k], total, devices[(size_t)k]);
-      for (Group& g : gs) {
+      stage_bytes = (stage_bytes + 4095) & ~(size_t)4095;
+      grow_dev(send[(size_t)k], total, dev);
+      grow_host(stage[(size_t)k], 2 * stage_bytes);
+      if (to_host) grow_host(hout[(size_t)k], total);
+      const bool peer_now = transport == DC_COMM_PEER && k > 0;
+      if (peer_now) {
+        grow_dev(recv[(size_t)k], total, devices[0]);  // (allocated on the root device; this thread's device is put back)
+        HIPCHECK(hipSetDevice(dev));
+      }
+      std::vector<void*>& ev = sub_ev[(size_t)k];
+      while (ev.size() < 2 * gs.size()) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev.push_back(e);
+      }
+      auto group_bytes = [](const Group& g) { return g.idx.size() * (size_t)(g.pc + g.lc + g.nc) * g.mh * g.mw * sizeof(float); };
+      auto scatter = [&](size_t j) {  // the caller's arrays of sub-batch j, once its download has landed
+        const Group& g = gs[j];
+        HIPCHECK(hipEventSynchronize((hipEvent_t)ev[2 * j + 1]));
         const int nb = (int)g.idx.size();
-        const size_t img = (size_t)net->blobs[net->inputs[0]]->st->dim(1) * g.h * g.w, cell = (size_t)g.mh * g.mw;
-        grow_host(stage[(size_t)k], nb * img * sizeof(float));
-        float* st = reinterpret_cast<float*>(stage[(size_t)k].p);
+        const size_t cell = (size_t)g.mh * g.mw;
+        const float* pp = reinterpret_cast<const float*>(hout[(size_t)k].p + g.off);
+        const float* lp = pp + (size_t)nb * g.pc * cell;
+        const float* np = lp + (size_t)nb * g.lc * cell;
+        for (int b = 0; b < nb; ++b) {
+          const int i = g.idx[(size_t)b];
+          if (prob && prob[i]) std::memcpy(prob[i], pp + (size_t)b * g.pc * cell, (size_t)g.pc * cell * sizeof(float));
+          if (loc && loc[i]) std::memcpy(loc[i], lp + (size_t)b * g.lc * cell, (size_t)g.lc * cell * sizeof(float));
+          if (next && next[i]) std::memcpy(next[i], np + (size_t)b * g.nc * cell, (size_t)g.nc * cell * sizeof(float));
+        }
+      };
+      for (size_t j = 0; j < gs.size(); ++j) {
+        const Group& g = gs[j];
+        const int nb = (int)g.idx.size();
+        const size_t img = in_c * g.h * g.w, cell = (size_t)g.mh * g.mw;
+        // the staging half of sub-batch j - 2 is free once that sub-batch's work — its upload first of all — is done
+        if (j >= 2) HIPCHECK(hipEventSynchronize((hipEvent_t)ev[2 * (j - 2)]));
+        float* st = reinterpret_cast<float*>(stage[(size_t)k].p + (j & 1) * stage_bytes);
         for (int b = 0; b < nb; ++b) std::memcpy(st + b * img, inputs[g.idx[(size_t)b]], img * sizeof(float));
         float* pp = reinterpret_cast<float*>(send[(size_t)k].p + g.off);
         float* lp = pp + (size_t)nb * g.pc * cell;
         float* np = lp + (size_t)nb * g.lc * cell;
-        net->forward_batch(st, nb, g.h, g.w, false, nullptr, nullptr, nullptr, nullptr);  // host batch up + forward, the net's own stream
-        net->emit_last_maps(pp, lp, np, 0, true, (void*)-1);                              // ... and the maps, same stream, not waited for
+        net->forward_batch(st, nb, g.h, g.w, false, nullptr, nullptr, nullptr, nullptr, true);  // upload + forward enqueued on the net's own stream, not waited for
+        net->emit_last_maps(pp, lp, np, 0, true, (void*)-1);                                    // ... and the maps, same stream
+        HIPCHECK(hipEventRecord((hipEvent_t)ev[2 * j], (hipStream_t)net->stream));
+        if (to_host) {
+          HIPCHECK(hipStreamWaitEvent((hipStream_t)copy_stream[(size_t)k], (hipEvent_t)ev[2 * j], 0));
+          HIPCHECK(hipMemcpyAsync(hout[(size_t)k].p + g.off, send[(size_t)k].p + g.off, group_bytes(g), hipMemcpyDeviceToHost, (hipStream_t)copy_stream[(size_t)k]));
+          HIPCHECK(hipEventRecord((hipEvent_t)ev[2 * j + 1], (hipStream_t)copy_stream[(size_t)k]));
+        }
+        if (peer_now) {
+          HIPCHECK(hipStreamWaitEvent((hipStream_t)comm_stream[(size_t)k], (hipEvent_t)ev[2 * j], 0));
+          if (dev == devices[0])
+            HIPCHECK(hipMemcpyAsync(recv[(size_t)k].p + g.off, send[(size_t)k].p + g.off, group_bytes(g), hipMemcpyDeviceToDevice, (hipStream_t)comm_stream[(size_t)k]));
+          else
+            HIPCHECK(hipMemcpyPeerAsync(recv[(size_t)k].p + g.off, devices[0], send[(size_t)k].p + g.off, dev, group_bytes(g), (hipStream_t)comm_stream[(size_t)k]));
+        }
+        if (to_host && j >= 1) scatter(j - 1);
       }
       payload[(size_t)k] = total;
       HIPCHECK(hipEventRecord((hipEvent_t)fwd_done[(size_t)k], (hipStream_t)net->stream));
-      // the caller's HOST arrays are filled here, by every executor for its own share and from its own device: the downloads use
-      // each GPU's own host link and the scatter runs on n threads (the gather below serves device-side consumers on the root)
-      if (prob || loc || next) {
-        grow_host(hout[(size_t)k], total);
-        HIPCHECK(hipMemcpyAsync(hout[(size_t)k].p, send[(size_t)k].p, total, hipMemcpyDeviceToHost, (hipStream_t)net->stream));
-        HIPCHECK(hipStreamSynchronize((hipStream_t)net->stream));
-        for (const Group& g : gs) {
-          const int nb = (int)g.idx.size();
-          const size_t cell = (size_t)g.mh * g.mw;
-          const float* pp = reinterpret_cast<const float*>(hout[(size_t)k].p + g.off);
-          const float* lp = pp + (size_t)nb * g.pc * cell;
-          const float* np = lp + (size_t)nb * g.lc * cell;
-          for (int b = 0; b < nb; ++b) {
-            const int i = g.idx[(size_t)b];
-            if (prob && prob[i]) std::memcpy(prob[i], pp + (size_t)b * g.pc * cell, (size_t)g.pc * cell * sizeof(float));
-            if (loc && loc[i]) std::memcpy(loc[i], lp + (size_t)b * g.lc * cell, (size_t)g.lc * cell * sizeof(float));
-            if (next && next[i]) std::memcpy(next[i], np + (size_t)b * g.nc * cell, (size_t)g.nc * cell * sizeof(float));
-          }
-        }
-      }
+      if (to_host) scatter(gs.size() - 1);
+      HIPCHECK(hipStreamSynchronize((hipStream_t)net->stream));  // (the staging halves and the net are the next call's again)
     });
   }
   std::string err;
@@ -388,14 +519,15 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
   }
   if (code) throw DcError(code, err);
 
-  // ---- ONE exchange: every executor's payload -> the root's device, each behind its own forwards
-  for (int k = 1; k < nexec; ++k) grow_dev(recv[(size_t)k], payload[(size_t)k], devices[0]);
-  for (int k = 0; k < nexec; ++k)
-    if (payload[(size_t)k]) {
-      HIPCHECK(hipSetDevice(devices[(size_t)k]));
-      HIPCHECK(hipStreamWaitEvent((hipStream_t)comm_stream[(size_t)k], (hipEvent_t)fwd_done[(size_t)k], 0));
-    }
+  // ---- RCCL: ONE exchange, every executor's payload -> the root's device behind its last forward (all RCCL calls of a call from this
+  //      one thread, in one group).  PEER: the copies are already on their way, sub-batch by sub-batch.
   if (transport == DC_COMM_RCCL && nexec > 1) {
+    for (int k = 1; k < nexec; ++k) grow_dev(recv[(size_t)k], payload[(size_t)k], devices[0]);
+    for (int k = 0; k < nexec; ++k)
+      if (payload[(size_t)k]) {
+        HIPCHECK(hipSetDevice(devices[(size_t)k]));
+        HIPCHECK(hipStreamWaitEvent((hipStream_t)comm_stream[(size_t)k], (hipEvent_t)fwd_done[(size_t)k], 0));
+      }
     NCCLCHECK(rccl().GroupStart());
     try {
       for (int k = 1; k < nexec; ++k)
@@ -410,21 +542,11 @@ void Comm::forward(Net* const* nets, const float* const* inputs, const int (*hw)
       throw;
     }
     NCCLCHECK(rccl().GroupEnd());
-  } else {
-    for (int k = 1; k < nexec; ++k)
-      if (payload[(size_t)k]) {
-        HIPCHECK(hipSetDevice(devices[(size_t)k]));
-        if (devices[(size_t)k] == devices[0])
-          HIPCHECK(hipMemcpyAsync(recv[(size_t)k].p, send[(size_t)k].p, payload[(size_t)k], hipMemcpyDeviceToDevice, (hipStream_t)comm_stream[(size_t)k]));
-        else
-          HIPCHECK(hipMemcpyPeerAsync(recv[(size_t)k].p, devices[0], send[(size_t)k].p, devices[(size_t)k], payload[(size_t)k], (hipStream_t)comm_stream[(size_t)k]));
-      }
   }
   for (int k = 0; k < nexec; ++k) {
     HIPCHECK(hipSetDevice(devices[(size_t)k]));
     HIPCHECK(hipStreamSynchronize((hipStream_t)comm_stream[(size_t)k]));
   }
-  HIPCHECK(hipSetDevice(devices[0]));
   items = std::move(placed);  // only a forward that went through is "the last forward"
 }
 

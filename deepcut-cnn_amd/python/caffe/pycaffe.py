@@ -558,7 +558,25 @@ class Net(object):
         for a in (x, prob, loc_pred, next_pred):
             if a is not None and not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]):
                 raise ValueError("forward_host_async wants C-contiguous float32 arrays")
+        if x.ndim != 4:
+            raise ValueError("forward_host_async takes a [n, C, H, W] batch, got shape %s" % (x.shape,))
         n, c, h, w = x.shape
+        # the library reads n*C*h*w floats and writes whole maps through these raw pointers, asynchronously (DMA): a wrongly shaped
+        # array would be silent out-of-bounds host memory access, so every size is checked against the net's own shape inference
+        want_c = self.blobs["data"].channels
+        if c != want_c:
+            raise ValueError("forward_host_async: input has %d channels, the net's 'data' blob %d" % (c, want_c))
+        dims = self.__dict__.setdefault("_host_map_counts", {})
+        key = (n, h, w)
+        if key not in dims:
+            self.blobs["data"].reshape(n, c, h, w)
+            self.reshape()  # shape inference only (host)
+            dims[key] = {k: int(np.prod(self.blobs[k].shape)) for k in ("prob", "loc_pred", "next_pred") if k in self.blobs}
+            while len(dims) > 64:
+                dims.pop(next(iter(dims)))
+        for name, a in (("prob", prob), ("loc_pred", loc_pred), ("next_pred", next_pred)):
+            if a is not None and a.size != dims[key].get(name, -1):
+                raise ValueError("forward_host_async: %s has %d elements, the map of a %s batch %d" % (name, a.size, (n, c, h, w), dims[key].get(name, -1)))
         ptr = lambda a: C.c_void_p(a.ctypes.data if a is not None else 0)  # noqa: E731
         _check(_lib.dc_net_forward_host_async(self._h, ptr(x), n, h, w, ptr(prob), ptr(loc_pred), ptr(next_pred)))
 

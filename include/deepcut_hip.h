@@ -371,9 +371,15 @@ int dc_group_flops(dc_group* group, double* out);
  * own (mode and device are per thread, src/caffe/common.cpp:13-20).  transport: how the maps travel to the root executor's device —
  * DC_COMM_RCCL: one grouped ncclRecv x (n-1) / ncclSend exchange (librccl.so is opened with dlopen at the first use; needs one
  * executor per device); DC_COMM_PEER: hipMemcpyPeerAsync (device-to-device copies when executors share a device: the loop-back
- * transport of the 1-GPU tests); DC_COMM_AUTO: RCCL when it loads and the devices are distinct, else PEER.
+ * transport of the 1-GPU tests); DC_COMM_AUTO: RCCL when it loads, the devices are distinct AND the communicators it makes move a
+ * byte from every peer to the root at creation (dc_comm_create probes them), else PEER; an explicit DC_COMM_RCCL reports the failure
+ * instead.  ENVIRONMENT: on hosts whose driver offers dmabuf IPC only (the MI355X boxes this was built on), RCCL's peer buffers need
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in the process environment BEFORE the HIP runtime is loaded — without it ncclCommInitAll / the first
+ * exchange fail with `hipIpcGetMemHandle: invalid argument`.  The library does not change the environment of its host process.
+ * The calling thread's current HIP device is the same after dc_comm_create / dc_forward_batch as before.
  * dc_forward_batch: `n` host images (inputs[i]: 3 x hw[i][0] x hw[i][1] float32 NCHW, shapes may differ) are dealt to the executors
- * longest-processing-time-first over H*W, every executor forwards the same-shape images of its share as one batch on nets[k] —
+ * longest-processing-time-first over H*W, every executor forwards the same-shape images of its share on nets[k], a group of 8 (float16:
+ * 16) or more images as two sub-batches, so that staging, forward and the way back of consecutive (sub-)batches overlap (round 6) —
  * nets[k] must live on devices[k]: replicas created under dc_set_device(k), or clones where executors share a device —, the maps are
  * gathered on the root's device (dc_comm_root_maps: NCHW float32 device pointers of image i, dims = {prob, loc_pred, next_pred
  * channels, map height, map width}, valid until the next call) and copied to prob[i] / loc_pred[i] / next_pred[i] (host; arrays or

@@ -275,8 +275,9 @@ def test_communicators_and_pipelines_leave_nothing_behind(gpu_caffe, base_net):
 def test_config3_through_the_in_process_path(gpu_caffe, synth152):
     """BASELINE configs[3] at its real size through dc_forward_batch: 64 images of 544x736 (seeds 100..163) on 8 executors — which
     share GPU 0 here; on an 8-GPU node executor k is a replica on device k and the same call gathers over RCCL —, 8 per executor
-    by the LPT schedule, each share forwarded as ONE batch of 8.  Checked: executor 0's share against the single net's batch-8 forward
-    (itself within 1e-3 of the oracle: tests/test_gpu_configs.py), every image against itself across two calls (determinism), and the
+    by the LPT schedule, each share forwarded as TWO sub-batches of 4 (the executor's pipeline: staging of the second under the forward
+    of the first, the way back of the first under the forward of the second).  Checked: executor 0's share against the single net's two
+    batch-4 forwards (themselves within 1e-3 of the oracle: tests/test_gpu_configs.py), every image against itself across two calls (determinism), and the
     maps of an image landing in that image's slot (the input seeds make every image distinct: a permutation would show)."""
     from deepcut_tools import deepercut_prototxt
 
@@ -288,11 +289,12 @@ def test_config3_through_the_in_process_path(gpu_caffe, synth152):
     got = comm.forward(imgs)
     shares = gpu_caffe.lpt_schedule([544.0 * 736] * 64, 8)
     assert [len(s) for s in shares] == [8] * 8 and all(comm.executor_of(i) == k for k, s in enumerate(shares) for i in s)
-    want = net.forward_batch(np.stack([imgs[i] for i in shares[0]]))
-    for b, i in enumerate(shares[0]):
-        for k in ("prob", "loc_pred", "next_pred"):
-            assert got[i][k].shape == want[k][b].shape
-            assert np.array_equal(got[i][k], want[k][b]), (i, k)  # same net, same batch, same tiles: bit-identical
+    for half in (shares[0][:4], shares[0][4:]):
+        want = {k: v.copy() for k, v in net.forward_batch(np.stack([imgs[i] for i in half])).items()}
+        for b, i in enumerate(half):
+            for k in ("prob", "loc_pred", "next_pred"):
+                assert got[i][k].shape == want[k][b].shape
+                assert np.array_equal(got[i][k], want[k][b]), (i, k)  # same net, same sub-batch, same tiles: bit-identical
     again = comm.forward(imgs)
     single = gpu_caffe.Net(deepercut_prototxt(152, 544, 736, 1), path, gpu_caffe.TEST, from_text=True)
     for i in (1, 17, 42, 63):  # images of other executors: against a batch-1 forward of that image (another tile may sum in another order)

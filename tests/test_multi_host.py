@@ -122,3 +122,53 @@ def test_set_tile_keeps_what_the_tune_cache_file_already_held(tmp_path, monkeypa
     net2.set_tile(done[0], [r for r in rep if r["signature"] == done[0]][0]["tile"])
     lines = [ln for ln in cache.read_text().splitlines() if ln.strip()]
     assert len([ln for ln in lines if ln.startswith(done[0] + " ")]) == 1 and all(ln in lines for ln in old)
+
+
+def test_host_async_entry_checks_every_array_against_the_nets_shapes():
+    """forward_host_async hands raw host pointers to asynchronous DMA: a wrongly shaped array must be refused in Python, before the
+    library reads n*C*h*w floats or writes a whole map through it (the checks are host-only shape inference: no GPU needed)"""
+    import caffe
+    from deepcut_tools import deepercut_prototxt
+
+    net = caffe.Net(deepercut_prototxt(152, 64, 80), caffe.TEST, from_text=True)
+    x = np.zeros((1, 3, 64, 80), np.float32)
+    prob = np.zeros((1, 14, 8, 10), np.float32)
+    with pytest.raises(ValueError, match="channels"):
+        net.forward_host_async(np.zeros((1, 4, 64, 80), np.float32), prob=prob)
+    with pytest.raises(ValueError, match="prob has"):
+        net.forward_host_async(x, prob=np.zeros((1, 14, 8, 9), np.float32))
+    with pytest.raises(ValueError, match="next_pred has"):
+        net.forward_host_async(x, next_pred=np.zeros((1, 28, 8, 10), np.float32))
+    with pytest.raises(ValueError, match="batch"):
+        net.forward_host_async(np.zeros((3, 64, 80), np.float32))
+    with pytest.raises(ValueError, match="C-contiguous"):
+        net.forward_host_async(x, prob=np.zeros((1, 14, 8, 20), np.float32)[..., ::2])
+    # well-formed arrays pass the checks and reach the library, which refuses for ITS reason (CPU mode / no device), not a shape
+    with pytest.raises(caffe.DeepcutError):
+        net.forward_host_async(x, prob=prob, loc_pred=np.zeros((1, 28, 8, 10), np.float32), next_pred=np.zeros((1, 364, 8, 10), np.float32))
+
+
+def test_output_selection_on_the_host(tmp_path):
+    """DC_OPT_OUTPUTS is a property of the lowering (host only): launches, FLOPs and the refusal of bad selections"""
+    import caffe
+    from deepcut_tools import deepercut_prototxt
+
+    net = caffe.Net(deepercut_prototxt(152, 544, 736), caffe.TEST, from_text=True)
+    f_all, n_all = net.flops(), len(net.plan_text().splitlines())
+    net.set_outputs(["prob", "loc_pred"])
+    assert net.wanted_outputs == ["loc_pred", "prob"] and net.outputs == ["loc_pred", "next_pred", "prob"]
+    t = net.plan_text()
+    assert "next" not in t and " N=42 " in t and len(t.splitlines()) == n_all  # still one skip GEMM + one merged deconvolution
+    assert abs((f_all - net.flops()) - (2.0 * 2048 * 34 * 46 * 364 * 9 + 2.0 * 364 * 68 * 92 * 512)) < 1e3
+    clone = net.clone()
+    assert clone.wanted_outputs == ["loc_pred", "prob"]  # executors of one model agree on what they compute
+    net.set_outputs(["next_pred"])
+    assert "res5c_up_pose" not in net.plan_text() and "res5c_up_next" in net.plan_text()
+    net.set_outputs(None)
+    assert net.flops() == f_all
+    with pytest.raises(ValueError):
+        net.set_outputs(["res5c"])
+    with pytest.raises(caffe.DeepcutError):
+        net.set_option(4, 0)
+    with pytest.raises(caffe.DeepcutError):
+        net.set_option(4, 8)
