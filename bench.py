@@ -127,6 +127,45 @@ def hbm_traffic_from_profile(workload=("f32", 1, 544, 736)):
     return None, None
 
 
+def mfma_counters_from_profile(workload=("f32", 1, 544, 736)):
+    """What the committed counter passes say about the matrix pipes (profiles/rNN_pmc_mfma_util_in_flight_by_stage.txt, made by
+    tools/pmc_in_flight.sh: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per dispatch window, one executor profiled alone and with the
+    executors of a second, unprofiled process in flight beside it) — counters cannot be read inside the timed run.
+    -> {"busy_cycles_per_forward": MFMA busy cycles of one forward summed over the 1024 SIMDs (a property of the launches, from the
+        ALONE pass), "by_stage_alone": {...}, "by_stage_in_flight": {stage: raw MfmaUtil %}, "source": file} or None."""
+    import glob
+    import re
+
+    want = {("f32", 1, 544, 736): "float32, batch 1", ("f16", 8, 544, 736): "float16, batch 8"}.get(tuple(workload))
+    if want is None:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_mfma_util_in_flight_by_stage.txt")), reverse=True):
+        try:
+            blocks = re.split(r"^################ ", open(path).read(), flags=re.M)[1:]
+            out = {"source": os.path.basename(path)}
+            for b in blocks:
+                head = b.splitlines()[0]
+                if not head.startswith(want):
+                    continue
+                stages = {}
+                for ln in b.splitlines():
+                    m = re.match(r"^(conv1|res2|res3|res4|res5|heads)\b.*?\s(\d+)\s+([\d.]+)%\s+([\d.]+)%", ln)
+                    if m:
+                        stages[m.group(1)] = float(m.group(4))
+                m = re.search(r"MFMA busy cycles per forward .*?: ([\d.e+]+)", b)
+                if "ALONE" in head:
+                    out["by_stage_alone"] = stages
+                    if m:
+                        out["busy_cycles_per_forward"] = float(m.group(1))
+                else:
+                    out["by_stage_in_flight"] = stages
+            if "busy_cycles_per_forward" in out and "by_stage_in_flight" in out:
+                return out
+        except Exception:
+            continue
+    return None
+
+
 def config2_f16_line(caffe, layers, depth, steps, dev, inject, execs=2, tune=True, regions=5):
     """BASELINE configs[2] beside the headline: batch 8 x the 4-scale pyramid of 736x544 (272x368, 408x552, 544x736,
     680x920), float16 operands with float32 accumulation, device-resident.  A step = one pyramid batch (32 forwards = 8
@@ -668,7 +707,7 @@ def main():
     if rank == 0:
         total_images = args.steps * B * world
         launches = net.num_launches()
-        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln)
+        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln or "wino_h23<" in ln)
         # roofline of the dominant kernel family (conv_gemm: every convolution/deconvolution launch):
         # algorithmic FLOPs per launch / average launch duration over the ONE-FORWARD-AT-A-TIME timed
         # region (launches do not overlap there, so the duration is the kernel's own and agrees with
@@ -718,7 +757,7 @@ def main():
                                       "tflops": total_images * flops_img / lat_dt / 1e12},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_gemm + wino_f23 (%s gather-GEMM, all tile variants; Winograd F(2x2,3x3) where it is faster)" % (
+                "kernel": "conv_gemm + wino_f23 / wino_h23 (%s gather-GEMM, all tile variants; Winograd F(2x2,3x3) where it is faster)" % (
                     "f16 v_mfma_f32_32x32x16_f16, fp32 accumulate" if args.dtype == "f16" else "fp32 v_mfma_f32_32x32x2_f32"),
                 "achieved": achieved,
                 "peak": PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS,
@@ -734,8 +773,24 @@ def main():
                                 "algorithmic minimum %.1f MB" % (hbm_traffic_from_profile((args.dtype, B, H, W))[1],
                                                                  (2.07e9 * (H * W) / (544.0 * 736.0) * B + 0.263e9) * (0.5 if args.dtype == "f16" else 1.0) / conv_launches / 1e6),
                 "achieved_with_forwards_in_flight": total_images * flops_img / dt / 1e12,
+                # `value` is the in-flight regime, `frac` above the one-forward-at-a-time one (launches do not overlap there, so a launch
+                # duration exists): the same ratio for the regime of `value`, and what the counters say about it
+                "frac_in_flight": total_images * flops_img / dt / 1e12 / (PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS),
             },
         }
+        mc = mfma_counters_from_profile((args.dtype, B, H, W))
+        if mc:
+            # share of the wall time the 1024 matrix pipes are busy = busy cycles one forward issues (counted) x forwards per second
+            # (this run) / (2.4e9 x 1024): at the 2.4 GHz the loaded chip does not always hold — an upper bound on the clock, a lower
+            # bound on the share.  by_stage: raw SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE of the committed counter windows
+            res["roofline"].update({
+                "mfma_busy_cycles_per_forward": mc["busy_cycles_per_forward"],
+                "mfma_busy_frac_in_flight": mc["busy_cycles_per_forward"] * (total_images / dt / B) / (2.4e9 * 1024),
+                "mfma_busy_frac_one_at_a_time": mc["busy_cycles_per_forward"] * (total_images / lat_dt / B) / (2.4e9 * 1024),
+                "mfma_util_by_stage_in_flight_pct": mc["by_stage_in_flight"],
+                "mfma_util_by_stage_alone_pct": mc.get("by_stage_alone"),
+                "mfma_counters_source": "committed profile profiles/%s (tools/pmc_in_flight.sh)" % mc["source"],
+            })
         # --- measurements reported BESIDE the headline (never as `value`).  Each one is guarded: whatever happens in them,
         #     the line with `value`, `roofline` (and, if it ran, `cpu_baseline`) is printed.
         def beside(key, fn):

@@ -42,6 +42,8 @@ def variant_name(name):
 
 
 def label(name):
+    if "wino_h23" in name:  # the float16 kernel (csrc/wino_f16.hip)
+        return "wino_h23 (Winograd F(2x2,3x3), float16)"
     if "wino_f23" in name:  # wino_f23_kernel<1> / <2> (demangled) or ...wino_f23_kernelILi2EEE... (mangled): 8 / 16 waves per workgroup
         w16 = "wino_f23_kernel<2>" in name or "wino_f23_kernelILi2E" in name
         return "wino_f23_w16 (Winograd F(2x2,3x3), 16 waves)" if w16 else "wino_f23 (Winograd F(2x2,3x3))"

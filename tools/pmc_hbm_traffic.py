@@ -11,7 +11,7 @@ import sys
 
 def per_launch(path, counter):
     c = sqlite3.connect(path)
-    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and (kernel_name like '%conv_gemm%' or kernel_name like '%wino_f23%')",
+    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and (kernel_name like '%conv_gemm%' or kernel_name like '%wino__23%')",
                      (counter,)).fetchone()
     return v / n, n
 
@@ -27,7 +27,7 @@ def main(fetch_db, write_db, desc, min_bytes_per_forward=2.07e9 + 0.263e9):
     f, nf = per_launch(fetch_db, "FETCH_SIZE")
     w, nw = per_launch(write_db, "WRITE_SIZE")
     fam = {}
-    for name, like in (("wino_f23", "%wino_f23%"), ("conv_gemm", "%conv_gemm%")):
+    for name, like in (("wino_f23", "%wino_f23%"), ("wino_h23", "%wino_h23%"), ("conv_gemm", "%conv_gemm%")):
         ff, n = family(fetch_db, "FETCH_SIZE", like)
         ww, _ = family(write_db, "WRITE_SIZE", like)
         fam[name] = {"dispatches": n, "hbm_bytes_per_launch": (2.0 * ff + ww) * 1024.0}
