@@ -302,3 +302,37 @@ def test_config3_through_the_in_process_path(gpu_caffe, synth152):
         for k in ref:
             assert np.array_equal(got[i][k], again[i][k])
             assert float(np.abs(got[i][k] - ref[k][0]).max()) <= 1e-5 * max(1.0, float(np.abs(ref[k]).max())), (i, k)
+
+
+def test_pipeline_tunes_for_its_own_load_when_a_tune_cache_is_set(gpu_caffe, synth152, tmp_path, monkeypatch):
+    """DC_TUNE_CACHE set: the first device-resident request shape a Pipeline meets is re-tuned under the pipeline's own load (what
+    bench.py does for `value`), the overrides land in the cache file, the side-car lists the shape, and a second pipeline in the
+    same or a later process does not tune again; results are the forward's own."""
+    import json
+    import torch
+    from deepcut_tools import Pipeline, deepercut_prototxt
+
+    path, _ = synth152
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("DC_TUNE_CACHE", str(cache))
+    net = gpu_caffe.Net(deepercut_prototxt(152, 64, 80), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+    dev = torch.device("cuda", 0)
+    x = (torch.randn(1, 3, 64, 80) * 50).to(dev)
+    want = net.forward_batch(x.cpu().numpy())
+    pipe = Pipeline(net, depth=2, max_batch=2)
+    outs = [[torch.empty(want[k].shape, device=dev) for k in ("prob", "loc_pred", "next_pred")] for _ in range(6)]
+    for i, o in enumerate(outs):
+        pipe.submit(x.data_ptr(), 1, 64, 80, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), tag=i)
+    assert sorted(pipe.drain()) == list(range(6))
+    (key, rep), = pipe.auto_tune_report.items()
+    assert "64x80" in key and "depth2" in key and rep["runs"] > 0 and rep["after"] <= rep["before"] * 1.05
+    assert key in json.load(open(str(cache) + ".inflight")) and cache.exists()
+    for o in outs:
+        for t, k in zip(o, ("prob", "loc_pred", "next_pred")):
+            assert float((t.cpu() - torch.from_numpy(want[k])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(want[k]).max())), k
+    again = Pipeline(net, depth=2, max_batch=2)
+    again.submit(x.data_ptr(), 1, 64, 80, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr(), tag=0)
+    again.drain()
+    assert again.auto_tune_report == {}  # the side-car says it is done
+    monkeypatch.delenv("DC_TUNE_CACHE")
+    assert Pipeline(net, depth=2)._auto_tune is False
