@@ -75,6 +75,12 @@ constexpr int HLDS16 = HPART16;                        // the staging ring (3 x 
 static_assert(3 * HSTAGE16 <= HLDS16, "the staging ring lives in the memory the partials reuse");
 static_assert((HLDS16 + 32) * 16 <= 160 * 1024, "LDS of a CU");
 constexpr unsigned kOOBh = 0x80000000u;
+#ifndef DC_WINO_LATE_STORE
+#define DC_WINO_LATE_STORE 0
+#endif
+#ifndef DC_WINO_ABL
+#define DC_WINO_ABL 0  // diagnostics builds only (tools/wino_f16_ablate.sh): 1 no barrier in the K loop, 2 MFMAs only, 3 everything but the MFMAs
+#endif
 constexpr int HUB = 1;  // filter-fragment register sets: 1 = the next sub-step's fragments into the registers just read, 2 = two sub-steps ahead
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t h_rsrc(const void* p) {
@@ -245,6 +251,9 @@ __global__ __launch_bounds__(HNTH, 1) void wino_h23_kernel(const ConvGemmParams 
     };
     auto rd = [&](auto u_tag, auto h_tag, auto m_tag, Patch& pt) {
       constexpr int U = decltype(u_tag)::value, HH = decltype(h_tag)::value, M = decltype(m_tag)::value;
+#if DC_WINO_ABL == 2
+      return;
+#endif
       __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist the reads above the adds that free their registers)
 #pragma unroll
       for (int x = 0; x < 3; ++x) {
@@ -254,6 +263,9 @@ __global__ __launch_bounds__(HNTH, 1) void wino_h23_kernel(const ConvGemmParams 
       __builtin_amdgcn_sched_barrier(0);
     };
     auto stage1 = [&](const Patch& pt, Rows& r) {
+#if DC_WINO_ABL == 2
+      return;
+#endif
 #pragma unroll
       for (int x = 0; x < 3; ++x)
 #pragma unroll
@@ -270,11 +282,20 @@ __global__ __launch_bounds__(HNTH, 1) void wino_h23_kernel(const ConvGemmParams 
         const int xa = XA[JP][jj], xb = XB[JP][jj];
         const bool plus = JP == 0 && jj == 1;
         u32x4 v;
+#if DC_WINO_ABL == 2
+        v = u32x4{(unsigned)rofs[jj][0], (unsigned)rofs[jj][1], (unsigned)lane, (unsigned)r.t[0][0][0]};
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = h_as_u(plus ? r.t[xa][e] + r.t[xb][e] : r.t[xa][e] - r.t[xb][e]);
+#endif
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
+#if DC_WINO_ABL == 3
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[M][jj][nf][e] += __builtin_bit_cast(float, ub[S][jj][nf][e] ^ v[e]);
+#else
           acc[M][jj][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ub[S][jj][nf]), __builtin_bit_cast(f16x8, v), acc[M][jj][nf], 0, 0, 0);
+#endif
           if constexpr (decltype(load_tag)::value) bload(S, jj, nf, k16);
         }
       }
@@ -286,14 +307,21 @@ __global__ __launch_bounds__(HNTH, 1) void wino_h23_kernel(const ConvGemmParams 
     auto step = [&](int K, auto u_tag, auto un_tag) {
       constexpr int U = decltype(u_tag)::value;
       const int last = 2 * NS - 1;  // (loads past the end re-read the last sub-step: harmless, never used)
+#if DC_WINO_ABL != 1
       __syncthreads();  // stages <= K+1 are complete; buffer (K+2) % 3 is free
+#endif
       stage1(pt, r), rd(u_tag, T0{}, T1{}, pt), stage2(r, T0{}, T0{}, T0{}, 0);
       stage1(pt, r), rd(u_tag, T1{}, T0{}, pt), stage2(r, T0{}, T1{}, T1{}, min(2 * K + HUB, last));
+#if !DC_WINO_LATE_STORE
       if (K + 2 < NS) sstore((U + 2) % 3, g);
+#endif
       stage1(pt, r), rd(u_tag, T1{}, T1{}, pt), stage2(r, T1{}, T0{}, T0{}, 0);
       stage1(pt, r);
       if (K + 1 < NS) rd(un_tag, T0{}, T0{}, pt);  // the first unit of the next stage (complete since this step's barrier)
       stage2(r, T1{}, T1{}, T1{}, min(2 * K + 1 + HUB, last));
+#if DC_WINO_LATE_STORE
+      if (K + 2 < NS) sstore((U + 2) % 3, g);
+#endif
       if (K + 3 < NS) gload(K + 3);
     };
     __syncthreads();  // stages 0 and 1 are in LDS

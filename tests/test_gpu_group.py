@@ -259,8 +259,14 @@ def test_sharded_runner_groups_the_scales_of_a_pyramid(gpu_caffe, synth152, dtyp
             assert a.shape == b.shape and float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max())), (k, name)
     assert np.allclose(res["item_poses"][:, 2], plain["item_poses"][:, 2], atol=tol)  # confidences of every item
     assert res["best_scale"] == plain["best_scale"] or dtype == "f16"
-    again = runner.run(imgs, scales)  # second run: plans, graphs and group plans are there
+    again = runner.run(imgs, scales, want_maps=True)  # second run: plans, graphs and group plans are there
     assert np.array_equal(again["item_poses"], res["item_poses"])
+    # poses only: the runner leaves `next_pred` out of the lowering (DC_OPT_OUTPUTS; the reference's demo reads prob and loc_pred only,
+    # estimate_pose.py:231-241) — the 42-channel heads run on other tiles, so the poses agree up to the summation order
+    only = runner.run(imgs, scales)
+    assert net.wanted_outputs == ["loc_pred", "prob"] and "res5c_up_next" not in net.plan_text()
+    assert np.allclose(only["item_poses"], res["item_poses"], atol=tol * 50), float(np.abs(only["item_poses"] - res["item_poses"]).max())
+    assert runner.run(imgs, scales, want_maps=True)["maps"][0]["next_pred"].shape[0] == 364  # and back
 
 
 def test_group_tile_choices_persist_in_the_tune_cache_file(gpu_caffe, synth152, refs, monkeypatch, tmp_path):
