@@ -567,6 +567,13 @@ int dc_net_set_tile(dc_net* net, const char* signature, const char* tile) {
 int dc_conv_variant_count(void) { return dc::conv_num_variants(); }
 const char* dc_conv_variant_name(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant(i).name : nullptr; }
 int dc_conv_variant_esize(int i) { return i >= 0 && i < dc::conv_num_variants() ? dc::conv_variant_esize(i) : 0; }
+int dc_wino_half_pack(const float* g, int cout, int cin, int rowscale, float* out, float* row_scale) {
+  REQUIRE(g);
+  REQUIRE(out);
+  REQUIRE(row_scale);
+  if (cout <= 0 || cin <= 0 || cout % 32 || cin % 16) return fail(DC_EINVAL, "dc_wino_half_pack: cout must be a multiple of 32, cin of 16");
+  return guard([&] { dc::wino_half_pack_filters(g, cout, cin, rowscale != 0, out, row_scale); });
+}
 
 // ---- pyramid-grouped execution ---------------------------------------------------------------------------------------
 namespace {

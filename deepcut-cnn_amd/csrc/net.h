@@ -277,6 +277,9 @@ struct Net {
   // stream and the caller collects with synchronize(); truly asynchronous for pinned buffers (dc_host_alloc), staged by the runtime otherwise
   void forward_batch(const float* input, int n, int h, int w, bool is_device, float* prob, float* loc,
                      float* next, void* user_stream, bool host_async = false);
+  // the same from n separate HOST images (one pointer each; pinned memory: the DMA engines read them in place), asynchronous on the
+  // net's own stream — what dc_forward_batch uses when the caller's arrays are pinned: no staging copy on the host
+  void forward_host_images(const float* const* inputs, int n, int h, int w);
   // cross-request batching: n independent single-image requests (device buffers, one pointer set per request) as ONE batch-n forward
   void forward_requests(int n, const float* const* inputs, int h, int w, float* const* prob, float* const* loc, float* const* next,
                         void* user_stream);

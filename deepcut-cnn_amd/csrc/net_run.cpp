@@ -398,6 +398,18 @@ void Net::forward_batch(const float* input, int n, int h, int w, bool is_device,
   if (!(is_device && (user_stream || own_async)) && !host_async) HIPCHECK(hipStreamSynchronize((hipStream_t)s));
 }
 
+void Net::forward_host_images(const float* const* inputs, int n, int h, int w) {
+  Storage& in = begin_batch(n, h, w);
+  const int C = in.dim(1);
+  const size_t img = (size_t)C * h * w;
+  in.ensure_stage(img * n);
+  for (int i = 0; i < n; ++i)
+    HIPCHECK(hipMemcpyAsync(reinterpret_cast<float*>(in.stage) + i * img, inputs[i], img * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  KCHECK(launch_nchw_to_nhwc(reinterpret_cast<const float*>(in.stage), in.dev, in.esize, n, C, h, w, in.cp(), stream));
+  in.head = HEAD_AT_GPU;
+  enqueue_plan(stream);
+}
+
 // n independent requests of one image each -> one batch-n launch plan: at batch 1 a res4 layer is 196 workgroups on 256 CUs
 // and a third of its time is fixed cost; the same layers at batch 2-4 fill the chip and pay the fixed cost once.  The
 // per-request NCHW device buffers are gathered into / scattered from the batch image by the layout kernels themselves.

@@ -141,6 +141,7 @@ def _load():
         "dc_conv_variant_count": (ci, []),
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
+        "dc_wino_half_pack": (ci, [C.c_void_p, ci, ci, ci, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -176,6 +177,17 @@ def device_count():
 def conv_variants():
     """[(name, element size)] of the gather-GEMM tile variants, in DC_CONV_VARIANT index order (diagnostics)."""
     return [((_lib.dc_conv_variant_name(i) or b"").decode(), _lib.dc_conv_variant_esize(i)) for i in range(_lib.dc_conv_variant_count())]
+
+
+def wino_half_pack(g, rowscale=True):
+    """dc_wino_half_pack: the float16 Winograd form's filter image of g [cout, cin, 3, 3] as the lowering packs it (float32 values,
+    before the conversion to half) -> (image [cout/32, 4, cin/16, 4, 64, 8], row_scale [cout]).  Host only (tests)."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    cout, cin = g.shape[:2]
+    out = np.empty((cout // 32, 4, cin // 16, 4, 64, 8), np.float32)
+    rs = np.empty(cout, np.float32)
+    _check(_lib.dc_wino_half_pack(g.ctypes.data_as(C.c_void_p), cout, cin, 1 if rowscale else 0, out.ctypes.data_as(C.c_void_p), rs.ctypes.data_as(C.c_void_p)))
+    return out, rs
 
 
 def canvas_size(height, width, scale):
@@ -944,8 +956,12 @@ class Comm(object):
         t = _lib.dc_comm_transport(self._h)
         return {1: "rccl", 2: "peer"}.get(t, t)
 
-    def forward(self, images, want=("prob", "loc_pred", "next_pred")):
-        """images: a list of float32 [3,H,W] host arrays (shapes may differ) -> a list of dicts of [C,h,w] host arrays."""
+    def forward(self, images, want=("prob", "loc_pred", "next_pred"), pinned=False, out=None):
+        """images: a list of float32 [3,H,W] host arrays (shapes may differ) -> a list of dicts of [C,h,w] host arrays.
+        pinned=True: the result arrays are pinned host memory (caffe.pinned_empty) — the library then downloads every map straight
+        into them on the DMA engines, no scatter copy; images that are pinned arrays themselves are uploaded in place likewise.
+        out: the list a previous call returned (same images' shapes, same `want`): its arrays are written again instead of new ones
+        being made — page-locking 10 MB per image on every call costs more than the copies it saves."""
         xs = [np.ascontiguousarray(x, dtype=np.float32) for x in images]
         n, k = len(xs), len(self.nets)
         if any(x.ndim != 3 or x.shape[0] != 3 for x in xs):
@@ -963,7 +979,14 @@ class Comm(object):
                 m0.blobs["data"].reshape(1, 3, *hw_)
                 m0.reshape()
                 dims[hw_] = {key: tuple(m0.blobs[key].shape[1:]) for key in ("prob", "loc_pred", "next_pred")}
-        outs = [{key: np.empty(dims[(x.shape[1], x.shape[2])][key], np.float32) for key in want} for x in xs]
+        mk = pinned_empty if pinned else (lambda shape: np.empty(shape, np.float32))
+        if out is not None:
+            if len(out) != n or any(set(o) != set(want) or any(tuple(o[key].shape) != tuple(dims[(x.shape[1], x.shape[2])][key]) or o[key].dtype != np.float32
+                                                                 or not o[key].flags["C_CONTIGUOUS"] for key in want) for o, x in zip(out, xs)):
+                raise ValueError("out= must be the result list of a call with the same image shapes and `want`")
+            outs = out
+        else:
+            outs = [{key: mk(dims[(x.shape[1], x.shape[2])][key]) for key in want} for x in xs]
 
         def col(key):
             if key not in want:

@@ -313,6 +313,13 @@ int dc_net_set_tile(dc_net* net, const char* signature, const char* tile);
 int dc_conv_variant_count(void);
 const char* dc_conv_variant_name(int i);
 int dc_conv_variant_esize(int i);
+/* the float16 Winograd form's filter image (csrc/wino_f16.hip, tile `wino_h23`), made on the host exactly as the lowering makes it:
+ * g = [cout][cin][3][3] (Caffe order, convolution_param of a stride-1 3x3 layer; cin % 16 == 0, cout % 32 == 0) -> out[16 * cout * cin]
+ * = U = G g G^T per (co, ci) in double, channel co multiplied by row_scale[co]^-1 — an exact power of two bringing its largest |U|
+ * into [2^13, 2^14) when `rowscale` is non-zero, else 1 —, in MFMA fragment order [cout/32][4 i][cin/16][4 j][64 lanes][8]:
+ * lane = 32 * ((ci % 16) / 8) + co % 32, element = ci % 8.  Diagnostics / tests (the host half of the kernel's parity:
+ * tests/test_wino_half_pack.py); the reference has no counterpart (its 3x3 layers are im2col + SGEMM, base_conv_layer.cpp:257-280). */
+int dc_wino_half_pack(const float* g, int cout, int cin, int rowscale, float* out, float* row_scale);
 
 /* ---- pyramid-grouped execution: several executors of ONE model, each at its own input shape, as ONE launch sequence ----
  * Replaces the scale loop of the demo (python/pose/estimate_pose.py:81-128: one net.forward() per scale, every shape change a

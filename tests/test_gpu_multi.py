@@ -117,6 +117,17 @@ def test_in_process_multi_executor_forward(gpu_caffe, base_net):
             for k in want[i]:
                 # an executor forwards its same-shape images as ONE batch: another tile may sum in another order
                 assert float(np.abs(got[i][k] - want[i][k][0]).max()) <= 1e-5 * max(1.0, float(np.abs(want[i][k]).max())), (rep, i, k)
+    # pinned arrays of the caller travel in place (no staging copy in, no scatter copy out): the same bits
+    pimgs = []
+    for x in imgs:
+        a = gpu_caffe.pinned_empty(x.shape)
+        a[...] = x
+        pimgs.append(a)
+    gotp = c8.forward(pimgs, pinned=True)
+    mixed = c8.forward([pimgs[i] if i % 3 else imgs[i] for i in range(len(imgs))], pinned=False)  # pinned and pageable arrays in one call
+    for i in range(len(imgs)):
+        for k in want[i]:
+            assert np.array_equal(gotp[i][k], got[i][k]) and np.array_equal(mixed[i][k], got[i][k]), (i, k)
     shares = gpu_caffe.lpt_schedule([float(x.shape[1] * x.shape[2]) for x in imgs], 8)
     for kx, share in enumerate(shares):
         assert all(c8.executor_of(i) == kx for i in share)
