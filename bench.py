@@ -832,15 +832,24 @@ def main():
 
         def image_entry():
             # uint8 pixels up (1.2 MB), pre-processing + forward + pose decode on the device, 5x14 doubles down — what the
-            # demo needs per image
+            # demo needs per image.  As pose.estimate_pose runs it since round 6: the net computes `prob` and `loc_pred` only
+            # (DC_OPT_OUTPUTS; the reference's demo never reads `next_pred`, python/pose/estimate_pose.py:231-241: 23.3 of the 241 GFLOP)
             img8 = np.random.RandomState(2).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
-            net.forward_images(img8, 1.0, want=(), pose=True)
-            t1 = time.perf_counter()
-            for _ in range(n_pcie):
-                net.forward_images(img8, 1.0, want=(), pose=True)
-            dt_img = time.perf_counter() - t1
-            return {"value": n_pcie * B / dt_img, "unit": "images/s", "ms_per_forward": dt_img / n_pcie * 1e3,
-                    "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous"}
+
+            def rate(e):
+                e.forward_images(img8, 1.0, want=(), pose=True)
+                t1 = time.perf_counter()
+                for _ in range(n_pcie):
+                    e.forward_images(img8, 1.0, want=(), pose=True)
+                return n_pcie * B / (time.perf_counter() - t1)
+
+            demo = net.clone()
+            demo.set_outputs(["prob", "loc_pred"])
+            v_two, v_all = rate(demo), rate(net)
+            return {"value": v_two, "unit": "images/s", "ms_per_forward": B / v_two * 1e3, "gflop_per_image": demo.flops() / B / 1e9,
+                    "all_three_outputs_computed": {"value": v_all, "ms_per_forward": B / v_all * 1e3, "gflop_per_image": flops_img / 1e9},
+                    "note": "dc_net_forward_images: uint8 HWC in, pose out, synchronous; outputs prob + loc_pred only (DC_OPT_OUTPUTS), beside it the "
+                            "same call on a net that computes next_pred as well"}
 
         def cross_request_batching():
             # deepcut_tools.Pipeline, its default policy: independent batch-1 requests; one goes out alone while an executor is free,

@@ -6,6 +6,7 @@ Tolerances (stated, not 1e-3: activations are rounded to 11 significant bits aft
   loc_pred, next_pred <= 4e-3 x max(1, range of the map)   (measured ~1.4e-3 x range)
 Single layers: <= 2e-3 relative to the output range (one rounding of inputs, weights and output)."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -89,7 +90,7 @@ def test_switching_dtype_on_a_live_net(gpu_caffe, synth152):
                                  ("conv", 1, 1, 0, 1, 2048, 512, 5, 6), ("deconv", 3, 2, 0, 1, 2048, 28, 4, 5)])
 def test_fp16_single_layers(gpu_caffe, cfg):
     kind, k, s, p, d, cin, cout, h, w = cfg
-    rs = np.random.RandomState(abs(hash(cfg)) % (2 ** 31))
+    rs = np.random.RandomState(zlib.crc32(repr(cfg).encode()) & 0x7fffffff)  # (hash() of a tuple holding a str moves with PYTHONHASHSEED)
     typ = "Convolution" if kind == "conv" else "Deconvolution"
     text = ('input: "x" input_dim: 2 input_dim: %d input_dim: %d input_dim: %d\n' % (cin, h, w) +
             'layer { name: "l" type: "%s" bottom: "x" top: "y" convolution_param { num_output: %d kernel_size: %d '

@@ -2,6 +2,8 @@
 DC_OPT_FUSE 0, weights injected through net.params) and every one of the 26 distinct convolution /
 deconvolution configurations of the DeeperCut net at reduced spatial size, against the
 CPU oracle.  fp32; bound 1e-4 relative to the output range (the reference's own conv-test bound)."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -60,7 +62,7 @@ T2 = [
 @pytest.mark.parametrize("batch", [1, 2])
 def test_conv_deconv_configs(gpu_caffe, cfg, batch):
     kind, k, s, p, d, bias, cin, cout, h, w = cfg
-    rs = np.random.RandomState(hash(cfg) % (2 ** 31))
+    rs = np.random.RandomState(zlib.crc32(repr(cfg).encode()) & 0x7fffffff)  # (hash() of a tuple holding a str moves with PYTHONHASHSEED)
     typ = "Convolution" if kind == "conv" else "Deconvolution"
     text = _inp("x", (batch, cin, h, w)) + (
         'layer { name: "l" type: "%s" bottom: "x" top: "y" convolution_param { num_output: %d kernel_size: %d '
