@@ -38,7 +38,8 @@
 //    (SQ_LDS_BANK_CONFLICT of the kernel: 0);
 //  * the transformed filters (16/9 of the filter bytes, no reuse inside a wave) are packed on the host in fragment order
 //    — one wave load = 1 KiB contiguous — and read straight from global memory into registers (32 KB per sub-step and
-//    workgroup, no fragment fetched twice by a workgroup, none through LDS), two sub-steps ahead in two register sets;
+//    workgroup, no fragment fetched twice by a workgroup, none through LDS), the next sub-step's fragment into the registers the
+//    MFMA has just read (HUB = 1; two register sets — two sub-steps ahead — spill: EXPERIMENTS.md I);
 //  * inverse transform: the wave's two positions in registers, the other position pair and the four rows through LDS (128 KB:
 //    the staging ring's memory and more), one tile block per round; then folded BatchNorm/Scale, ReLU, one rounding to
 //    float16, v_permlane32_swap -> 16-byte stores.
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(HNTH, 1) void wino_h23_kernel(const ConvGemmParams 
         for (int e = 0; e < 4; ++e) r.t[x][e] = SB > 0 ? h_as_h2(pt.a[x][e]) + h_as_h2(pt.b[x][e]) : h_as_h2(pt.a[x][e]) - h_as_h2(pt.b[x][e]);
     };
     // S: parity of the unit's sub-step (which fragment register set); LOAD: the unit's MFMAs are the last readers of that set —
-    // each requests the fragment of sub-step k16 (two sub-steps ahead) into the registers it has just read
+    // each requests the fragment of sub-step k16 (HUB sub-steps ahead) into the registers it has just read
     auto stage2 = [&](const Rows& r, auto s_tag, auto m_tag, auto load_tag, int k16) {
       constexpr int S = decltype(s_tag)::value % HUB, M = decltype(m_tag)::value;
 #pragma unroll
