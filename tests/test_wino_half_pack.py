@@ -66,3 +66,43 @@ def test_bad_sizes_are_refused():
         caffe.wino_half_pack(np.zeros((48, 32, 3, 3), np.float32))
     with pytest.raises(caffe.DeepcutError):
         caffe.wino_half_pack(np.zeros((32, 24, 3, 3), np.float32))
+
+
+def test_the_kernels_float16_arithmetic_emulated_in_numpy_stays_inside_the_layer_bound():
+    """No GPU: the arithmetic of wino_h23 restated in NumPy with float16 where the kernel has float16 — activations rounded to half,
+    pre-multiplied by 1/4 (exact), B^T d B by packed float16 adds (two roundings), the row-scaled filter image rounded to half,
+    products accumulated wider, inverse transform and the x 4 x row-scale epilogue in float32 — against the CPU oracle's float32
+    convolution (oracle/caffe_cpu.c: im2col + SGEMM, base_conv_layer.cpp:257-280).  Bound: the float16 path's single-layer 2e-3 x range
+    (tests/test_gpu_fp16.py); what the GPU kernel measures is 4-7e-4 x range."""
+    from oracle import oracle as O
+
+    rs = np.random.RandomState(3)
+    cin, cout, h, w = 64, 64, 12, 10
+    x = rs.randn(1, cin, h, w).astype(np.float32)
+    g = (rs.randn(cout, cin, 3, 3) / np.sqrt(9.0 * cin)).astype(np.float32)
+    ref = O.conv_forward(x, g, None, 1, 1, 1)[0]
+    img, scale = caffe.wino_half_pack(g, rowscale=True)
+    u16 = _unpack(img, cout, cin).astype(np.float16)                      # [co, ci, i, j], as uploaded
+    xp = np.zeros((cin, h + 2 + 2, w + 2 + 2), np.float16)               # zero padding 1 (+ slack for the last tile)
+    xp[:, 1:h + 1, 1:w + 1] = x[0].astype(np.float16) * np.float16(0.25)  # staged pixels: rounded to half, x 1/4 (exact)
+    out = np.zeros((cout, h, w), np.float32)
+    for ty in range((h + 1) // 2):
+        for tx in range((w + 1) // 2):
+            d = xp[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]              # [ci, 4, 4] float16
+            t = np.stack([d[:, 0] - d[:, 2], d[:, 1] + d[:, 2], d[:, 2] - d[:, 1], d[:, 1] - d[:, 3]], 1)      # B^T rows: float16 adds
+            v = np.stack([t[:, :, 0] - t[:, :, 2], t[:, :, 1] + t[:, :, 2], t[:, :, 2] - t[:, :, 1], t[:, :, 1] - t[:, :, 3]], 2)
+            assert t.dtype == np.float16 and v.dtype == np.float16
+            m = np.einsum("ocij,cij->oij", u16.astype(np.float64), v.astype(np.float64)).astype(np.float32)   # MFMA: exact products, wide sums
+            y = np.einsum("ai,oij,bj->oab", AT.astype(np.float32), m, AT.astype(np.float32)) * (np.float32(4.0) * scale)[:, None, None]
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = y[:, :min(2, h - 2 * ty), :min(2, w - 2 * tx)]
+    out = out.astype(np.float16).astype(np.float32)                       # the stored activation
+    err, rng = float(np.abs(out - ref).max()), float(np.abs(ref).max())
+    assert 1e-5 * rng < err <= 2e-3 * max(1.0, rng), (err, rng)
+    # and the 1/4 is what keeps a trunk at 70 % of float16's range finite: without it the transformed patch overflows
+    big = np.full((1, 4, 4), 4.6e4, np.float16)
+    big[0, 1::2, :] *= np.float16(-1)  # alternating rows: B^T rows 1..3 subtract, so magnitudes add
+    with np.errstate(over="ignore"):
+        assert np.isinf((big[:, 2] - big[:, 1]).astype(np.float16)).any()
+    q = big * np.float16(0.25)
+    tq = q[:, 2] - q[:, 1]
+    assert np.isfinite(tq).all() and np.isfinite(tq[:, 2:3] - tq[:, 1:2]).all()
