@@ -1,6 +1,11 @@
 """-m gpu: dc_net_detect_parts / dc_net_decode_pairwise against oracle/multiperson.py on the maps
 of a real forward.  The score threshold sits between values, so the candidate SETS must agree exactly; scores and cell
-indices bit-for-bit, refined positions to double-precision rounding."""
+indices bit-for-bit, refined positions to double-precision rounding.
+
+PARITY UNPINNED BY THE REFERENCE: eldar/deepcut-cnn has no consumer of `next_pred` and no part-candidate extraction (it stops at the maps,
+SURVEY F6), so there is no reference output, test or golden vector to hold these kernels to.  The oracle restates the INVERSE of the label
+encoding of the reference's training layer (src/caffe/layers/pose_data_layer.cpp:686-802), and that encoding is all it is pinned to
+(tests/test_multiperson_oracle.py); what is proven here is that the device kernels compute exactly what that restatement computes."""
 import numpy as np
 import pytest
 
