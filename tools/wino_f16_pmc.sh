@@ -1,3 +1,7 @@
+#!/bin/bash
+# ON THE GPU BOX: SQ counters of the forced wino_h23 launch on the conv4_x 3x3 shape (batch 8, 544x736), three passes of eight counters
+# (separate runs: --pmc with --kernel-trace only).  WAVE_CYCLES / WAIT_* / ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles
+# (32 per v_mfma_f32_32x32x16_f16); LDS_BANK_CONFLICT / LDS_IDX_ACTIVE: extra / all LDS-array cycles.   gpurun -- 'bash tools/wino_f16_pmc.sh'
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   n=$1; shift
@@ -10,5 +14,5 @@ for r in c.execute("select counter_name, sum(value) from counters_collection whe
 PY
 }
 run a SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
-run b SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_ACTIVE_INST_MISC
-run c SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE
+run b SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INSTS_LDS
+run c SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_IFETCH GRBM_GUI_ACTIVE
