@@ -159,8 +159,11 @@ int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stre
 constexpr int kWinoVariant = 1000;             // Launch::variant value that selects this kernel: 8 waves per workgroup ("wino_f23")
 constexpr int kWinoVariant16 = 1001;           // ... its 16-wave form ("wino_f23_w16": launches of at most one workgroup per CU, kernels.hip)
 constexpr int kWinoHalf = 1002;                // the float16 kernel (wino_f16.hip, "wino_h23"): fp16 operands, fp32 accumulate
-inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf; }
-inline int wino_variant_esize(int v) { return v == kWinoHalf ? 2 : 4; }  // element size of the nets the form serves
+constexpr int kStreamHalf = 1003;              // NOT Winograd: the float16 streaming form of the dense 1x1 layers (stream1x1.hip, "ws1x1") — listed
+                                               // here because it is handled like one everywhere: a form outside the tile table with a filter
+                                               // image of its own (Launch::wino_w), timed against the tiles per shape
+inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf || v == kStreamHalf; }
+inline int wino_variant_esize(int v) { return v == kWinoHalf || v == kStreamHalf ? 2 : 4; }  // element size of the nets the form serves
 const char* wino_variant_name(int variant);    // the tile name of tune caches / reports / set_tile
 const char* wino_kernel_label(int variant);    // the kernel column of plan texts
 int wino_variant_by_name(const char* name);    // -1: not a Winograd tile name
@@ -178,6 +181,14 @@ long wino_half_grid(const ConvGemmParams& p);
 size_t wino_half_packed_elems(int Cout, int Cin);
 void wino_half_pack_filters(const float* g, int Cout, int Cin, bool rowscale, float* out, float* row_scale);
 int launch_wino_half(const ConvGemmParams& p, void* stream);
+// ---- the streaming form of the dense float16 1x1 / stride-1 layers (stream1x1.hip): filters resident in registers, the pixels walked in
+// 32-pixel steps through an LDS-DMA ring.  `w` is the image made by stream1x1_pack_filters() uploaded as _Float16; x / y / resid / scale /
+// shift / relu as the gather-GEMM (the epilogue is the same instruction sequence: bit-identical results)
+bool stream1x1_eligible(const ConvGemmParams& p);
+long stream1x1_grid(const ConvGemmParams& p);
+size_t stream1x1_packed_elems(int Cout, int K);
+void stream1x1_pack_filters(const float* g, int Cout, int K, float* out);
+int launch_stream1x1(const ConvGemmParams& p, void* stream);
 
 // The remaining kernels take `esize` = bytes per device element (4 float / 2 _Float16); host-side tensors
 // and the per-channel affine vectors are always float.

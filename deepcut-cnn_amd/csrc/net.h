@@ -169,10 +169,13 @@ struct Launch {
   ConvGemmParams cg{};  // pointers filled at launch time
   int variant = 0;
   std::shared_ptr<DevVec> w, scale, shift;  // packed filters / folded affine (kept alive by the plan)
-  std::shared_ptr<DevVec> wino_w;           // Winograd-transformed filters (eligible 3x3 layers), else null
+  std::shared_ptr<DevVec> wino_w;           // Winograd-transformed filters (eligible 3x3 layers) / the fragment-order image of the streaming
+                                            // form (eligible float16 1x1 layers, stream1x1.hip), else null
   std::shared_ptr<DevVec> wino_scale;       // float16 nets: the epilogue scale of the Winograd form (folded affine x the image's row scale x 4)
   // a Winograd form this launch can run as: the image exists and the form serves the net's element type
-  bool takes_wino(int v) const { return is_wino_variant(v) && (bool)wino_w && wino_variant_esize(v) == cg.esize && cg.ncls <= 1; }
+  bool takes_wino(int v) const {
+    return is_wino_variant(v) && (bool)wino_w && wino_variant_esize(v) == cg.esize && cg.ncls <= 1 && (v == kStreamHalf) == (cg.nty == 1 && cg.ntx == 1);
+  }
   long y_off = 0;                      // element offset of this launch's first output (deconvolution classes, channel splits)
   long w_off = 0;                      // element offset of this launch's first filter row inside `w` (channel splits)
   int c_off = 0;                       // first output channel of this launch inside scale / shift (channel splits)

@@ -493,6 +493,7 @@ void Net::build_plan() {
   };
   // -1: where measured faster (autotune); 0: never; 1: wherever eligible, 8 waves per workgroup; 2: wherever eligible, the 16-wave form
   const int wino_mode = env_int("DC_WINOGRAD", -1);
+  const int stream_mode = env_int("DC_STREAM1X1", -1);  // the streaming form of the float16 dense 1x1 layers: -1 where measured faster, 0 never, 1 wherever eligible
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
     double bc = 0;
@@ -699,6 +700,22 @@ void Net::build_plan() {
           for (int q = 0; q < OC; ++q) h[q] = (float)((op.a.empty() ? 1.0 : op.a[q]) * 4.0 * (double)(ws->row_scale.empty() ? 1.f : ws->row_scale[q]));
         });
         if (wino_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kWinoHalf);
+      } else if (!rowtap && stream_mode != 0 && op.wls.empty() && dtype == 1 && g.klen == C && g.Ktot == C && stream1x1_eligible(g)) {
+        // float16 dense 1x1 layers (stream1x1.hip): the same row-scaled filters as the direct image, in MFMA fragment order;
+        // scale / shift / shortcut are the launch's own.  The per-shape timing decides (DC_STREAM1X1=1: wherever eligible, 0: never)
+        std::shared_ptr<DevVec> direct = l.w;
+        l.wino_w = get_vec(dkey + "ws:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          const float* src = L.params[0]->st->host_ptr();  // [OC][C][1][1]
+          std::vector<float> scaled((size_t)OC * C);
+          for (int co = 0; co < OC; ++co) {
+            const float f = direct->row_scale.empty() ? 1.f : 1.f / direct->row_scale[co];  // an exact power of two
+            for (int k = 0; k < C; ++k) scaled[(size_t)co * C + k] = src[(size_t)co * C + k] * f;
+          }
+          h.assign(stream1x1_packed_elems(OC, C), 0.f);
+          stream1x1_pack_filters(scaled.data(), OC, C, h.data());
+        });
+        l.wino_w->as_half = true;
+        if (stream_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStreamHalf);
       }
       if (l.wino_w || rowtap) plan.push_back(std::move(l));
       else push_split(std::move(l), kgcd);

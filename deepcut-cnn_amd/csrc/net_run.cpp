@@ -114,7 +114,7 @@ void Net::run_launch(const Launch& l, void* s) {
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
         // device-side phase timestamps of ONE launch (diagnostics only): per wave the shader cycle counter at up to 8 phase
         // boundaries (slots 0..7) and the chip-wide 100 MHz clock at start / end (slots 8, 9)
-        const int nwv = wino ? (l.variant == kWinoVariant16 ? 16 : 8) : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
+        const int nwv = wino ? (l.variant == kWinoVariant16 ? 16 : l.variant == kStreamHalf ? 4 : 8) : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
         const long n = (l.grid * 2 + 64) * nwv * 12;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         dev_alloc((void**)&d, n * sizeof(long long));
@@ -152,10 +152,14 @@ void Net::run_launch(const Launch& l, void* s) {
                                        "K loop", "split-K exchange", "epilogue math+stores"};
         static const char* kWino[7] = {"index setup", "first loads issued", "two stages in LDS", "K loop", "partials to LDS + barrier",
                                        "inverse transform + epilogue constants", "shortcut + stores"};
+        // ws1x1 (stream1x1.hip) slots: 0 start, 1 every prologue request issued, 2 first stage + filters + constants landed, 3 first step's
+        // barrier + MFMAs issued, 4 its epilogue issued, 5 last step done, 6 requests drained
+        static const char* kStream[7] = {"prologue requests issued", "first stage + filters landed", "first step: barrier + MFMAs", "first step: epilogue",
+                                         "the other steps", "drain", "exit"};
         std::string line;
         for (int k = 1; k < 8; ++k) {
           char buf[96];
-          std::snprintf(buf, sizeof buf, "%s%s %.0f", k > 1 ? " | " : "", (wino ? kWino : kGemm)[k - 1], dsum[k] / std::max(cnt, 1L));
+          std::snprintf(buf, sizeof buf, "%s%s %.0f", k > 1 ? " | " : "", (l.variant == kStreamHalf ? kStream : wino ? kWino : kGemm)[k - 1], dsum[k] / std::max(cnt, 1L));
           line += buf;
         }
         std::fprintf(stderr, "[dc timing] launch %d %s %s\n  mean cycles per wave: %s\n", my_idx, l.kernel.c_str(), l.label.c_str(), line.c_str());

@@ -1,0 +1,514 @@
+// stream1x1.hip — the float16 1x1 / stride-1 layers whose time is memory traffic, not arithmetic, as a STREAM ("ws1x1": weight-stationary).
+//
+// Which layers: the 1x1 expansions that close a bottleneck block with the shortcut add + ReLU (resNx_branch2c, ResNet-152.prototxt: 64 -> 256,
+// 128 -> 512, 256 -> 1024, 512 -> 2048 channels) and the stride-1 projections (res2a_branch1).  At batch 8 (BASELINE configs[2]) a res4 one
+// moves 58 MB (6.4 in, 25.6 shortcut, 25.6 out) for 6.6 GFLOP: 9 us of HBM time, 2.6 us of MFMA time — the gather-GEMM tile took 17.3 us
+// (3.35 TB/s): per 128 x 64 tile it paid 3.7 k cycles of prologue, a 4-tile K loop that waits for memory once per tile (MFMA content 1.0 k of
+// 5.7 k cycles) and a 2.3 k epilogue, with one tile per workgroup in flight (profiles/r06_stream1x1_*.txt; VERDICT r5 weak spot 1: "the
+// 1x1+shortcut layers reach 3.2 TB/s where 6.3 is achievable").
+//
+// The form here, per workgroup of 4 waves:
+//  * the FILTERS of its channel slice (128 * FN channels x all K) live in REGISTERS for the whole launch, as the A operand of
+//    v_mfma_f32_32x32x16_f16 (rows = output channels): fetched once, in fragment order, 1 KiB per wave instruction (ws_pack_filters);
+//  * the workgroup walks a contiguous range of 32-pixel STEPS (a persistent loop, the grid is ~2 workgroups per CU); the pixels of a step
+//    (32 x K halves) travel by LDS-DMA into a ring of D stages, D-1 steps ahead of their use, swizzled at the source like the gather-GEMM's
+//    operand tiles (conflict-free ds_read_b128 B operands); one workgroup barrier per step;
+//  * the shortcut vectors of the NEXT step are requested before the MFMAs of this one (registers), the epilogue (folded BatchNorm/Scale affine
+//    in fp32, shortcut add by v_fma_mix, ReLU, 16-byte stores formed with v_permlane32_swap) is the gather-GEMM's swapped-operand one —
+//    same instructions in the same order, so the results are bit-identical to the direct tiles';
+//  * vmcnt is counted: DMA pieces, shortcut loads and stores of a step are a fixed number of requests (dummy out-of-range requests past the
+//    end of the range), so "my pieces of step s have landed" is s_waitcnt vmcnt(constant) with D-1 steps still in flight;
+//  * blocks of the same pixel range (the tn channel slices) are neighbours on one XCD (blockIdx % 8), so the pixels cross the fabric once.
+// A multi-problem launch (NetGroup: the scales of an image pyramid) is the same walk over the steps of several tensors in turn.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace dc {
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOOBs = 0x80000000u;
+#pragma clang diagnostic ignored "-Winline-asm"
+
+struct WsProblem {
+  const void* x;
+  void* y;
+  const void* resid;
+  int M;      // pixels
+  int sxb;    // bytes between the pixels of x
+  int ypb;    // bytes between the pixels of y (and resid)
+  int step0;  // first step of this tensor in the launch-wide numbering
+};
+struct WsArgs {
+  const void* w;  // ws_pack_filters image, _Float16
+  const float* scale;
+  const float* shift;
+  int Cout, relu, tn, J, S, nprob;
+  unsigned div_tn[2], div_J[2];
+  long long* dbg;
+  WsProblem prob[kMaxProblems];
+};
+
+__device__ __forceinline__ i32x4 s_rsrc_words(const void* p) {
+  const unsigned long long a = (unsigned long long)p;
+  return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+}
+// LDS-DMA, as dc_dma16 of kernels.hip (inline asm: the compiler must not make later ds_reads wait for vmcnt(0))
+__device__ __forceinline__ void s_dma16(i32x4 rs, unsigned lds, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
+}
+// a 16-byte buffer store the compiler does not track (no s_waitcnt of its own): the counted vmcnt below covers it
+// (the s_nop behind it: a store of more than 8 bytes reads its data registers over several cycles, and the hazard recogniser, which does not
+//  look inside inline asm, let a v_or overwrite the first of them in the next cycle — one wrong dword per vector on some lanes)
+__device__ __forceinline__ void s_store16_untracked(i32x4 rs, unsigned voff, u32x4 v) {
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void s_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int s_fastdiv(int n, const unsigned (&mg)[2]) {
+  return (mg[1] >> 31) ? n : (int)(__umulhi((unsigned)n, mg[0]) >> (mg[1] & 31));
+}
+__device__ __forceinline__ void s_permlane32_swap4(float (&lo)[4], float (&hi)[4]) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+      : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+}
+__device__ __forceinline__ float s_add_half_lo(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
+}
+__device__ __forceinline__ float s_add_half_hi(unsigned h2, float f) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(f));
+  return d;
+}
+
+// KC = K / 16 (MFMA steps along the input channels), FN = 32-channel fragments per wave, NW = waves per workgroup (its channel slice is
+// NW * FN * 32 wide), D = ring stages, RES = the layer has a shortcut operand, RELU, MULTI = more than one tensor (problem) in the launch.
+// The step loop is issue-bound once memory is out of the way (stamps inside a step: no wait longer than 200 cycles, 4 k cycles of
+// instructions per wave and step with two waves per SIMD), so everything that is not a matrix, LDS or memory instruction was taken out of
+// it: no branch except the loop's own (RELU / MULTI are template parameters, the first D-1 steps with their own vmcnt counts are peeled),
+// addresses are a per-lane constant + a scalar per step, masked by one compare (no 64-bit multiply-add, no exec juggling).
+template <int KC, int FN, int NW, int D, bool RES, bool RELU, bool MULTI>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const WsArgs a) {
+  const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
+  constexpr int NT = NW * 64;
+  constexpr int RB = KC * 32;       // bytes of a pixel's K halves = one row of a stage
+  constexpr int STG = 32 * RB;      // a stage: 32 pixels
+  constexpr int NPC = STG / 1024;   // its 1 KiB DMA pieces
+  constexpr int NA = NPC / NW;      // ... per wave
+  constexpr int LPR = RB / 16;      // lanes (16-byte chunks) per row
+  constexpr int PPI = 1024 / RB > 0 ? 1024 / RB : 1;  // rows per piece
+  constexpr int BN = NW * FN * 32;
+  // a wave's own 32 pixels x FN*32 channels of shortcut / output: rows of RBO bytes, NO 1 KiB pieces, two buffers with a shortcut
+  constexpr int RBO = FN * 64, OBUF = 32 * RBO, NO = OBUF / 1024, LPO = RBO / 16, RPO = 1024 / RBO, NOB = RES ? 2 : 1;
+  constexpr int NR = RES ? NO : 0, NS = NO;  // shortcut requests / stores per wave and step
+  constexpr bool CREG = FN == 1;             // epilogue constants in registers (32 of them) instead of re-read from LDS every step
+  static_assert(NPC % NW == 0 && NA >= 1, "a stage is a whole number of pieces per wave");
+  static_assert(RB == 128 || RB == 256 || RB == 512 || RB == 1024, "row swizzles below");
+  static_assert(RBO == 64 || RBO == 128, "row swizzles below");
+  static_assert(D >= 2 && D <= 4, "the peeled early steps below");
+  static_assert((D - 2) * NA + (D - 1) * (NR + NS) <= 63 && 2 * NA + NS + NR <= 63, "vmcnt is a 6-bit counter");
+  static_assert(BN <= NT, "one epilogue constant per thread");
+  constexpr int LDSB = D * STG + NW * NOB * OBUF + 2 * BN * 4;
+  static_assert(LDSB <= (NW == 8 ? 160 : 80) * 1024, "LDS of a CU (two workgroups of the 4-wave form)");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
+  float* scl = reinterpret_cast<float*>(smem + D * STG + NW * NOB * OBUF);
+  float* shl = scl + BN;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p32 = lane & 31, h = lane >> 5;
+
+  // ---- block -> (channel slice nt, pixel-range chunk jc): XCD x = blockIdx % 8 walks chunks x, x + 8, ..., all tn slices of a chunk in a row
+  const int bx = blockIdx.x, xcd = bx & 7, bi = bx >> 3;
+  const int ci = s_fastdiv(bi, a.div_tn);
+  const int nt = bi - ci * a.tn;
+  const int jc = xcd + 8 * ci;
+  if (jc >= a.J) return;
+  const int gs0 = s_fastdiv(a.S * jc, a.div_J), gs1 = s_fastdiv(a.S * (jc + 1), a.div_J);  // S * J < 2^31 (host)
+  const int n0 = nt * BN;
+  const int nw0 = n0 + wave * FN * 32;  // first channel of this wave
+
+  // ---- the epilogue constants of the slice (one channel per thread) and the filters of this wave's FN fragments (registers, for the whole
+  //      launch).  Untracked loads, like everything else this kernel asks memory for: a load the compiler tracks gets an s_waitcnt vmcnt of
+  //      the compiler's own counting in front of its first use — inside the step loop that was vmcnt(0) on every step (the filters' first use
+  //      is the loop's first MFMA, and the back-edge keeps them "possibly pending"): every step drained the ring.  They are the OLDEST
+  //      requests of the wave, so the wait for the first stage covers them.
+  float c_sc = 1.f, c_sh = 0.f;
+  {
+    const unsigned co = t < BN ? (unsigned)((n0 + t) * 4) : kOOBs;
+    if (a.scale) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sc) : "v"(co), "s"(s_rsrc_words(a.scale)) : "memory");
+    if (a.shift) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sh) : "v"(co), "s"(s_rsrc_words(a.shift)) : "memory");
+  }
+  u32x4 wreg[FN][KC];
+  {
+    const i32x4 wrs = s_rsrc_words(a.w);
+    const int f0 = nw0 >> 5;
+    const unsigned wl = (unsigned)lane * 16u;
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        const unsigned so = (unsigned)(((f0 + f) * KC + kk) * 1024);
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wreg[f][kk]) : "v"(wl), "s"(wrs), "s"(so) : "memory");
+      }
+  }
+
+  // ---- per-lane constants of the DMA pieces and of the fragment reads
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // lane (pixel p32, K half h) reads chunk 2 kk + h of row p32: position (2 kk + h) ^ swz(p32) = ((h ^ swz) * 16) ^ (kk * 32) in bytes
+  const unsigned frag0 = (unsigned)(p32 * RB + (((h ^ (RB == 128 ? ((p32 >> 1) & 7) : (p32 & 15))) * 16)));
+  // the wave's shortcut / output tile, two views of the same swizzled image (position s of row r holds the row's chunk s ^ swo(r),
+  // swo(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3 for 64-byte rows: both views read and write without bank conflicts):
+  //  * memory view, piece i (1 KiB = RPO whole rows, what one DMA request / one store instruction moves): lane -> row i RPO + lane / LPO,
+  //    position lane % LPO: LPO consecutive lanes cover one contiguous run of RBO bytes of the tensor;
+  //  * MFMA view, vector (f, j): lane (p32, h) -> row p32, chunk f 4 + j 2 + h (what v_permlane32_swap leaves in a lane: 8 channels).
+  // (The scattered form of these accesses — every lane its own 16 bytes of a different cache line, as the gather-GEMM's swapped-operand
+  //  epilogue has them — costs the texture-address unit one line per lane.)
+  auto swo = [](int r) { return RBO == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+  const unsigned ovec0 = (unsigned)(p32 * RBO);  // + ((f 4 + j 2 + h) ^ swo(p32)) * 16
+  const int oswz = swo(p32);
+  const unsigned obuf0 = (unsigned)(D * STG + wave * NOB * OBUF);  // this wave's buffers inside smem
+
+  // ---- the tensor (problem) a step belongs to: three monotone cursors (pixels run D-1 steps ahead, the shortcut two steps ahead).
+  //      Per cursor: descriptor, pixels of the tensor, its first step, and the per-lane byte offsets of the requests of a step at row 0
+  struct Cur {
+    int pi, M, step0, pitch;
+    i32x4 rs;
+  };
+  Cur cd, cr, cc;
+  int arow[NA], orow[NO];
+  unsigned aoff[NA], roff[NO], yoff[NO];  // (single tensor: constants of the launch; MULTI: recomputed when a cursor moves on)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) arow[i] = (wave + NW * i) * PPI + lane / LPR;
+#pragma unroll
+  for (int i = 0; i < NO; ++i) orow[i] = i * RPO + lane / LPO;
+  auto set_cd = [&](int pi) {
+    cd.pi = pi, cd.M = a.prob[pi].M, cd.step0 = a.prob[pi].step0, cd.pitch = a.prob[pi].sxb, cd.rs = s_rsrc_words(a.prob[pi].x);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = arow[i], sl = lane % LPR;
+      aoff[i] = (unsigned)r * (unsigned)cd.pitch + (unsigned)((sl ^ (RB == 128 ? ((r >> 1) & 7) : (r & 15))) * 16);
+    }
+  };
+  auto set_co = [&](Cur& c, unsigned (&off)[NO], int pi, const void* base) {
+    c.pi = pi, c.M = a.prob[pi].M, c.step0 = a.prob[pi].step0, c.pitch = a.prob[pi].ypb, c.rs = s_rsrc_words(base);
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int r = orow[i], sl = lane % LPO;
+      off[i] = (unsigned)r * (unsigned)c.pitch + (unsigned)(nw0 * 2) + (unsigned)((sl ^ swo(r)) * 16);
+    }
+  };
+  auto find = [&](int pi, int gs) {  // gs only grows
+    while (pi + 1 < a.nprob && gs >= a.prob[pi + 1].step0) ++pi;
+    return pi;
+  };
+  {
+    const int pi = MULTI ? find(0, gs0) : 0;
+    set_cd(pi);
+    set_co(cr, roff, pi, RES ? a.prob[pi].resid : a.prob[pi].y);
+    set_co(cc, yoff, pi, a.prob[pi].y);
+  }
+
+  // requests of a step: always the same number (past the range: out-of-range offsets — zeros into a free stage, nothing stored)
+  auto dma_step = [&](int gs, int slot) {  // NA requests
+    if (MULTI && gs < gs1) {
+      const int pi = find(cd.pi, gs);
+      if (pi != cd.pi) set_cd(pi);
+    }
+    const int row0 = (gs - cd.step0) * 32;
+    const int lim = gs < gs1 ? cd.M - row0 : 0;  // rows of the step that exist
+    const unsigned so = (unsigned)row0 * (unsigned)cd.pitch;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s_dma16(cd.rs, lds0 + (unsigned)(slot * STG + (wave + NW * i) * 1024), arow[i] < lim ? aoff[i] + so : kOOBs);
+  };
+  auto resid_step = [&](int gs, int buf) {  // NR requests: the wave's shortcut tile of step gs -> its buffer `buf`
+    if (!RES) return;
+    if (MULTI && gs < gs1) {
+      const int pi = find(cr.pi, gs);
+      if (pi != cr.pi) set_co(cr, roff, pi, a.prob[pi].resid);
+    }
+    const int row0 = (gs - cr.step0) * 32;
+    const int lim = gs < gs1 ? cr.M - row0 : 0;
+    const unsigned so = (unsigned)row0 * (unsigned)cr.pitch;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) s_dma16(cr.rs, lds0 + obuf0 + (unsigned)(buf * OBUF + i * 1024), orow[i] < lim ? roff[i] + so : kOOBs);
+  };
+  auto stamp = [&](int sl) {  // DC_DEBUG_TIMING: per-wave phase stamps (format of conv_gemm_kernel)
+    if (a.dbg && lane == 0) {
+      long long* d = a.dbg + ((long)blockIdx.x * NW + wave) * 12;
+      d[sl] = (long long)__builtin_readcyclecounter();
+      if (sl == 0) d[8] = t_entry, d[10] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (sl == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+  };
+  stamp(0);
+
+  // ---- prologue: D-1 steps of pixels and the shortcut tiles of the first two steps behind the filters
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) dma_step(gs0 + d, d);
+  resid_step(gs0, 0);
+  resid_step(gs0 + 1, 1);
+  stamp(1);
+  // the first stage, and with it everything older (constants, filters), has landed; the registers of the untracked loads are tied to the wait
+  s_wait_vm<(D - 2) * NA + 2 * NR>();
+  asm volatile("" : "+v"(c_sc), "+v"(c_sh));
+#pragma unroll
+  for (int f = 0; f < FN; ++f)
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) asm volatile("" : "+v"(wreg[f][kk]));
+  if (t < BN) scl[t] = c_sc, shl[t] = c_sh;
+  stamp(2);
+  // FN == 1: the 16 scales and 16 shifts of the lane's channels, in registers for the whole launch (read back once, behind a barrier of
+  // its own; channel order of the accumulator registers: 8 (r >> 2) + 4 h + (r & 3))
+  f32x4 csc[CREG ? 4 : 1], csh[CREG ? 4 : 1];
+  if (CREG) {
+    s_lds_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      csc[CREG ? g : 0] = *reinterpret_cast<const f32x4*>(scl + wave * 32 + 8 * g + 4 * h);
+      csh[CREG ? g : 0] = *reinterpret_cast<const f32x4*>(shl + wave * 32 + 8 * g + 4 * h);
+    }
+  }
+
+  const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
+  int slot = 0, ob = 0;
+  // one step.  EARLY = k for the first D-1 steps of the walk (their pieces were requested by the prologue: other vmcnt counts), -1 after
+  auto do_step = [&](int gs, auto early_tag) {
+    constexpr int EARLY = decltype(early_tag)::value;
+    // (1) my pieces of step gs are in LDS: everything requested after them may stay in flight.
+    //     After A(k), steady state: the stores and the shortcut request of its step, then D-2 whole steps of NA + NS + NR requests;
+    //     for a stage of the prologue: the later prologue stages, the two shortcut tiles, then k whole steps less their A pieces
+    if (EARLY < 0) s_wait_vm<(D - 2) * NA + (D - 1) * (NR + NS)>();
+    else s_wait_vm<(D - 2) * NA + 2 * NR + (EARLY < 0 ? 0 : EARLY) * (NR + NS)>();
+    s_lds_barrier();  // every wave's pieces are in; every wave is done reading the stage of step gs-1 (and, at the first step, the constants are written)
+    // (2) refill that stage with step gs+D-1
+    dma_step(gs + D - 1, slot == 0 ? D - 1 : slot - 1);
+    // (3) the matrix products of the step
+    f32x16 acc[FN];
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    const unsigned char* st = smem + slot * STG;
+    // fragment reads run PD-1 chunks ahead of their MFMAs
+    constexpr int PD = KC < 4 ? KC : 4;
+    u32x4 xf[PD];
+#pragma unroll
+    for (int q = 0; q < PD - 1; ++q) xf[q] = *reinterpret_cast<const u32x4*>(st + (frag0 ^ (unsigned)(q * 32)));
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      if (kk + PD - 1 < KC) xf[(kk + PD - 1) % PD] = *reinterpret_cast<const u32x4*>(st + (frag0 ^ (unsigned)((kk + PD - 1) * 32)));
+#pragma unroll
+      for (int f = 0; f < FN; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[f][kk]), __builtin_bit_cast(f16x8, xf[kk % PD]), acc[f], 0, 0, 0);
+    }
+    // (4) epilogue of the step, in the wave's own buffer `ob` (no other wave touches it: LDS operations of one wave execute in order).
+    //     Its shortcut tile was requested two steps ago; behind it: a whole step's requests and this step's A pieces (first step: the second
+    //     tile and the A pieces)
+    unsigned char* const obp = smem + obuf0 + ob * OBUF;
+    if (RES) {
+      if (EARLY == 0) s_wait_vm<NR + NA>();
+      else s_wait_vm<2 * NA + NS + NR>();
+    }
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 s0, h0, s1, h1;
+        if (CREG) {
+          s0 = csc[CREG ? 2 * j : 0], h0 = csh[CREG ? 2 * j : 0], s1 = csc[CREG ? 2 * j + 1 : 0], h1 = csh[CREG ? 2 * j + 1 : 0];
+        } else {
+          const int cb0 = (wave * FN + f) * 32 + 16 * j + 4 * h, cb1 = cb0 + 8;
+          s0 = *reinterpret_cast<const f32x4*>(scl + cb0), h0 = *reinterpret_cast<const f32x4*>(shl + cb0);
+          s1 = *reinterpret_cast<const f32x4*>(scl + cb1), h1 = *reinterpret_cast<const f32x4*>(shl + cb1);
+        }
+        u32x4* const vp = reinterpret_cast<u32x4*>(obp + ovec0 + (unsigned)(((f * 4 + j * 2 + h) ^ oswz) * 16));
+        u32x4 rv = u32x4{0u, 0u, 0u, 0u};
+        if (RES) rv = *vp;
+        float lo[4], hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] = acc[f][8 * j + e] * s0[e] + h0[e];
+          hi[e] = acc[f][8 * j + 4 + e] * s1[e] + h1[e];
+        }
+        s_permlane32_swap4(lo, hi);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x0 = i < 2 ? lo[2 * i] : hi[2 * i - 4], x1 = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+          if (RES) {
+            x0 = s_add_half_lo(rv[i], x0);
+            x1 = s_add_half_hi(rv[i], x1);
+          }
+          const f32x2 xp = {x0, x1};
+          f16x2 hp = __builtin_convertvector(xp, f16x2);
+          if (RELU) hp = __builtin_elementwise_max(hp, zero2);
+          o[i] = __builtin_bit_cast(unsigned, hp);
+        }
+        *vp = o;  // the lane's own position: read (shortcut) and written (result) by this lane only
+      }
+    // the tile leaves in the memory view: whole runs of RBO bytes per LPO lanes
+    {
+      if (MULTI) {
+        const int pi = find(cc.pi, gs);
+        if (pi != cc.pi) set_co(cc, yoff, pi, a.prob[pi].y);
+      }
+      const int row0 = (gs - cc.step0) * 32;
+      const int lim = cc.M - row0;
+      const unsigned so = (unsigned)row0 * (unsigned)cc.pitch;
+      u32x4 ov[NO];
+#pragma unroll
+      for (int i = 0; i < NO; ++i) ov[i] = *reinterpret_cast<const u32x4*>(obp + i * 1024 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < NO; ++i) s_store16_untracked(cc.rs, orow[i] < lim ? yoff[i] + so : kOOBs, ov[i]);
+    }
+    // the buffer is free (its reads have returned: the stores above took their data): the shortcut tile of step gs+2 goes into it
+    resid_step(gs + 2, ob);
+    slot = slot + 1 == D ? 0 : slot + 1;
+    if (RES) ob ^= 1;
+  };
+  int gs = gs0;
+  if (gs < gs1) do_step(gs++, std::integral_constant<int, 0>{});
+  if (D > 2 && gs < gs1) do_step(gs++, std::integral_constant<int, 1>{});
+  if (D > 3 && gs < gs1) do_step(gs++, std::integral_constant<int, 2>{});
+  stamp(3);
+  for (; gs < gs1; ++gs) do_step(gs, std::integral_constant<int, -1>{});
+  stamp(4);
+  s_wait_vm<0>();  // the dummy DMA pieces past the range must not land in the LDS of the next workgroup on this CU
+  stamp(5);
+  stamp(6);
+  stamp(7);
+}
+
+typedef void (*WsKernel)(const WsArgs);
+struct WsForm {
+  int K, FN, NW, D;
+  WsKernel k[2][2][2];  // [shortcut][relu][multi]
+};
+#define DC_WS_K(K_, FN_, NW_, D_, R_, L_, M_) ws1x1_kernel<K_ / 16, FN_, NW_, D_, R_, L_, M_>
+#define DC_WS_FORM(K_, FN_, NW_, D_)                                                                                                    \
+  {K_, FN_, NW_, D_,                                                                                                                    \
+   {{{DC_WS_K(K_, FN_, NW_, D_, false, false, false), DC_WS_K(K_, FN_, NW_, D_, false, false, true)},                                     \
+     {DC_WS_K(K_, FN_, NW_, D_, false, true, false), DC_WS_K(K_, FN_, NW_, D_, false, true, true)}},                                      \
+    {{DC_WS_K(K_, FN_, NW_, D_, true, false, false), DC_WS_K(K_, FN_, NW_, D_, true, false, true)},                                       \
+     {DC_WS_K(K_, FN_, NW_, D_, true, true, false), DC_WS_K(K_, FN_, NW_, D_, true, true, true)}}}}
+const WsForm kForms[] = {
+    DC_WS_FORM(64, 2, 4, 4),   // 256-channel slices, 50 KB: res2x_branch2c, res2a_branch1
+    DC_WS_FORM(128, 1, 8, 4),  // 256 as eight waves of one fragment, 66 KB: res3x_branch2c in two (20.4 us at batch 8; the tiles 23.6)
+    DC_WS_FORM(128, 2, 4, 4),  //   alt 1: four waves of two fragments, two workgroups per CU (21.4)
+    DC_WS_FORM(256, 1, 8, 4),  // 256, 98 KB, one workgroup per CU: res4x_branch2c in four (13.7 us at batch 8; the tiles 17.7)
+    DC_WS_FORM(256, 2, 8, 4),  //   alt 1: 512 (256 KB of filters per CU: a 5-us prologue; 16.7)
+    DC_WS_FORM(256, 1, 4, 3),  //   alt 2: 128, two workgroups per CU
+    DC_WS_FORM(512, 1, 8, 3),  // 256, 130 KB: res5x_branch2c in eight
+};
+const WsForm* form_of(int K) {
+  static const int alt = getenv("DC_WS_ALT") ? atoi(getenv("DC_WS_ALT")) : 0;
+  const WsForm* first = nullptr;
+  int n = 0;
+  for (const WsForm& f : kForms)
+    if (f.K == K) {
+      if (!first) first = &f;
+      if (n++ == alt) return &f;
+    }
+  return first;
+}
+void ws_magic(unsigned dv, unsigned (&mg)[2]) {  // dc_magic of kernels.hip
+  if (dv <= 1) {
+    mg[0] = 0, mg[1] = 0x80000000u;
+    return;
+  }
+  int l = 0;
+  while ((1ull << l) < dv) ++l;
+  const int sh = 31 + l;
+  const unsigned long long qq = (unsigned long long)((((unsigned __int128)1) << sh) / dv);
+  mg[0] = (unsigned)(qq + 1), mg[1] = (unsigned)(sh - 32);
+}
+int ws_slots() {  // workgroups the walk is cut into: two per CU
+  static const int s = getenv("DC_WS_SLOTS") ? atoi(getenv("DC_WS_SLOTS")) : 512;
+  return std::max(8, s);
+}
+// fills J, S, tn and the magic numbers; returns the grid
+long ws_plan(WsArgs& a, int K) {
+  const WsForm* f = form_of(K);
+  const int BN = f->NW * f->FN * 32;
+  a.tn = a.Cout / BN;
+  long S = 0;
+  for (int c = 0; c < a.nprob; ++c) {
+    a.prob[c].step0 = (int)S;
+    S += (a.prob[c].M + 31) / 32;
+  }
+  a.S = (int)S;
+  long J = std::min<long>(S, std::max(1, ws_slots() / (f->NW == 8 ? 2 : 1) / a.tn));
+  if (J >= 8) J -= J % 8;
+  a.J = (int)J;
+  ws_magic((unsigned)a.tn, a.div_tn);
+  ws_magic((unsigned)a.J, a.div_J);
+  return (J + 7) / 8 * 8 * a.tn;
+}
+bool ws_tensor_ok(const void* x, const void* y, const void* resid, long M, long sx, long ypix) {
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)resid & 15)) return false;
+  if ((sx * 2) % 16 != 0 || (ypix * 2) % 16 != 0) return false;
+  return M > 0 && M * sx * 2 < 0x7fffffffL && M * ypix * 2 < 0x7fffffffL;
+}
+}  // namespace
+
+bool stream1x1_eligible(const ConvGemmParams& p) {
+  if (p.esize != 2 || p.ncls > 1 || p.nprob > 0 || p.nty != 1 || p.ntx != 1 || p.dy0 != 0 || p.x0 != 0 || p.sy != 1 || p.sigmoid_ch != 0) return false;
+  const WsForm* f = form_of(p.klen);
+  if (!f || p.Ktot != p.klen || p.Cout % (f->NW * f->FN * 32) != 0) return false;
+  // dense NHWC on both sides: output pixel m reads the klen halves at m * sx and is written at m * y_pix_stride
+  if (p.x_rows != p.OH || p.x_row_stride != p.OW * p.sx || p.x_img_stride != (long)p.OH * p.x_row_stride || p.x_rowlen < (p.OW - 1) * p.sx + p.klen) return false;
+  if (p.y_row_stride != p.OW * p.y_pix_stride || p.y_img_stride != (long)p.OH * p.y_row_stride) return false;
+  if ((p.sx * 2) % 16 != 0 || (p.y_pix_stride * 2) % 16 != 0) return false;
+  if ((long)p.M * p.sx * 2 >= 0x7fffffffL || (long)p.M * p.y_pix_stride * 2 >= 0x7fffffffL) return false;
+  if ((long)p.M / 32 * ws_slots() >= 0x7fffffffL) return false;
+  return true;
+}
+
+long stream1x1_grid(const ConvGemmParams& p) {
+  WsArgs a{};
+  a.Cout = p.Cout, a.nprob = 1;
+  a.prob[0].M = p.M;
+  return ws_plan(a, p.klen);
+}
+
+size_t stream1x1_packed_elems(int Cout, int K) { return (size_t)Cout * K; }
+
+// g: [Cout][K] (a 1x1 filter bank, Caffe order) -> MFMA A-operand fragment order [Cout/32][K/16][64 lanes][8]:
+// lane = 32 * ((k % 16) / 8) + co % 32, element = k % 8 — one wave instruction fetches 1 KiB contiguous
+void stream1x1_pack_filters(const float* g, int Cout, int K, float* out) {
+  for (int co = 0; co < Cout; ++co)
+    for (int k = 0; k < K; ++k)
+      out[((((size_t)(co / 32) * (K / 16) + k / 16) * 64) + ((k % 16) / 8) * 32 + co % 32) * 8 + k % 8] = g[(size_t)co * K + k];
+}
+
+int launch_stream1x1(const ConvGemmParams& p, void* stream) {
+  if (!stream1x1_eligible(p)) return (int)hipErrorInvalidValue;
+  if (!ws_tensor_ok(p.x, p.y, p.resid, p.M, p.sx, p.y_pix_stride) || ((uintptr_t)p.w & 15)) return (int)hipErrorInvalidValue;
+  const WsForm* f = form_of(p.klen);
+  WsArgs a{};
+  a.w = p.w, a.scale = p.scale, a.shift = p.shift, a.Cout = p.Cout, a.relu = p.relu, a.nprob = 1, a.dbg = p.dbg;
+  a.prob[0] = WsProblem{p.x, p.y, p.resid, p.M, p.sx * 2, p.y_pix_stride * 2, 0};
+  const long grid = ws_plan(a, p.klen);
+  if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(f->k[p.resid ? 1 : 0][p.relu ? 1 : 0][0], dim3((unsigned)grid), dim3(f->NW * 64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace dc
