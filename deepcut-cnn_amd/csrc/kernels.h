@@ -189,6 +189,9 @@ long stream1x1_grid(const ConvGemmParams& p);
 size_t stream1x1_packed_elems(int Cout, int K);
 void stream1x1_pack_filters(const float* g, int Cout, int K, float* out);
 int launch_stream1x1(const ConvGemmParams& p, void* stream);
+// multi-problem (NetGroup): prepare_conv_multi / launch_conv_multi take kStreamHalf as a variant and end here; p.w must be the packed image
+long stream1x1_prepare_multi(const ConvGemmParams& p, const ConvMultiTable& tb, int nprob);  // the grid, or -1
+int launch_stream1x1_multi(const ConvMultiArgs& a, void* stream);                              // a.p.nprob, a.t as filled by the caller
 
 // The remaining kernels take `esize` = bytes per device element (4 float / 2 _Float16); host-side tensors
 // and the per-channel affine vectors are always float.

@@ -1221,10 +1221,14 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 }  // namespace
 
 int conv_num_variants() { return kNumVariants; }
-const ConvVariant& conv_variant(int i) { return kVariants[i].v; }
-int conv_variant_bk(int i) { return kVariants[i].BK; }
-int conv_variant_esize(int i) { return kVariants[i].esize; }
-bool conv_variant_multiclass(int i) { return kVariants[i].kernel_mc != nullptr; }
+// (kStreamHalf — stream1x1.hip — answers these like a table entry: the group code handles it as one more multi-problem tile)
+const ConvVariant& conv_variant(int i) {
+  static const ConvVariant kStream = {"ws1x1", 32, 256, 1, 8, 1};
+  return i == kStreamHalf ? kStream : kVariants[i].v;
+}
+int conv_variant_bk(int i) { return i == kStreamHalf ? 64 : kVariants[i].BK; }
+int conv_variant_esize(int i) { return i == kStreamHalf ? 2 : kVariants[i].esize; }
+bool conv_variant_multiclass(int i) { return i == kStreamHalf ? false : kVariants[i].kernel_mc != nullptr; }
 
 long conv_grid(const ConvGemmParams& p, int variant) {
   const ConvVariant& v = kVariants[variant].v;
@@ -1381,10 +1385,15 @@ int launch_conv_gemm(const ConvGemmParams& p_in, int variant, void* stream) {
   return (int)hipGetLastError();
 }
 
-bool conv_variant_multiproblem(int i) { return kVariants[i].kernel_mp != nullptr; }
+bool conv_variant_multiproblem(int i) { return i == kStreamHalf ? true : kVariants[i].kernel_mp != nullptr; }
 
 // Multi-problem launch: host-side preparation (once per plan), see kernels.h.
 long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& tb, int nprob, int variant) {
+  if (variant == kStreamHalf) {
+    const long g = stream1x1_prepare_multi(p, tb, nprob);
+    if (g > 0) p.nprob = nprob, p.ncls = 0;
+    return g;
+  }
   if (variant < 0 || variant >= kNumVariants || nprob < 1 || nprob > kMaxProblems) return -1;
   const VariantEntry& e = kVariants[variant];
   if (!e.kernel_mp || p.esize != e.esize || p.klen % e.BK != 0) return -1;
@@ -1479,6 +1488,7 @@ long prepare_conv_multi(ConvGemmParams& p, ConvMultiTable& tb, int nprob, int va
 }
 
 int launch_conv_multi(const ConvMultiArgs& a, int variant, long grid, void* stream) {
+  if (variant == kStreamHalf) return launch_stream1x1_multi(a, stream);
   if (variant < 0 || variant >= kNumVariants || !kVariants[variant].kernel_mp || a.p.nprob < 1 || grid <= 0) return (int)hipErrorInvalidValue;
   const VariantEntry& e = kVariants[variant];
   const int nt = e.v.WR * e.v.WC * e.v.WK * 64;

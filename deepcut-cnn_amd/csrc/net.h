@@ -357,6 +357,7 @@ struct GroupLaunch {
   int index = 0;              // index into every member's plan
   int member = -1;            // !multi: the member whose launch `index` this is
   ConvGemmParams p{};         // multi: the layer's common block (not yet prepared for a variant)
+  const void* ws_w = nullptr; // ... the layer's stream1x1 filter image if every member has one (variant kStreamHalf reads it instead of p.w)
   ConvMultiTable table{};     // ... and the problems (pointers filled, not yet prepared)
   ConvMultiArgs args{};       // both, prepared for `variant`: the kernel arguments
   int nprob = 0;

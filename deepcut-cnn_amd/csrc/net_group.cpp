@@ -145,6 +145,25 @@ void NetGroup::forget_plan(GroupPlan* gp) {
     }
 }
 
+// the kernel arguments of a merged launch for a tile (common block + problem table); returns the grid, <= 0 if the tile cannot take it
+static long group_args(const GroupLaunch& gl, int variant, ConvMultiArgs& a) {
+  a.p = gl.p;
+  a.t = gl.table;
+  if (variant == kStreamHalf) {
+    if (!gl.ws_w) return -1;
+    a.p.w = gl.ws_w;
+  }
+  return prepare_conv_multi(a.p, a.t, gl.nprob, variant);
+}
+// the tiles a merged launch can be timed on: every multi-problem tile of its K granularity and type, and the streaming form
+static std::vector<int> group_candidates(const GroupLaunch& gl) {
+  std::vector<int> c;
+  for (int v = 0; v < conv_num_variants(); ++v)
+    if (conv_variant_multiproblem(v) && gl.p.klen % conv_variant_bk(v) == 0 && conv_variant_esize(v) == gl.p.esize) c.push_back(v);
+  if (gl.ws_w && env_int("DC_STREAM1X1", -1) != 0) c.push_back(kStreamHalf);
+  return c;
+}
+
 void NetGroup::merge(GroupPlan& gp) {
   const size_t NM = nets.size();
   gp.lowerings.resize(NM), gp.buf_gens.resize(NM), gp.weight_gens.resize(NM), gp.tile_gens.resize(NM);
@@ -297,6 +316,11 @@ void NetGroup::merge(GroupPlan& gp) {
       gl.p.dbg = nullptr;
       gl.p.x = nullptr, gl.p.y = nullptr, gl.p.resid = nullptr;
       gl.p.w = l0.w->dev;
+      {  // the streaming form of a dense float16 1x1 layer (stream1x1.hip) is a candidate if every member carries the (shared) image
+        bool all = l0.takes_wino(kStreamHalf) && l0.wino_w->dev;
+        for (int c : mem) all = all && nets[c]->plan[i].wino_w == l0.wino_w && nets[c]->plan[i].takes_wino(kStreamHalf);
+        gl.ws_w = all ? l0.wino_w->dev : nullptr;
+      }
       gl.p.scale = l0.scale ? l0.scale->dev + l0.c_off : nullptr;
       gl.p.shift = l0.shift ? l0.shift->dev + l0.c_off : nullptr;
       for (int k = 0; k < gl.nprob; ++k) {
@@ -325,6 +349,7 @@ void NetGroup::merge(GroupPlan& gp) {
       if (forced >= 0 && forced < conv_num_variants() && conv_variant_multiproblem(forced) && gl.p.klen % conv_variant_bk(forced) == 0 &&
           conv_variant_esize(forced) == gl.p.esize)
         v = forced;
+      if (forced < 0 && gl.ws_w && env_int("DC_STREAM1X1", -1) >= 1) v = kStreamHalf;  // (forced on: wherever eligible, as in Net's lowering)
       gl.variant = v;
     }
   }
@@ -332,10 +357,9 @@ void NetGroup::merge(GroupPlan& gp) {
     if (!gl.multi) continue;
     int v = gl.variant;
     auto usable = [&](int cand) {
-      if (cand < 0 || cand >= conv_num_variants() || is_wino_variant(cand)) return false;
-      ConvGemmParams p = gl.p;
-      ConvMultiTable t = gl.table;
-      return prepare_conv_multi(p, t, gl.nprob, cand) > 0;
+      if (cand != kStreamHalf && (cand < 0 || cand >= conv_num_variants() || is_wino_variant(cand))) return false;
+      ConvMultiArgs a;
+      return group_args(gl, cand, a) > 0;
     };
     if (!usable(v)) {
       v = -1;
@@ -354,9 +378,7 @@ void NetGroup::merge(GroupPlan& gp) {
 // prepare the launch (common block + problem table = its kernel arguments) for a tile
 void NetGroup::apply_variant(GroupPlan&, GroupLaunch& gl, int variant) {
   ConvMultiArgs a;
-  a.p = gl.p;
-  a.t = gl.table;
-  const long grid = prepare_conv_multi(a.p, a.t, gl.nprob, variant);
+  const long grid = group_args(gl, variant, a);
   if (grid <= 0) throw DcError(DC_EUNSUP, "group launch '" + gl.label + "': tile " + conv_variant(variant).name + " cannot take it");
   gl.args = a;
   gl.variant = variant;
@@ -389,12 +411,9 @@ void NetGroup::autotune(GroupPlan& gp) {
     timed_any = true;
     fresh.insert(gl.key);
     std::vector<std::pair<float, int>> c;
-    for (int v = 0; v < conv_num_variants(); ++v) {
-      if (!conv_variant_multiproblem(v) || gl.p.klen % conv_variant_bk(v) != 0 || conv_variant_esize(v) != gl.p.esize) continue;
+    for (int v : group_candidates(gl)) {
       ConvMultiArgs p;
-      p.p = gl.p;
-      p.t = gl.table;
-      const long grid = prepare_conv_multi(p.p, p.t, gl.nprob, v);
+      const long grid = group_args(gl, v, p);
       if (grid <= 0) continue;
       KCHECK(launch_conv_multi(p, v, grid, s));  // warm
       float ms = 1e30f;
@@ -756,14 +775,13 @@ void NetGroup::set_tile(const std::string& key, const std::string& tile) {
   int v = -1;
   for (int i = 0; v < 0 && i < conv_num_variants(); ++i)
     if (tile == conv_variant(i).name) v = i;
+  if (tile == conv_variant(kStreamHalf).name) v = kStreamHalf;
   if (v < 0) throw DcError(DC_EINVAL, "no tile variant named '" + tile + "'");
   bool any = false;
   for (auto& gl : cur_->launches) {
     if (!gl.multi || gl.key != key) continue;
     ConvMultiArgs a;
-    a.p = gl.p;
-    a.t = gl.table;
-    if (!conv_variant_multiproblem(v) || prepare_conv_multi(a.p, a.t, gl.nprob, v) <= 0)
+    if (!conv_variant_multiproblem(v) || group_args(gl, v, a) <= 0)
       throw DcError(DC_EUNSUP, "tile '" + tile + "' cannot take group launch '" + gl.label + "'");
     any = true;
   }

@@ -511,4 +511,46 @@ int launch_stream1x1(const ConvGemmParams& p, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ---- multi-problem launches (NetGroup): the same walk over the steps of several tensors in turn.  `p` carries the layer's common fields
+// (klen, sx, Cout, relu, scale, shift, w = the stream1x1_pack_filters image), tb.prob[0..nprob) the tensors.
+namespace {
+bool ws_fill_multi(WsArgs& a, const ConvGemmParams& p, const ConvMultiTable& tb, int nprob) {
+  if (p.esize != 2 || p.sy != 1 || p.sigmoid_ch != 0 || nprob < 1 || nprob > kMaxProblems) return false;
+  const WsForm* f = form_of(p.klen);
+  if (!f || p.Cout % (f->NW * f->FN * 32) != 0 || (p.sx * 2) % 16 != 0) return false;
+  a = WsArgs{};
+  a.w = p.w, a.scale = p.scale, a.shift = p.shift, a.Cout = p.Cout, a.relu = p.relu, a.nprob = nprob, a.dbg = nullptr;
+  long steps = 0;
+  for (int c = 0; c < nprob; ++c) {
+    const ConvProblem& q = tb.prob[c];
+    if (q.nty != 1 || q.ntx != 1 || q.dy0 != 0 || q.x0 != 0 || q.Ktot != p.klen || q.w_off != 0 || q.M <= 0 || q.M != q.NB * q.OH * q.OW) return false;
+    if ((q.resid != nullptr) != (tb.prob[0].resid != nullptr)) return false;
+    // dense NHWC on both sides (as stream1x1_eligible)
+    if (q.x_rows != q.OH || q.x_row_stride != q.OW * p.sx || q.x_img_stride != (long)q.OH * q.x_row_stride || q.x_rowlen < (q.OW - 1) * p.sx + p.klen) return false;
+    if (q.y_row_stride != q.OW * q.y_pix_stride || q.y_img_stride != (long)q.OH * q.y_row_stride) return false;
+    if (!ws_tensor_ok(q.x, q.y, q.resid, q.M, p.sx, q.y_pix_stride)) return false;
+    a.prob[c] = WsProblem{q.x, q.y, q.resid, q.M, p.sx * 2, q.y_pix_stride * 2, 0};
+    steps += (q.M + 31) / 32;
+  }
+  return steps * ws_slots() < 0x7fffffffL;
+}
+}  // namespace
+
+long stream1x1_prepare_multi(const ConvGemmParams& p, const ConvMultiTable& tb, int nprob) {
+  WsArgs a;
+  if (!ws_fill_multi(a, p, tb, nprob)) return -1;
+  const long grid = ws_plan(a, p.klen);
+  return grid > 0 && grid <= 0x7fffffffL ? grid : -1;
+}
+
+int launch_stream1x1_multi(const ConvMultiArgs& m, void* stream) {
+  WsArgs a;
+  if (!ws_fill_multi(a, m.p, m.t, m.p.nprob) || ((uintptr_t)m.p.w & 15)) return (int)hipErrorInvalidValue;
+  const WsForm* f = form_of(m.p.klen);
+  const long grid = ws_plan(a, m.p.klen);
+  if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(f->k[a.prob[0].resid ? 1 : 0][a.relu ? 1 : 0][a.nprob > 1 ? 1 : 0], dim3((unsigned)grid), dim3(f->NW * 64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 }  // namespace dc
