@@ -189,6 +189,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   //      Per cursor: descriptor, pixels of the tensor, its first step, and the per-lane byte offsets of the requests of a step at row 0
   struct Cur {
     int pi, M, step0, pitch;
+    int next0;  // first step of the next tensor (INT_MAX behind the last): the only thing a step compares
     i32x4 rs;
   };
   Cur cd, cr, cc;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   for (int i = 0; i < NO; ++i) orow[i] = i * RPO + lane / LPO;
   auto set_cd = [&](int pi) {
     cd.pi = pi, cd.M = a.prob[pi].M, cd.step0 = a.prob[pi].step0, cd.pitch = a.prob[pi].sxb, cd.rs = s_rsrc_words(a.prob[pi].x);
+    cd.next0 = MULTI && pi + 1 < a.nprob ? a.prob[pi + 1].step0 : 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = arow[i], sl = lane % LPR;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   };
   auto set_co = [&](Cur& c, unsigned (&off)[NO], int pi, const void* base) {
     c.pi = pi, c.M = a.prob[pi].M, c.step0 = a.prob[pi].step0, c.pitch = a.prob[pi].ypb, c.rs = s_rsrc_words(base);
+    c.next0 = MULTI && pi + 1 < a.nprob ? a.prob[pi + 1].step0 : 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
       const int r = orow[i], sl = lane % LPO;
@@ -227,10 +230,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
 
   // requests of a step: always the same number (past the range: out-of-range offsets — zeros into a free stage, nothing stored)
   auto dma_step = [&](int gs, int slot) {  // NA requests
-    if (MULTI && gs < gs1) {
-      const int pi = find(cd.pi, gs);
-      if (pi != cd.pi) set_cd(pi);
-    }
+    if (MULTI && gs < gs1 && gs >= cd.next0) set_cd(find(cd.pi, gs));
     const int row0 = (gs - cd.step0) * 32;
     const int lim = gs < gs1 ? cd.M - row0 : 0;  // rows of the step that exist
     const unsigned so = (unsigned)row0 * (unsigned)cd.pitch;
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   };
   auto resid_step = [&](int gs, int buf) {  // NR requests: the wave's shortcut tile of step gs -> its buffer `buf`
     if (!RES) return;
-    if (MULTI && gs < gs1) {
+    if (MULTI && gs < gs1 && gs >= cr.next0) {
       const int pi = find(cr.pi, gs);
-      if (pi != cr.pi) set_co(cr, roff, pi, a.prob[pi].resid);
+      set_co(cr, roff, pi, a.prob[pi].resid);
     }
     const int row0 = (gs - cr.step0) * 32;
     const int lim = gs < gs1 ? cr.M - row0 : 0;
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
       }
     // the tile leaves in the memory view: whole runs of RBO bytes per LPO lanes
     {
-      if (MULTI) {
+      if (MULTI && gs >= cc.next0) {
         const int pi = find(cc.pi, gs);
-        if (pi != cc.pi) set_co(cc, yoff, pi, a.prob[pi].y);
+        set_co(cc, yoff, pi, a.prob[pi].y);
       }
       const int row0 = (gs - cc.step0) * 32;
       const int lim = cc.M - row0;
