@@ -66,14 +66,23 @@ __device__ __forceinline__ i32x4 s_rsrc_words(const void* p) {
   const unsigned long long a = (unsigned long long)p;
   return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
 }
+// (wave-uniform values that the compiler keeps in vector registers — it does behind the wave-uniform branches of the step loop — come back
+//  to scalar ones here: an "s" operand is not converted by the compiler, the assembler rejects the instruction)
+__device__ __forceinline__ unsigned s_uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ i32x4 s_uni4(i32x4 r) {
+  return i32x4{__builtin_amdgcn_readfirstlane(r[0]), __builtin_amdgcn_readfirstlane(r[1]), __builtin_amdgcn_readfirstlane(r[2]), __builtin_amdgcn_readfirstlane(r[3])};
+}
 // LDS-DMA, as dc_dma16 of kernels.hip (inline asm: the compiler must not make later ds_reads wait for vmcnt(0))
-__device__ __forceinline__ void s_dma16(i32x4 rs, unsigned lds, unsigned voff) {
+__device__ __forceinline__ void s_dma16(i32x4 rs_, unsigned lds_, unsigned voff) {
+  const i32x4 rs = s_uni4(rs_);
+  const unsigned lds = s_uni(lds_);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
 }
 // a 16-byte buffer store the compiler does not track (no s_waitcnt of its own): the counted vmcnt below covers it
 // (the s_nop behind it: a store of more than 8 bytes reads its data registers over several cycles, and the hazard recogniser, which does not
 //  look inside inline asm, let a v_or overwrite the first of them in the next cycle — one wrong dword per vector on some lanes)
-__device__ __forceinline__ void s_store16_untracked(i32x4 rs, unsigned voff, u32x4 v) {
+__device__ __forceinline__ void s_store16_untracked(i32x4 rs_, unsigned voff, u32x4 v) {
+  const i32x4 rs = s_uni4(rs_);
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs) : "memory");
 }
 template <int N>
@@ -152,19 +161,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   float c_sc = 1.f, c_sh = 0.f;
   {
     const unsigned co = t < BN ? (unsigned)((n0 + t) * 4) : kOOBs;
-    if (a.scale) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sc) : "v"(co), "s"(s_rsrc_words(a.scale)) : "memory");
-    if (a.shift) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sh) : "v"(co), "s"(s_rsrc_words(a.shift)) : "memory");
+    if (a.scale) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sc) : "v"(co), "s"(s_uni4(s_rsrc_words(a.scale))) : "memory");
+    if (a.shift) asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(c_sh) : "v"(co), "s"(s_uni4(s_rsrc_words(a.shift))) : "memory");
   }
   u32x4 wreg[FN][KC];
   {
-    const i32x4 wrs = s_rsrc_words(a.w);
+    const i32x4 wrs = s_uni4(s_rsrc_words(a.w));
     const int f0 = nw0 >> 5;
     const unsigned wl = (unsigned)lane * 16u;
 #pragma unroll
     for (int f = 0; f < FN; ++f)
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk) {
-        const unsigned so = (unsigned)(((f0 + f) * KC + kk) * 1024);
+        const unsigned so = s_uni((unsigned)(((f0 + f) * KC + kk) * 1024));
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wreg[f][kk]) : "v"(wl), "s"(wrs), "s"(so) : "memory");
       }
   }
@@ -288,26 +297,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
 
   const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
   int slot = 0, ob = 0;
-  // one step.  EARLY = k for the first D-1 steps of the walk (their pieces were requested by the prologue: other vmcnt counts), -1 after
-  auto do_step = [&](int gs, auto early_tag) {
-    constexpr int EARLY = decltype(early_tag)::value;
-    // (1) my pieces of step gs are in LDS: everything requested after them may stay in flight.
-    //     After A(k), steady state: the stores and the shortcut request of its step, then D-2 whole steps of NA + NS + NR requests;
-    //     for a stage of the prologue: the later prologue stages, the two shortcut tiles, then k whole steps less their A pieces
-    if (EARLY < 0) s_wait_vm<(D - 2) * NA + (D - 1) * (NR + NS)>();
-    else s_wait_vm<(D - 2) * NA + 2 * NR + (EARLY < 0 ? 0 : EARLY) * (NR + NS)>();
-    s_lds_barrier();  // every wave's pieces are in; every wave is done reading the stage of step gs-1 (and, at the first step, the constants are written)
-    // (2) refill that stage with step gs+D-1
-    dma_step(gs + D - 1, slot == 0 ? D - 1 : slot - 1);
-    // (3) the matrix products of the step
-    f32x16 acc[FN];
+  // Two halves of the workgroup run the step in opposite order.  Waves w and w + NW/2 share a SIMD (a workgroup's waves go to the SIMDs
+  // cyclically), and behind the step's barrier both would issue their matrix instructions at the same time and then their epilogues at
+  // the same time — the matrix pipe and the vector ALU each idle half of the step (stamps: 2.4 k cycles per step for 1.0 k of MFMA and
+  // ~1.2 k of everything else per SIMD).  So the upper half ("late") keeps its accumulators across the barrier: in step k it first
+  // finishes step k-1 (epilogue, stores) while its partner multiplies, then multiplies while the partner finishes step k.
+  constexpr bool STAG = FN == 1 && KC <= 16;  // (the wider forms have no registers left for it: both orders inlined spilled 16-160 of them)
+  const bool late = STAG && __builtin_amdgcn_readfirstlane(wave >= NW / 2 ? 1 : 0) != 0;
+  f32x16 acc[FN];
+  // the matrix products of step gs, from stage `slot`
+  auto mfma_part = [&]() {
 #pragma unroll
     for (int f = 0; f < FN; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
     const unsigned char* st = smem + slot * STG;
-    // fragment reads run PD-1 chunks ahead of their MFMAs
-    constexpr int PD = KC < 4 ? KC : 4;
+    constexpr int PD = KC < 4 ? KC : 4;  // fragment reads run PD-1 chunks ahead of their MFMAs
     u32x4 xf[PD];
 #pragma unroll
     for (int q = 0; q < PD - 1; ++q) xf[q] = *reinterpret_cast<const u32x4*>(st + (frag0 ^ (unsigned)(q * 32)));
@@ -318,13 +323,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
       for (int f = 0; f < FN; ++f)
         acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[f][kk]), __builtin_bit_cast(f16x8, xf[kk % PD]), acc[f], 0, 0, 0);
     }
-    // (4) epilogue of the step, in the wave's own buffer `ob` (no other wave touches it: LDS operations of one wave execute in order).
-    //     Its shortcut tile was requested two steps ago; behind it: a whole step's requests and this step's A pieces (first step: the second
-    //     tile and the A pieces)
+  };
+  // epilogue of step ge (the accumulators hold it), in the wave's own buffer `ob` (no other wave touches it: LDS operations of one wave
+  // execute in order), then the shortcut request of step ge+2 into the buffer it frees.  WAIT: how many requests younger than the
+  // shortcut tile of step ge may stay in flight (-1: none, the tail)
+  auto epi_part = [&](int ge, auto wait_tag) {
+    constexpr int WAIT = decltype(wait_tag)::value;
     unsigned char* const obp = smem + obuf0 + ob * OBUF;
     if (RES) {
-      if (EARLY == 0) s_wait_vm<NR + NA>();
-      else s_wait_vm<2 * NA + NS + NR>();
+      if (WAIT < 0) s_wait_vm<0>();
+      else s_wait_vm<(WAIT < 0 ? 0 : WAIT)>();
     }
 #pragma unroll
     for (int f = 0; f < FN; ++f)
@@ -365,11 +373,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
       }
     // the tile leaves in the memory view: whole runs of RBO bytes per LPO lanes
     {
-      if (MULTI && gs >= cc.next0) {
-        const int pi = find(cc.pi, gs);
+      if (MULTI && ge >= cc.next0) {
+        const int pi = find(cc.pi, ge);
         set_co(cc, yoff, pi, a.prob[pi].y);
       }
-      const int row0 = (gs - cc.step0) * 32;
+      const int row0 = (ge - cc.step0) * 32;
       const int lim = cc.M - row0;
       const unsigned so = (unsigned)row0 * (unsigned)cc.pitch;
       u32x4 ov[NO];
@@ -378,17 +386,56 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
 #pragma unroll
       for (int i = 0; i < NO; ++i) s_store16_untracked(cc.rs, orow[i] < lim ? yoff[i] + so : kOOBs, ov[i]);
     }
-    // the buffer is free (its reads have returned: the stores above took their data): the shortcut tile of step gs+2 goes into it
-    resid_step(gs + 2, ob);
-    slot = slot + 1 == D ? 0 : slot + 1;
+    // the buffer is free (its reads have returned: the stores above took their data): the shortcut tile of step ge+2 goes into it
+    resid_step(ge + 2, ob);
     if (RES) ob ^= 1;
+  };
+  // request bookkeeping (vmcnt counts requests, oldest first).  Per step and wave, in this order: NA pixel pieces (behind the barrier), then
+  // — with the epilogue — NS stores and NR shortcut requests.  An "early" wave finishes step k in step k, a "late" one in step k+1 (none
+  // in its step 0, the last one behind the loop).  Waiting for the pieces of step k (requested D-1 steps earlier, or by the prologue: the
+  // D-1 stages, then the two shortcut tiles) lets everything younger stay in flight:
+  //   steady state (k >= D, early also k = D-1)   (D-2) NA + (D-1) (NS+NR)
+  //   early, k <= D-2                             (D-2) NA + 2 NR + k (NS+NR)
+  //   late, k = 0                                 (D-2) NA + 2 NR
+  //   late, 1 <= k <= D-2                         (D-2) NA + 2 NR + (k-1) (NS+NR)
+  //   late, k = D-1                               (D-2) NA + (D-2) (NS+NR)
+  // and for the shortcut tile of step m: NR + NA if m = 0 (requested by the prologue), else 2 NA + NS + NR (the late half's count for m = 1
+  // is larger; the smaller one is used).
+  auto do_step = [&](int gs, auto k_tag) {
+    constexpr int KS = decltype(k_tag)::value;  // the step's number if < D, else -1
+    constexpr int STEADY = (D - 2) * NA + (D - 1) * (NS + NR), E0 = (D - 2) * NA + 2 * NR;
+    if (late) {
+      if (KS < 0) s_wait_vm<STEADY>();
+      else if (KS == 0) s_wait_vm<E0>();
+      else if (KS <= D - 2) s_wait_vm<E0 + (KS > 0 ? KS - 1 : 0) * (NS + NR)>();
+      else s_wait_vm<(D - 2) * NA + (D - 2) * (NS + NR)>();
+    } else {
+      if (KS < 0 || KS >= D - 1) s_wait_vm<STEADY>();
+      else s_wait_vm<E0 + (KS > 0 ? KS : 0) * (NS + NR)>();
+    }
+    s_lds_barrier();  // every wave's pieces are in; every wave is done reading the stage of step gs-1 (and, at the first step, the constants are written)
+    dma_step(gs + D - 1, slot == 0 ? D - 1 : slot - 1);  // refill that stage with step gs+D-1
+    if (late) {
+      if (KS != 0) {
+        if (KS == 1) epi_part(gs - 1, std::integral_constant<int, NR + NA>{});
+        else epi_part(gs - 1, std::integral_constant<int, 2 * NA + NS + NR>{});
+      }
+      mfma_part();
+    } else {
+      mfma_part();
+      if (KS == 0) epi_part(gs, std::integral_constant<int, NR + NA>{});
+      else epi_part(gs, std::integral_constant<int, 2 * NA + NS + NR>{});
+    }
+    slot = slot + 1 == D ? 0 : slot + 1;
   };
   int gs = gs0;
   if (gs < gs1) do_step(gs++, std::integral_constant<int, 0>{});
-  if (D > 2 && gs < gs1) do_step(gs++, std::integral_constant<int, 1>{});
-  if (D > 3 && gs < gs1) do_step(gs++, std::integral_constant<int, 2>{});
+  if (D > 1 && gs < gs1) do_step(gs++, std::integral_constant<int, 1>{});
+  if (D > 2 && gs < gs1) do_step(gs++, std::integral_constant<int, 2>{});
+  if (D > 3 && gs < gs1) do_step(gs++, std::integral_constant<int, 3>{});
   stamp(3);
   for (; gs < gs1; ++gs) do_step(gs, std::integral_constant<int, -1>{});
+  if (late) epi_part(gs1 - 1, std::integral_constant<int, -1>{});  // the late half's last step
   stamp(4);
   s_wait_vm<0>();  // the dummy DMA pieces past the range must not land in the LDS of the next workgroup on this CU
   stamp(5);
