@@ -162,8 +162,9 @@ constexpr int kWinoHalf = 1002;                // the float16 kernel (wino_f16.h
 constexpr int kStreamHalf = 1003;              // NOT Winograd: the float16 streaming form of the dense 1x1 layers (stream1x1.hip, "ws1x1") — listed
                                                // here because it is handled like one everywhere: a form outside the tile table with a filter
                                                // image of its own (Launch::wino_w), timed against the tiles per shape
-inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf || v == kStreamHalf; }
-inline int wino_variant_esize(int v) { return v == kWinoHalf || v == kStreamHalf ? 2 : 4; }  // element size of the nets the form serves
+constexpr int kStemHalf = 1004;                // NOT Winograd either: the float16 7x7 / stride-2 stem as a kernel of its own (stem_f16.hip, "stem7x7")
+inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf || v == kStreamHalf || v == kStemHalf; }
+inline int wino_variant_esize(int v) { return v == kWinoHalf || v == kStreamHalf || v == kStemHalf ? 2 : 4; }  // element size of the nets the form serves
 const char* wino_variant_name(int variant);    // the tile name of tune caches / reports / set_tile
 const char* wino_kernel_label(int variant);    // the kernel column of plan texts
 int wino_variant_by_name(const char* name);    // -1: not a Winograd tile name
@@ -189,6 +190,13 @@ long stream1x1_grid(const ConvGemmParams& p);
 size_t stream1x1_packed_elems(int Cout, int K);
 void stream1x1_pack_filters(const float* g, int Cout, int K, float* out);
 int launch_stream1x1(const ConvGemmParams& p, void* stream);
+// ---- the float16 stem (stem_f16.hip): conv1 7x7 / 2 over the NHWC4 image, as the lowering's 7-row-tap launch describes it (4 or 8 channels
+// per pixel, at most 4 of them real); `w` is the image made by stem7x7_pack_filters(), uploaded as _Float16
+bool stem7x7_eligible(const ConvGemmParams& p);
+long stem7x7_grid(const ConvGemmParams& p);
+size_t stem7x7_packed_elems();
+void stem7x7_pack_filters(const float* g, int C, float* out);  // g: [64][C][7][7], C <= 4
+int launch_stem7x7(const ConvGemmParams& p, void* stream);
 // multi-problem (NetGroup): prepare_conv_multi / launch_conv_multi take kStreamHalf as a variant and end here; p.w must be the packed image
 long stream1x1_prepare_multi(const ConvGemmParams& p, const ConvMultiTable& tb, int nprob);  // the grid, or -1
 int launch_stream1x1_multi(const ConvMultiArgs& a, void* stream);                              // a.p.nprob, a.t as filled by the caller

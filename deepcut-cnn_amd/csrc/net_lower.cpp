@@ -493,6 +493,7 @@ void Net::build_plan() {
   };
   // -1: where measured faster (autotune); 0: never; 1: wherever eligible, 8 waves per workgroup; 2: wherever eligible, the 16-wave form
   const int wino_mode = env_int("DC_WINOGRAD", -1);
+  const int stem_mode = env_int("DC_STEM", -1);          // the float16 stem kernel: -1 where measured faster, 0 never, 1 forced
   const int stream_mode = env_int("DC_STREAM1X1", -1);  // the streaming form of the float16 dense 1x1 layers: -1 where measured faster, 0 never, 1 wherever eligible
   auto choose_variant = [&](Launch& l, int kgcd) {
     int best = -1;
@@ -716,6 +717,23 @@ void Net::build_plan() {
         });
         l.wino_w->as_half = true;
         if (stream_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStreamHalf);
+      }
+      if (rowtap && stem_mode != 0 && op.wls.empty() && dtype == 1 && C <= 4 && stem7x7_eligible(g)) {
+        // float16 stem (stem_f16.hip): the same row-scaled filters as the row-tap image, the 28 real elements of every kernel row in MFMA
+        // operand order; scale / shift are the launch's own.  The per-shape timing decides (DC_STEM=1: forced, 0: never)
+        std::shared_ptr<DevVec> direct = l.w;
+        l.wino_w = get_vec(dkey + "stem:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          const float* src = L.params[0]->st->host_ptr();  // [64][C][7][7]
+          std::vector<float> scaled((size_t)64 * C * 49);
+          for (int co = 0; co < 64; ++co) {
+            const float f = direct->row_scale.empty() ? 1.f : 1.f / direct->row_scale[co];  // an exact power of two
+            for (int q = 0; q < C * 49; ++q) scaled[(size_t)co * C * 49 + q] = src[(size_t)co * C * 49 + q] * f;
+          }
+          h.assign(stem7x7_packed_elems(), 0.f);
+          stem7x7_pack_filters(scaled.data(), C, h.data());
+        });
+        l.wino_w->as_half = true;
+        if (stem_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStemHalf);
       }
       if (l.wino_w || rowtap) plan.push_back(std::move(l));
       else push_split(std::move(l), kgcd);

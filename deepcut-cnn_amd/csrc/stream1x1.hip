@@ -312,28 +312,42 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
     const unsigned char* st = smem + slot * STG;
-    constexpr int PD = KC < 4 ? KC : 4;  // fragment reads run PD-1 chunks ahead of their MFMAs
+    // fragment reads run PD-1 chunks ahead of their MFMAs: an LDS read takes 200-250 cycles beside seven other waves and a matrix
+    // instruction wants its fragment every 32 (three ahead: 60 cycles per MFMA, stamps)
+    constexpr int PD = KC < 8 ? KC : 8;
     u32x4 xf[PD];
 #pragma unroll
     for (int q = 0; q < PD - 1; ++q) xf[q] = *reinterpret_cast<const u32x4*>(st + (frag0 ^ (unsigned)(q * 32)));
+    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler pairs the reads of chunks kk and kk + 8 on one address register and
+                                        //  waits for the first of each pair in front of its MFMA: one read ahead, whatever PD says)
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       if (kk + PD - 1 < KC) xf[(kk + PD - 1) % PD] = *reinterpret_cast<const u32x4*>(st + (frag0 ^ (unsigned)((kk + PD - 1) * 32)));
 #pragma unroll
       for (int f = 0; f < FN; ++f)
         acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[f][kk]), __builtin_bit_cast(f16x8, xf[kk % PD]), acc[f], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // epilogue of step ge (the accumulators hold it), in the wave's own buffer `ob` (no other wave touches it: LDS operations of one wave
   // execute in order), then the shortcut request of step ge+2 into the buffer it frees.  WAIT: how many requests younger than the
   // shortcut tile of step ge may stay in flight (-1: none, the tail)
-  auto epi_part = [&](int ge, auto wait_tag) {
+  u32x4 rvv[RES ? 2 * FN : 1];  // the lane's shortcut vectors of the step being finished
+  // its first half: the shortcut tile has landed (WAIT: how many requests younger than it may stay in flight; -1: none, the tail) and the
+  // lane's vectors of it are on their way from LDS — an early wave does this BEFORE its matrix products, which then hide the read
+  auto epi_pre = [&](auto wait_tag) {
     constexpr int WAIT = decltype(wait_tag)::value;
+    if (!RES) return;
+    if (WAIT < 0) s_wait_vm<0>();
+    else s_wait_vm<(WAIT < 0 ? 0 : WAIT)>();
+    const unsigned char* const obp = smem + obuf0 + ob * OBUF;
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rvv[RES ? f * 2 + j : 0] = *reinterpret_cast<const u32x4*>(obp + ovec0 + (unsigned)(((f * 4 + j * 2 + h) ^ oswz) * 16));
+  };
+  auto epi_part = [&](int ge) {
     unsigned char* const obp = smem + obuf0 + ob * OBUF;
-    if (RES) {
-      if (WAIT < 0) s_wait_vm<0>();
-      else s_wait_vm<(WAIT < 0 ? 0 : WAIT)>();
-    }
 #pragma unroll
     for (int f = 0; f < FN; ++f)
 #pragma unroll
@@ -347,8 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
           s1 = *reinterpret_cast<const f32x4*>(scl + cb1), h1 = *reinterpret_cast<const f32x4*>(shl + cb1);
         }
         u32x4* const vp = reinterpret_cast<u32x4*>(obp + ovec0 + (unsigned)(((f * 4 + j * 2 + h) ^ oswz) * 16));
-        u32x4 rv = u32x4{0u, 0u, 0u, 0u};
-        if (RES) rv = *vp;
+        const u32x4 rv = rvv[RES ? f * 2 + j : 0];
         float lo[4], hi[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -417,14 +430,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
     dma_step(gs + D - 1, slot == 0 ? D - 1 : slot - 1);  // refill that stage with step gs+D-1
     if (late) {
       if (KS != 0) {
-        if (KS == 1) epi_part(gs - 1, std::integral_constant<int, NR + NA>{});
-        else epi_part(gs - 1, std::integral_constant<int, 2 * NA + NS + NR>{});
+        if (KS == 1) epi_pre(std::integral_constant<int, NR + NA>{});
+        else epi_pre(std::integral_constant<int, 2 * NA + NS + NR>{});
+        epi_part(gs - 1);
       }
       mfma_part();
     } else {
-      mfma_part();
-      if (KS == 0) epi_part(gs, std::integral_constant<int, NR + NA>{});
-      else epi_part(gs, std::integral_constant<int, 2 * NA + NS + NR>{});
+      if (!STAG) mfma_part();  // (the wider forms have no registers for vectors held across the matrix products)
+      if (KS == 0) epi_pre(std::integral_constant<int, NR + NA>{});
+      else epi_pre(std::integral_constant<int, 2 * NA + NS + NR>{});
+      if (STAG) mfma_part();
+      epi_part(gs);
     }
     slot = slot + 1 == D ? 0 : slot + 1;
   };
@@ -435,7 +451,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void ws1x1_kernel(const W
   if (D > 3 && gs < gs1) do_step(gs++, std::integral_constant<int, 3>{});
   stamp(3);
   for (; gs < gs1; ++gs) do_step(gs, std::integral_constant<int, -1>{});
-  if (late) epi_part(gs1 - 1, std::integral_constant<int, -1>{});  // the late half's last step
+  if (late) {  // the late half's last step
+    epi_pre(std::integral_constant<int, -1>{});
+    epi_part(gs1 - 1);
+  }
   stamp(4);
   s_wait_vm<0>();  // the dummy DMA pieces past the range must not land in the LDS of the next workgroup on this CU
   stamp(5);
