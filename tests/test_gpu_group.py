@@ -111,7 +111,9 @@ def test_group_fp16_batch8_pyramid(gpu_caffe, synth152):
     text = grp.plan_text()
     assert "conv_gemm_mp<d" in text or "conv_gemm_mp<h" in text, text[:300]
     st = grp.stats()
-    assert st["lanes"] == 2 and st["multi_launches"] == 2 * 157, st  # two lanes of two scales each
+    # two lanes of two scales each: every convolution merged, except that a lane whose members' conv1 was timed onto the float16 stem kernel
+    # (stem_f16.hip) runs that one layer member by member
+    assert st["lanes"] == 2 and 2 * 156 <= st["multi_launches"] <= 2 * 157, st
     # the device pose decode of every member reads the grouped results
     for m, sc in zip(grp.nets, (0.5, 0.75, 1.0, 1.25)):
         pose = m.decode_pose(sc)

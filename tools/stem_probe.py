@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""conv1 of a float16 net (7x7 / stride 2 / pad 3, 3 -> 64, + BatchNorm / Scale / ReLU) at 544x736: the autotuner's isolated timings of the
+stem kernel (csrc/stem_f16.hip, "stem7x7") and of the row-tap gather-GEMM tiles, batch 1 and 8.
+
+    python tools/stem_probe.py
+"""
 import os, sys
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "deepcut-cnn_amd"), os.path.join(ROOT, "deepcut-cnn_amd", "python"), os.path.join(ROOT,"tests")):
     sys.path.insert(0, p)
 import numpy as np
