@@ -575,6 +575,18 @@ int dc_wino_half_pack(const float* g, int cout, int cin, int rowscale, float* ou
   return guard([&] { dc::wino_half_pack_filters(g, cout, cin, rowscale != 0, out, row_scale); });
 }
 
+int dc_stream1x1_pack(const float* g, int cout, int k, float* out) {
+  if (!g || !out) return fail(DC_EINVAL, "dc_stream1x1_pack: null pointer");
+  if (cout <= 0 || k <= 0 || cout % 32 || k % 16) return fail(DC_EINVAL, "dc_stream1x1_pack: cout must be a multiple of 32, k of 16");
+  return guard([&] { dc::stream1x1_pack_filters(g, cout, k, out); });
+}
+
+int dc_stem7x7_pack(const float* g, int c, float* out) {
+  if (!g || !out) return fail(DC_EINVAL, "dc_stem7x7_pack: null pointer");
+  if (c < 1 || c > 4) return fail(DC_EINVAL, "dc_stem7x7_pack: 1 to 4 input channels");
+  return guard([&] { dc::stem7x7_pack_filters(g, c, out); });
+}
+
 // ---- pyramid-grouped execution ---------------------------------------------------------------------------------------
 namespace {
 inline NetGroup* G(dc_group* g) { return reinterpret_cast<NetGroup*>(g); }

@@ -142,6 +142,8 @@ def _load():
         "dc_conv_variant_name": (cp, [ci]),
         "dc_conv_variant_esize": (ci, [ci]),
         "dc_wino_half_pack": (ci, [C.c_void_p, ci, ci, ci, C.c_void_p, C.c_void_p]),
+        "dc_stream1x1_pack": (ci, [C.c_void_p, ci, ci, C.c_void_p]),
+        "dc_stem7x7_pack": (ci, [C.c_void_p, ci, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -177,6 +179,27 @@ def device_count():
 def conv_variants():
     """[(name, element size)] of the gather-GEMM tile variants, in DC_CONV_VARIANT index order (diagnostics)."""
     return [((_lib.dc_conv_variant_name(i) or b"").decode(), _lib.dc_conv_variant_esize(i)) for i in range(_lib.dc_conv_variant_count())]
+
+
+def stream1x1_pack(g):
+    """dc_stream1x1_pack: the filter image of the streaming 1x1 form (csrc/stream1x1.hip) of g [cout, k] (or [cout, k, 1, 1]) as the lowering
+    packs it: float32 values in the order [cout/32][k/16][64 lanes][8] (tests / diagnostics)."""
+    g = np.ascontiguousarray(g, np.float32)
+    cout, k = g.shape[0], int(np.prod(g.shape[1:]))
+    out = np.empty((cout // 32, k // 16, 64, 8), np.float32)
+    _check(_lib.dc_stream1x1_pack(g.ctypes.data_as(C.c_void_p), cout, k, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def stem7x7_pack(g):
+    """dc_stem7x7_pack: the filter image of the float16 stem kernel (csrc/stem_f16.hip) of g [64, c, 7, 7], c <= 4: float32 values in the
+    order [fragment 2][kernel row 7][K step 2][64 lanes][8] (tests / diagnostics)."""
+    g = np.ascontiguousarray(g, np.float32)
+    if g.ndim != 4 or g.shape[0] != 64 or g.shape[2:] != (7, 7):
+        raise ValueError("stem7x7_pack: g must be [64, c, 7, 7]")
+    out = np.empty((2, 7, 2, 64, 8), np.float32)
+    _check(_lib.dc_stem7x7_pack(g.ctypes.data_as(C.c_void_p), g.shape[1], out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def wino_half_pack(g, rowscale=True):

@@ -321,6 +321,16 @@ int dc_conv_variant_esize(int i);
  * tests/test_wino_half_pack.py); the reference has no counterpart (its 3x3 layers are im2col + SGEMM, base_conv_layer.cpp:257-280). */
 int dc_wino_half_pack(const float* g, int cout, int cin, int rowscale, float* out, float* row_scale);
 
+/* the filter images of the two float16 kernels added in round 6, made on the host exactly as the lowering makes them (diagnostics / tests:
+ * tests/test_stream_pack.py emulates the matrix instruction's operand layout on them; the reference has no counterpart — its 1x1 layers
+ * are one SGEMM per image, base_conv_layer.cpp:326-341, its stem im2col + SGEMM, base_conv_layer.cpp:257-280):
+ *  dc_stream1x1_pack: g = [cout][k] (a 1x1 filter bank; cout % 32 == 0, k % 16 == 0) -> out[cout * k] in the ROW-operand order of
+ *    v_mfma_f32_32x32x16_f16, [cout/32][k/16][64 lanes][8]: lane = 32 * ((kk % 16) / 8) + co % 32, element = kk % 8 (csrc/stream1x1.hip);
+ *  dc_stem7x7_pack:   g = [64][c][7][7] (c <= 4) -> out[14336] = [fragment 2][kernel row 7][K step 2][64 lanes][8], element e = kx * 4 + ci
+ *    of a kernel row at lane 32 * ((e % 16) / 8) + co % 32, position e % 8 of K step e / 16, zeros elsewhere (csrc/stem_f16.hip).        */
+int dc_stream1x1_pack(const float* g, int cout, int k, float* out);
+int dc_stem7x7_pack(const float* g, int c, float* out);
+
 /* ---- pyramid-grouped execution: several executors of ONE model, each at its own input shape, as ONE launch sequence ----
  * Replaces the scale loop of the demo (python/pose/estimate_pose.py:81-128: one net.forward() per scale, every shape change a
  * full Reshape) and, per layer, the reference's one-SGEMM-per-image loop (src/caffe/layers/base_conv_layer.cpp:326-341,
