@@ -152,10 +152,10 @@ void Net::run_launch(const Launch& l, void* s) {
                                        "K loop", "split-K exchange", "epilogue math+stores"};
         static const char* kWino[7] = {"index setup", "first loads issued", "two stages in LDS", "K loop", "partials to LDS + barrier",
                                        "inverse transform + epilogue constants", "shortcut + stores"};
-        // ws1x1 (stream1x1.hip) slots: 0 start, 1 every prologue request issued, 2 first stage + filters + constants landed, 3 first step's
-        // barrier + MFMAs issued, 4 its epilogue issued, 5 last step done, 6 requests drained
-        static const char* kStream[7] = {"prologue requests issued", "first stage + filters landed", "first step: barrier + MFMAs", "first step: epilogue",
-                                         "the other steps", "drain", "exit"};
+        // ws1x1 (stream1x1.hip) slots: 0 start, 1 every prologue request issued, 2 first stage + filters + constants landed, 3 the peeled
+        // first D steps done, 4 the other steps (and the late half's last epilogue) done, 5 requests drained
+        static const char* kStream[7] = {"prologue requests issued", "first stage + filters landed", "the first D steps", "the other steps",
+                                         "drain", "-", "exit"};
         std::string line;
         for (int k = 1; k < 8; ++k) {
           char buf[96];

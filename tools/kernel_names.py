@@ -42,6 +42,10 @@ def variant_name(name):
 
 
 def label(name):
+    if "ws1x1_kernel" in name:  # the streaming form of the dense float16 1x1 layers (csrc/stream1x1.hip)
+        return "ws1x1 (streaming 1x1, float16)"
+    if "stem7x7_kernel" in name:  # the float16 stem (csrc/stem_f16.hip)
+        return "stem7x7 (conv1, float16)"
     if "wino_h23" in name:  # the float16 kernel (csrc/wino_f16.hip)
         return "wino_h23 (Winograd F(2x2,3x3), float16)"
     if "wino_f23" in name:  # wino_f23_kernel<1> / <2> (demangled) or ...wino_f23_kernelILi2EEE... (mangled): 8 / 16 waves per workgroup

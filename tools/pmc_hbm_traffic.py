@@ -27,7 +27,7 @@ def main(fetch_db, write_db, desc, min_bytes_per_forward=2.07e9 + 0.263e9):
     f, nf = per_launch(fetch_db, "FETCH_SIZE")
     w, nw = per_launch(write_db, "WRITE_SIZE")
     fam = {}
-    for name, like in (("wino_f23", "%wino_f23%"), ("wino_h23", "%wino_h23%"), ("conv_gemm", "%conv_gemm%")):
+    for name, like in (("wino_f23", "%wino_f23%"), ("wino_h23", "%wino_h23%"), ("ws1x1", "%ws1x1%"), ("stem7x7", "%stem7x7%"), ("conv_gemm", "%conv_gemm%")):
         ff, n = family(fetch_db, "FETCH_SIZE", like)
         ww, _ = family(write_db, "WRITE_SIZE", like)
         fam[name] = {"dispatches": n, "hbm_bytes_per_launch": (2.0 * ff + ww) * 1024.0}
