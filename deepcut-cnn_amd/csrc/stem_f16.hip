@@ -9,7 +9,7 @@
 // per-pixel bounds = the zero padding), keeps the filters in registers in MFMA operand order (7 rows x 2 K-steps of 16: the 28 elements
 // kx 4 + ci of a row + 4 zeros, 112 registers for the 64 channels), and a wave walks 32-pixel row segments: 14 fragment reads (two adjacent
 // 4-channel pixels = one 16-byte chunk, always aligned because the band starts 3 pixels left of an even pixel) + 28 matrix instructions
-// per 32 x 64 outputs: 44.7 us at batch 8, 11.0 at batch 1 (16.7) — profiles/r06_stem_probe.txt.  The
+// per 32 x 64 outputs: 35.0 us at batch 8, 9.7 at batch 1 (16.7) — profiles/r06_stem_probe.txt.  The
 // epilogue is the one of stream1x1.hip (affine in fp32, ReLU, 16-byte vectors by v_permlane32_swap, transposed in a wave-private LDS tile
 // to whole 128-byte pixel rows).
 #include <hip/hip_runtime.h>
@@ -98,15 +98,23 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const StemArgs a) {
   // ---- the band: image rows 2 r0 - 3 ..., pixels 2 c0 - 3 ...; a pixel (8 bytes) per request, out of the image = 0
   {
     const __amdgpu_buffer_rsrc_t xr = t_rsrc(reinterpret_cast<const _Float16*>(a.x) + (long)n * a.x_img);
-    constexpr int NPX = BROWS * BPX;
+    constexpr int NPX = BROWS * BPX, NIT = (NPX + 255) / 256;
     const int iy0 = 2 * r0 - 3, ix0 = 2 * c0 - 3;
-    for (int q = t; q < NPX; q += 256) {
+    // every request of the thread first, then the LDS writes: one memory round trip for the band instead of one per pixel
+    u32x2 v[NIT];
+    int dst[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = t + i * 256;
       const int br = q / BPX, bp = q - br * BPX;
       const int iy = iy0 + br, ix = ix0 + bp;
-      const unsigned off = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (unsigned)(iy * a.x_row + ix * a.x_pix) * 2u : kOOBt;
-      const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
-      *reinterpret_cast<u32x2*>(smem + br * BROWB + bp * 8) = v;
+      const unsigned off = (q < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (unsigned)(iy * a.x_row + ix * a.x_pix) * 2u : kOOBt;
+      v[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
+      dst[i] = q < NPX ? br * BROWB + bp * 8 : -1;
     }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+      if (dst[i] >= 0) *reinterpret_cast<u32x2*>(smem + dst[i]) = v[i];
   }
   __syncthreads();
 

@@ -50,6 +50,13 @@ CASES = [  # n, cin, cout, h, w, shortcut, relu, affine
     (3, 128, 256, 7, 9, True, True, False),      # 189 pixels, no affine, batch 3
     (1, 256, 256, 34, 46, False, True, True),    # one 256-channel slice: a grid of pixel chunks only
     (1, 512, 256, 16, 16, True, True, True),     # K = 512 with a single slice
+    # walks of 1-2, 2-3, 4-5 and 6-7 steps per workgroup (64 pixel ranges at N = 1024): the peeled first steps, the steady loop, the tail
+    (1, 256, 1024, 45, 46, True, True, True),    # 2070 pixels = 65 steps
+    (1, 256, 1024, 65, 71, True, True, True),    # 4615 pixels = 145 steps
+    (2, 256, 1024, 67, 70, True, False, True),   # 9380 pixels = 294 steps
+    (3, 256, 1024, 61, 70, False, True, True),   # 12810 pixels = 401 steps
+    (2, 64, 256, 100, 101, True, True, True),    # the 4-wave form (512 ranges): 20200 pixels = 632 steps, 1-2 per workgroup
+    (1, 128, 512, 130, 131, True, True, True),   # K = 128: 17030 pixels = 533 steps over 128 ranges: 4-5 steps
 ]
 
 
