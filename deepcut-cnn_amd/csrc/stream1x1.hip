@@ -4,21 +4,24 @@
 // 128 -> 512, 256 -> 1024, 512 -> 2048 channels) and the stride-1 projections (res2a_branch1).  At batch 8 (BASELINE configs[2]) a res4 one
 // moves 58 MB (6.4 in, 25.6 shortcut, 25.6 out) for 6.6 GFLOP: 9 us of HBM time, 2.6 us of MFMA time — the gather-GEMM tile took 17.3 us
 // (3.35 TB/s): per 128 x 64 tile it paid 3.7 k cycles of prologue, a 4-tile K loop that waits for memory once per tile (MFMA content 1.0 k of
-// 5.7 k cycles) and a 2.3 k epilogue, with one tile per workgroup in flight (profiles/r06_stream1x1_*.txt; VERDICT r5 weak spot 1: "the
+// 5.7 k cycles) and a 2.3 k epilogue, with one tile per workgroup in flight (profiles/r06_stream1x1_probe.txt; VERDICT r5 weak spot 1: "the
 // 1x1+shortcut layers reach 3.2 TB/s where 6.3 is achievable").
 //
-// The form here, per workgroup of 4 waves:
-//  * the FILTERS of its channel slice (128 * FN channels x all K) live in REGISTERS for the whole launch, as the A operand of
-//    v_mfma_f32_32x32x16_f16 (rows = output channels): fetched once, in fragment order, 1 KiB per wave instruction (ws_pack_filters);
-//  * the workgroup walks a contiguous range of 32-pixel STEPS (a persistent loop, the grid is ~2 workgroups per CU); the pixels of a step
-//    (32 x K halves) travel by LDS-DMA into a ring of D stages, D-1 steps ahead of their use, swizzled at the source like the gather-GEMM's
-//    operand tiles (conflict-free ds_read_b128 B operands); one workgroup barrier per step;
-//  * the shortcut vectors of the NEXT step are requested before the MFMAs of this one (registers), the epilogue (folded BatchNorm/Scale affine
-//    in fp32, shortcut add by v_fma_mix, ReLU, 16-byte stores formed with v_permlane32_swap) is the gather-GEMM's swapped-operand one —
-//    same instructions in the same order, so the results are bit-identical to the direct tiles';
-//  * vmcnt is counted: DMA pieces, shortcut loads and stores of a step are a fixed number of requests (dummy out-of-range requests past the
-//    end of the range), so "my pieces of step s have landed" is s_waitcnt vmcnt(constant) with D-1 steps still in flight;
-//  * blocks of the same pixel range (the tn channel slices) are neighbours on one XCD (blockIdx % 8), so the pixels cross the fabric once.
+// The form here, per workgroup (8 waves, one workgroup per CU, for K = 128 / 256 / 512; 4 waves, two per CU, for K = 64):
+//  * the FILTERS of its channel slice (NW * FN * 32 channels x all K) live in REGISTERS for the whole launch, as the ROW operand of
+//    v_mfma_f32_32x32x16_f16 (rows = output channels): fetched once, in fragment order, 1 KiB per wave instruction (stream1x1_pack_filters);
+//  * the workgroup walks a contiguous range of 32-pixel STEPS (a persistent loop); the pixels of a step (32 x K halves) travel by LDS-DMA
+//    into a ring of D stages, D-1 steps ahead of their use, swizzled at the source like the gather-GEMM's operand tiles (conflict-free
+//    ds_read_b128 column operands); one workgroup barrier per step;
+//  * the wave's shortcut tile arrives by LDS-DMA in a wave-private buffer two steps ahead, as whole runs of the tensor; the epilogue (folded
+//    BatchNorm/Scale affine in fp32, shortcut add by v_fma_mix, ReLU, 16-byte vectors formed with v_permlane32_swap) is the gather-GEMM's
+//    swapped-operand one — same instructions on the same operands, so the results are bit-identical to a direct tile without split-K —,
+//    puts its vectors where it read the shortcut from, and the tile leaves as whole runs again;
+//  * vmcnt is counted: pixel pieces, shortcut pieces and stores of a step are a fixed number of requests (dummy out-of-range requests past
+//    the end of the range), so "my pieces of step s have landed" is s_waitcnt vmcnt(constant) with D-1 steps still in flight.  EVERY load
+//    is an inline-asm request the compiler does not track (a tracked one puts the compiler's own vmcnt(0) into the loop);
+//  * blocks of the same pixel range (the tn channel slices) are neighbours on one XCD (blockIdx % 8), so the pixels cross the fabric once;
+//  * the two halves of the workgroup take the step in opposite order (waves w and w + NW/2 share a SIMD).
 // A multi-problem launch (NetGroup: the scales of an image pyramid) is the same walk over the steps of several tensors in turn.
 #include <hip/hip_runtime.h>
 
