@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libdeepcut_hip.so")
 SOURCES = ["formats.cpp", "hdf5_reader.cpp", "runtime.cpp", "net_init.cpp", "net_lower.cpp", "net_tune.cpp", "net_run.cpp", "net_image.cpp",
-           "net_group.cpp", "streams.cpp", "multi_gpu.cpp", "c_api.cpp", "kernels.hip", "wino_f16.hip", "stream1x1.hip", "stem_f16.hip"]
+           "net_group.cpp", "streams.cpp", "multi_gpu.cpp", "c_api.cpp", "kernels.hip", "wino_f16.hip", "stream1x1.hip", "stem_f16.hip", "stream1x1_f32.hip"]
 HEADERS = ["formats.h", "net.h", "net_internal.h", "kernels.h", os.path.join("..", "..", "include", "deepcut_hip.h")]
 
 

@@ -174,7 +174,7 @@ struct Launch {
   std::shared_ptr<DevVec> wino_scale;       // float16 nets: the epilogue scale of the Winograd form (folded affine x the image's row scale x 4)
   // a Winograd form this launch can run as: the image exists and the form serves the net's element type
   bool takes_wino(int v) const {
-    return is_wino_variant(v) && (bool)wino_w && wino_variant_esize(v) == cg.esize && cg.ncls <= 1 && (v == kStreamHalf) == (cg.nty == 1 && cg.ntx == 1) &&
+    return is_wino_variant(v) && (bool)wino_w && wino_variant_esize(v) == cg.esize && cg.ncls <= 1 && (v == kStreamHalf || v == kStreamFloat) == (cg.nty == 1 && cg.ntx == 1) &&
            (v == kStemHalf) == (cg.nty == 7 && cg.ntx == 1);
   }
   long y_off = 0;                      // element offset of this launch's first output (deconvolution classes, channel splits)

@@ -718,6 +718,14 @@ void Net::build_plan() {
         l.wino_w->as_half = true;
         if (stream_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStreamHalf);
       }
+      if (!rowtap && !l.wino_w && stream_mode != 0 && op.wls.empty() && dtype == 0 && g.klen == C && g.Ktot == C && stream1x1f_eligible(g)) {
+        // float32 dense 1x1 layers with 256 / 512 input channels (stream1x1_f32.hip): the filters in the order of its 16x16x4 matrix steps
+        l.wino_w = get_vec(dkey + "wsf:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          h.assign(stream1x1f_packed_elems(OC, C), 0.f);
+          stream1x1f_pack_filters(L.params[0]->st->host_ptr(), OC, C, h.data());
+        });
+        if (stream_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStreamFloat);
+      }
       if (rowtap && stem_mode != 0 && op.wls.empty() && dtype == 1 && C <= 4 && stem7x7_eligible(g)) {
         // float16 stem (stem_f16.hip): the same row-scaled filters as the row-tap image, the 28 real elements of every kernel row in MFMA
         // operand order; scale / shift are the launch's own.  The per-shape timing decides (DC_STEM=1: forced, 0: never)

@@ -39,7 +39,7 @@ def make(caffe, a, name, rs, env, **kw):
     for k in ("DC_STREAM1X1", "DC_AUTOTUNE"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    net = caffe.Net(net_text(a.batch, cin, cout, h, w, shortcut), caffe.TEST, from_text=True, dtype="f16", **kw)
+    net = caffe.Net(net_text(a.batch, cin, cout, h, w, shortcut), caffe.TEST, from_text=True, dtype=a.dtype, **kw)
     return net
 
 
@@ -47,6 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--shapes", default="res4c,res3c,res2c,res5c,res2a1")
+    ap.add_argument("--dtype", default="f16", choices=("f16", "f32"), help="f32: the float32 form (csrc/stream1x1_f32.hip, 'ws1x1f': K = 256 / 512 only, not bit-identical to the tiles)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stamps", action="store_true", help="only the forced streaming launch of every shape, graph off (run with DC_DEBUG_TIMING=0)")
     a = ap.parse_args()
@@ -92,13 +93,14 @@ def main():
                 res[mode] = net.blobs[out].data.copy()
                 del net
             # float64 evaluation of the float16 operands (the library scales each filter row by a power of two before rounding: exact)
-            xh = x.astype(np.float16).astype(np.float64)
-            wh = wt.reshape(cout, cin).astype(np.float16).astype(np.float64)
+            ht = np.float16 if a.dtype == "f16" else np.float32
+            xh = x.astype(ht).astype(np.float64)
+            wh = wt.reshape(cout, cin).astype(ht).astype(np.float64)
             ref = np.einsum("nchw,oc->nohw", xh, wh)
             a_ = (ga.astype(np.float64) / np.sqrt(var.astype(np.float64) + 1e-5))
             ref = ref * a_[None, :, None, None] + (be.astype(np.float64) - mean.astype(np.float64) * a_)[None, :, None, None]
             if shortcut:
-                ref = np.maximum(ref + sc.astype(np.float16).astype(np.float64), 0.0)
+                ref = np.maximum(ref + sc.astype(ht).astype(np.float64), 0.0)
             err = float(np.abs(res["1"] - ref).max())
             same = bool(np.array_equal(res["1"], res["0"]))
             print("%s batch %d: ws1x1 vs float64 of the float16 operands max|d| = %.3e (range %.1f) | vs the direct tile: %s (max|d| %.3e)" % (
@@ -107,14 +109,15 @@ def main():
         fill(net)
         net.forward()
         M = a.batch * h * w
-        mbytes = 2.0 * (M * cin + M * cout * (2 if shortcut else 1) + cin * cout) / 1e6
+        mbytes = (2.0 if a.dtype == "f16" else 4.0) * (M * cin + M * cout * (2 if shortcut else 1) + cin * cout) / 1e6
         for e in net.tune_report():
             timed = sorted(e["timed"], key=lambda t: t[1])
             direct = [t for t in timed if not t[0].startswith("ws1x1")]
             ws = [t for t in timed if t[0].startswith("ws1x1")]
-            print("%s %dx%dx%d %d->%d%s (%.1f MB): chosen %s | best direct %s %.2f us (%.2f TB/s) | %s" % (
-                name, a.batch, h, w, cin, cout, " +shortcut" if shortcut else "", mbytes, e["tile"], direct[0][0], direct[0][1], mbytes / direct[0][1],
-                " ".join("%s %.2f us (%.2f TB/s)" % (t[0], t[1], mbytes / t[1]) for t in ws)), flush=True)
+            gflop = 2.0 * M * cin * cout / 1e9
+            print("%s %dx%dx%d %d->%d%s (%.1f MB, %.3f GFLOP): chosen %s | best direct %s %.2f us (%.2f TB/s, %.1f TFLOP/s) | %s" % (
+                name, a.batch, h, w, cin, cout, " +shortcut" if shortcut else "", mbytes, gflop, e["tile"], direct[0][0], direct[0][1], mbytes / direct[0][1],
+                gflop / direct[0][1] * 1e3, " ".join("%s %.2f us (%.2f TB/s, %.1f TFLOP/s)" % (t[0], t[1], mbytes / t[1], gflop / t[1] * 1e3) for t in ws)), flush=True)
         del net
 
 
