@@ -42,6 +42,8 @@ def variant_name(name):
 
 
 def label(name):
+    if "ws1x1f_kernel" in name:  # its float32 form (csrc/stream1x1_f32.hip)
+        return "ws1x1f (streaming 1x1, float32)"
     if "ws1x1_kernel" in name:  # the streaming form of the dense float16 1x1 layers (csrc/stream1x1.hip)
         return "ws1x1 (streaming 1x1, float16)"
     if "stem7x7_kernel" in name:  # the float16 stem (csrc/stem_f16.hip)

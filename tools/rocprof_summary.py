@@ -24,11 +24,11 @@ def main(path):
     print("# rocprofv3 --kernel-trace --stats summary of %s (from per-dispatch start/end, ns)" % path)
     print("%-112s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        shown = kernel_names.label(name) if ("conv_gemm_kernel" in name or "wino_f23" in name or "wino_h23" in name or "ws1x1_kernel" in name or "stem7x7_kernel" in name) else name
+        shown = kernel_names.label(name) if ("conv_gemm_kernel" in name or "wino_f23" in name or "wino_h23" in name or "ws1x1_kernel" in name or "ws1x1f_kernel" in name or "stem7x7_kernel" in name) else name
         print("%-112s %8d %12.1f %10.2f %7.2f" % (shown[:112], n, t / 1e3, t / n / 1e3, 100.0 * t / tot))
     print("# total kernel time: %.3f ms over %d dispatches" % (tot / 1e6, sum(a[0] for a in agg.values())))
-    n = sum(a[0] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k or "wino_h23_kernel" in k or "ws1x1_kernel" in k or "stem7x7_kernel" in k)
-    t = sum(a[1] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k or "wino_h23_kernel" in k or "ws1x1_kernel" in k or "stem7x7_kernel" in k)
+    n = sum(a[0] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k or "wino_h23_kernel" in k or "ws1x1_kernel" in k or "ws1x1f_kernel" in k or "stem7x7_kernel" in k)
+    t = sum(a[1] for k, a in agg.items() if "conv_gemm_kernel" in k or "wino_f23_kernel" in k or "wino_h23_kernel" in k or "ws1x1_kernel" in k or "ws1x1f_kernel" in k or "stem7x7_kernel" in k)
     if n:
         print("# conv_gemm_kernel + wino_f23_kernel (every convolution / deconvolution launch): %d dispatches, %.3f ms total, average %.2f us per launch" % (n, t / 1e6, t / n / 1e3))
 
