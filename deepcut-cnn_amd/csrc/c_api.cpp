@@ -581,6 +581,12 @@ int dc_stream1x1_pack(const float* g, int cout, int k, float* out) {
   return guard([&] { dc::stream1x1_pack_filters(g, cout, k, out); });
 }
 
+int dc_stream1x1f_pack(const float* g, int cout, int k, float* out) {
+  if (!g || !out) return fail(DC_EINVAL, "dc_stream1x1f_pack: null pointer");
+  if (cout <= 0 || k <= 0 || cout % 16 || k % 16) return fail(DC_EINVAL, "dc_stream1x1f_pack: cout and k must be multiples of 16");
+  return guard([&] { dc::stream1x1f_pack_filters(g, cout, k, out); });
+}
+
 int dc_stem7x7_pack(const float* g, int c, float* out) {
   if (!g || !out) return fail(DC_EINVAL, "dc_stem7x7_pack: null pointer");
   if (c < 1 || c > 4) return fail(DC_EINVAL, "dc_stem7x7_pack: 1 to 4 input channels");

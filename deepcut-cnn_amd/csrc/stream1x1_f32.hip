@@ -96,30 +96,22 @@ struct ReqCount {
   static_assert(resid(kSteady) <= 63 && stage(kSteady) >= 0 && pro >= 0, "vmcnt is a 6-bit counter");
 };
 
-// K = input channels (256 or 512: a pixel's row is a whole number of 1 KiB requests), D = ring stages.
-// 8 waves: waves 0-3 multiply (one per SIMD, 16 channels each), waves 4-7 move bytes (the LDS-DMA requests of the ring, the shortcut tiles,
-// the output stores and the shortcut add + ReLU).  A request costs the wave that issues it ~100 cycles of its instruction stream
-// (MI355X_MICROARCH.md: "LDS-DMA piece issue cost") and the partner on its SIMD ~20: in the multiplying wave's own stream five requests per
-// 16-pixel step were a quarter of the step (the first form of this kernel: 2 600 cycles per 2 048 cycles of products).
-template <int K, int D, bool RES, bool RELU, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void ws1x1f_kernel(const WsfArgs a) {
+// K = input channels (256 or 512: a pixel's row is a whole number of 1 KiB requests), D = ring stages
+template <int K, int D, bool RES, bool RELU>
+__global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
   constexpr int ROWB = K * 4 + 16;   // bytes of a pixel's row in LDS (padded: lanes p = 0..15 of a read land in 16 different bank groups)
   constexpr int STG = 16 * ROWB;     // a stage: 16 pixels
   constexpr int PPR = K * 4 / 1024;  // 1 KiB requests per pixel row
-  constexpr int NA = 16 * PPR / 4;   // ... per moving wave and stage
-  constexpr int NJ = K / 16;         // 16-byte reads (= 4 matrix steps each) per multiplying wave and step
+  constexpr int NA = 16 * PPR / 4;   // ... per wave and stage
+  constexpr int NJ = K / 16;         // 16-byte reads (= 4 matrix steps each) per wave and step
   constexpr int NR = RES ? 1 : 0, NS = 1;
   static_assert(K % 256 == 0 && D >= 3 && D <= 4, "row = whole requests; the ring");
   using Rq = ReqCount<D, NA, NR, NS>;
-  constexpr int OB0 = D * STG;             // 4 waves x 2 x 1 KiB: the product tiles (after scale / shift), written in the matrix view
-  constexpr int RB0 = OB0 + 4 * 2 * 1024;  // 4 waves x 2 x 1 KiB: the shortcut tiles, in the memory view
-  constexpr int LDSB = RB0 + 4 * 2 * 1024;
+  constexpr int LDSB = D * STG + 4 * 2 * 1024;
   static_assert(LDSB <= 160 * 1024, "LDS of a CU");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDSB];
-  const int t = threadIdx.x, lane = t & 63, wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wave = wave8 & 3;
-  const bool mover = wave8 >= 4 && ABL != 4 && ABL != 5;  // (4 / 5: all eight waves multiply — twice the products, no data)
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int p16 = lane & 15, q = lane >> 4;
 
   const int bx = blockIdx.x, xcd = bx & 7, bi = bx >> 3;
@@ -129,88 +121,9 @@ __global__ __launch_bounds__(512, 1) void ws1x1f_kernel(const WsfArgs a) {
   if (jc >= a.J) return;
   int gs0 = jc * a.sbase + min(jc, a.srem), gs1 = gs0 + a.sbase + (jc < a.srem ? 1 : 0);
   if (a.srem < 0) gs0 = a.S * jc / a.J, gs1 = a.S * (jc + 1) / a.J;  // (DC_WSF_REMAP=0: the longer ranges spread over the grid, for A/B timing)
-  const int nw0 = nt * 64 + wave * 16;  // first channel of this wave (of the pair on this SIMD)
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto stamp = [&](int sl) {
-    if (a.dbg && lane == 0 && !mover) {
-      long long* d = a.dbg + ((long)blockIdx.x * 4 + wave) * 12;
-      d[sl] = (long long)__builtin_readcyclecounter();
-      if (sl == 0) d[8] = t_entry, d[10] = (long long)__builtin_amdgcn_s_memrealtime();
-      if (sl == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
-    }
-  };
+  const int nw0 = nt * 64 + wave * 16;  // first channel of this wave
 
-  if (mover) {
-    // ================================================================ the moving wave
-    const i32x4 xr = f_rsrc_words(a.x), rr = f_rsrc_words(RES ? a.resid : a.y), yr = f_rsrc_words(a.y);
-    const int orow = lane >> 2;  // memory view: pixel lane / 4, channels 4 (lane % 4) .. + 3 of the wave's 16
-    const unsigned ooff = (unsigned)((nw0 + 4 * (lane & 3)) * 4);
-    auto dma_req = [&](int gs, int slot, int i) {  // request i of the wave's NA for stage gs (issued whatever gs is: beyond the range it moves nothing)
-      const int row0 = gs * 16;
-      const int lim = gs < gs1 ? a.M - row0 : 0;
-      const int pc = wave + 4 * i, row = pc / PPR, part = pc - row * PPR;  // request pc of the stage: part `part` of row `row`
-      const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(part * 1024 + lane * 16) : kOOBf;
-      f_dma16(xr, lds0 + (unsigned)(slot * STG + row * ROWB + part * 1024), vo);
-    };
-    auto resid_req = [&](int gs, int buf) {  // NR requests, always
-      if (!RES) return;
-      const int row0 = gs * 16;
-      const int lim = gs < gs1 ? a.M - row0 : 0;
-      f_dma16(rr, lds0 + (unsigned)(RB0 + (wave * 2 + buf) * 1024), orow < lim ? (unsigned)(row0 + orow) * (unsigned)a.ypb + ooff : kOOBf);
-    };
-    auto finish = [&](int gs, int buf) {  // product tile + shortcut tile of step gs -> memory
-      const f32x4 o = *reinterpret_cast<const f32x4*>(smem + OB0 + (wave * 2 + buf) * 1024 + lane * 16);
-      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-      if (RES) rv = *reinterpret_cast<const f32x4*>(smem + RB0 + (wave * 2 + buf) * 1024 + lane * 16);
-      u32x4 ov;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = o[r];
-        if (RES) v += rv[r];
-        ov[r] = __float_as_uint(RELU ? fmaxf(v, 0.f) : v);
-      }
-      const int row0 = gs * 16;
-      f_store16_untracked(yr, orow < a.M - row0 ? (unsigned)(row0 + orow) * (unsigned)a.ypb + ooff : kOOBf, ov);
-    };
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-#pragma unroll
-      for (int i = 0; i < NA; ++i) dma_req(gs0 + d, d, i);
-    resid_req(gs0, 0);
-    resid_req(gs0 + 1, 1);
-    f_wait_vm<Rq::pro>();
-    f_lds_barrier();
-    int slot = 0, ob = 0;
-    auto do_step = [&](int gs, auto k_tag) {
-      constexpr int KS = decltype(k_tag)::value;  // the step's number while the request counts still change (Rq), -1 in the steady state
-      constexpr int KQ = KS < 0 ? Rq::kSteady : KS;
-      const int nslot = slot + 1 == D ? 0 : slot + 1, pslot = slot == 0 ? D - 1 : slot - 1;
-      f_wait_vm<Rq::stage(KQ)>();
-      if (ABL != 2 && ABL != 5) f_lds_barrier();  // stage gs+1 is whole; the slot of step gs-1 is free; the product tile of step gs-1 is written
-#pragma unroll
-      for (int i = 0; i < NA; ++i) dma_req(gs + D - 1, pslot, i);
-      if (KS != 0) {
-        if (RES) f_wait_vm<Rq::resid(KQ)>();
-        finish(gs - 1, ob);
-        resid_req(gs + 1, ob);
-        ob ^= 1;
-      }
-      slot = nslot;
-    };
-    int gs = gs0;
-    if (gs < gs1) do_step(gs++, std::integral_constant<int, 0>{});
-    if (gs < gs1) do_step(gs++, std::integral_constant<int, 1>{});
-    if (gs < gs1) do_step(gs++, std::integral_constant<int, 2>{});
-    static_assert(Rq::kPeel == 3, "steps 0, 1, 2 above");
-    for (; gs < gs1; ++gs) do_step(gs, std::integral_constant<int, -1>{});
-    f_wait_vm<0>();
-    f_lds_barrier();  // the last product tile is written
-    finish(gs1 - 1, ob);  // (ob names the last step's tile: it has flipped once per finished step)
-    return;
-  }
-
-  // ================================================================ the multiplying wave
-  // ---- epilogue constants (4 channels per lane: 4 q + r) and filters: the wave's only vector-memory requests
+  // ---- epilogue constants (4 channels per lane: 4 q + r) and filters: untracked requests, the oldest of the wave (stream1x1.hip)
   f32x4 csc = {1.f, 1.f, 1.f, 1.f}, csh = {0.f, 0.f, 0.f, 0.f};
   {
     const unsigned co = (unsigned)((nw0 + 4 * q) * 4);
@@ -227,62 +140,97 @@ __global__ __launch_bounds__(512, 1) void ws1x1f_kernel(const WsfArgs a) {
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(wreg[j]) : "v"(wl), "s"(wrs), "s"(so) : "memory");
     }
   }
-  const unsigned frag0 = (unsigned)(p16 * ROWB + q * K);  // this lane's run of the pixel's row: + 16 j
-  const unsigned ovec = (unsigned)((4 * p16 + q) * 16);   // matrix view: pixel p16, channels 4 q .. + 3
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const i32x4 xr = f_rsrc_words(a.x), rr = f_rsrc_words(RES ? a.resid : a.y), yr = f_rsrc_words(a.y);
+  const unsigned frag0 = (unsigned)(p16 * ROWB + q * K);                  // this lane's run of the pixel's row: + 16 j
+  const unsigned obuf0 = (unsigned)(D * STG + wave * 2 * 1024);           // this wave's two 1 KiB tiles
+  const unsigned ovec = (unsigned)((4 * p16 + q) * 16);                   // MFMA view: pixel p16, channels 4 q .. + 3
+  const int orow = lane >> 2;                                             // memory view: pixel lane / 4, channels 4 (lane % 4) .. + 3
+  const unsigned ooff = (unsigned)((nw0 + 4 * (lane & 3)) * 4);
+  auto dma_req = [&](int gs, int slot, int i) {  // request i of the wave's NA for stage gs (issued whatever gs is: beyond the range it moves nothing)
+    const int row0 = gs * 16;
+    const int lim = gs < gs1 ? a.M - row0 : 0;
+    const int pc = wave + 4 * i, row = pc / PPR, part = pc - row * PPR;  // request pc of the stage: part `part` of row `row`
+    const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(part * 1024 + lane * 16) : kOOBf;
+    f_dma16(xr, lds0 + (unsigned)(slot * STG + row * ROWB + part * 1024), vo);
+  };
+  auto resid_step = [&](int gs, int buf) {  // NR requests, always
+    if (!RES) return;
+    const int row0 = gs * 16;
+    const int lim = gs < gs1 ? a.M - row0 : 0;
+    f_dma16(rr, lds0 + obuf0 + (unsigned)(buf * 1024), orow < lim ? (unsigned)(row0 + orow) * (unsigned)a.ypb + ooff : kOOBf);
+  };
+  auto stamp = [&](int sl) {
+    if (a.dbg && lane == 0) {
+      long long* d = a.dbg + ((long)blockIdx.x * 4 + wave) * 12;
+      d[sl] = (long long)__builtin_readcyclecounter();
+      if (sl == 0) d[8] = t_entry, d[10] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (sl == 7) d[9] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+  };
   stamp(0);
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma_req(gs0 + d, d, i);
+  resid_step(gs0, 0);
+  resid_step(gs0 + 1, 1);
   stamp(1);
-  f_wait_vm<0>();
+  f_wait_vm<Rq::pro>();
   asm volatile("" : "+v"(csc), "+v"(csh));
 #pragma unroll
   for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(wreg[j]));
-  f_lds_barrier();  // stage 0 is whole
+  f_lds_barrier();
   stamp(2);
 
-  // One step = the NJ x 4 matrix products of 16 pixels.  The matrix pipe runs from the first step's first product to the last step's last
-  // one: the operand reads run PD-1 reads ahead across the step boundary, and the step's one barrier (stage k+1 published, the tile of
-  // step k-1 handed to the moving wave) sits between its products.
+  // One step = the NJ x 4 matrix products of 16 pixels, and everything else BETWEEN them, so that the matrix pipe runs from the first
+  // step's first product to the last step's last one:
+  //  * the barrier that publishes stage k+1 (and frees the slot of step k-1 for stage k+D-1, requested right behind it) sits inside step k;
+  //    the operand reads run PD-1 reads ahead across the step boundary;
+  //  * the epilogue of step k-1 (shortcut wait, LDS round trips, store, next shortcut request) rides in step k.
   constexpr int PD = 4;
   static_assert(NJ % PD == 0, "the operand ring keeps its phase across steps");
   int slot = 0, ob = 0;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 xf[PD];
 #pragma unroll
   for (int j = 0; j < PD - 1; ++j) xf[j] = *reinterpret_cast<const f32x4*>(smem + frag0 + j * 16);
-  auto hand_over = [&](int buf) {  // register r of a lane = channel 4 q + r of pixel p16
-    const f32x4 sum = ABL == 3 ? (acc0 + acc1) + (acc2 + acc3) : acc0 + acc1;
+  auto epi_read = [&](unsigned char* obp, f32x4& rv) {
+    if (RES) rv = *reinterpret_cast<const f32x4*>(obp + ovec);
+  };
+  auto epi_math = [&](unsigned char* obp, const f32x4& sum, const f32x4& rv) {  // register r of a lane = channel 4 q + r of pixel p16
     f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = sum[r] * csc[r] + csh[r];
-    *reinterpret_cast<f32x4*>(smem + OB0 + (wave * 2 + buf) * 1024 + ovec) = o;
+    for (int r = 0; r < 4; ++r) {
+      float v = sum[r] * csc[r] + csh[r];
+      if (RES) v += rv[r];
+      o[r] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    *reinterpret_cast<f32x4*>(obp + ovec) = o;
   };
-  auto do_step = [&](bool first) {
-    constexpr int HB = 1;
-    static_assert(HB < NJ - PD + 1, "stage k+1 is read only behind its barrier");
-    const int nslot = slot + 1 == D ? 0 : slot + 1;
+  auto epi_store = [&](int gs, const u32x4& ov) {  // memory view: 16 pixels x 64-byte runs
+    const int row0 = gs * 16;
+    f_store16_untracked(yr, orow < a.M - row0 ? (unsigned)(row0 + orow) * (unsigned)a.ypb + ooff : kOOBf, ov);
+  };
+  auto do_step = [&](int gs, auto k_tag) {
+    constexpr int KS = decltype(k_tag)::value;  // the step's number while the request counts still change (Rq), -1 in the steady state
+    constexpr int KQ = KS < 0 ? Rq::kSteady : KS;
+    constexpr bool EPI = KS != 0;               // step 0 has no step before it
+    constexpr int HB = 1, H1 = HB + NA + 1, H2 = H1 + 2, H3 = H2 + 2, H4 = H3 + 2;
+    static_assert(H4 < NJ && HB < NJ - PD + 1, "the pieces inside the product loop; stage k+1 is read only behind its barrier");
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+    u32x4 ov = {0u, 0u, 0u, 0u};
+    if (EPI) sum = acc0 + acc1;
+    unsigned char* const obp = smem + obuf0 + ob * 1024;
+    const int nslot = slot + 1 == D ? 0 : slot + 1, pslot = slot == 0 ? D - 1 : slot - 1;
     const unsigned char* st = smem + slot * STG + frag0;
     const unsigned char* stn = smem + nslot * STG + frag0;
-    if (!first) {
-      hand_over(ob);
-      ob ^= 1;
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int jn = j + PD - 1;
-      if (ABL != 1 && ABL != 2 && ABL != 5) xf[jn % PD] = *reinterpret_cast<const f32x4*>(jn < NJ ? st + jn * 16 : stn + (jn - NJ) * 16);
-      if (ABL == 3) {  // four accumulators
-        if (j == 0) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][0], xf[j % PD][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][1], xf[j % PD][1], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][2], xf[j % PD][2], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][3], xf[j % PD][3], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][0], xf[j % PD][0], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][1], xf[j % PD][1], acc1, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][2], xf[j % PD][2], acc2, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][3], xf[j % PD][3], acc3, 0, 0, 0);
-        }
-      } else {
+      xf[jn % PD] = *reinterpret_cast<const f32x4*>(jn < NJ ? st + jn * 16 : stn + (jn - NJ) * 16);
       if (j == 0) {  // fresh accumulators: the first two products take the constant 0
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][0], xf[j % PD][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][1], xf[j % PD][1], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -292,20 +240,44 @@ __global__ __launch_bounds__(512, 1) void ws1x1f_kernel(const WsfArgs a) {
       }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][2], xf[j % PD][2], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][3], xf[j % PD][3], acc1, 0, 0, 0);
+      if (j == HB) {
+        f_wait_vm<Rq::stage(KQ)>();
+        asm volatile("s_barrier" ::: "memory");
       }
-      if (j == HB && ABL != 2 && ABL != 5) f_lds_barrier();
+      if (j > HB && j <= HB + NA) dma_req(gs + D - 1, pslot, j - HB - 1);
+      if (EPI && j == H1) {
+        if (RES) f_wait_vm<Rq::resid(KQ)>();
+        epi_read(obp, rv);
+      }
+      if (EPI && j == H2) epi_math(obp, sum, rv);
+      if (EPI && j == H3) ov = *reinterpret_cast<const u32x4*>(obp + lane * 16);
+      if (EPI && j == H4) {
+        epi_store(gs - 1, ov);
+        resid_step(gs + 1, ob);
+        if (RES) ob ^= 1;
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     slot = nslot;
   };
   int gs = gs0;
-  if (gs < gs1) do_step(true), ++gs;
+  if (gs < gs1) do_step(gs++, std::integral_constant<int, 0>{});
+  if (gs < gs1) do_step(gs++, std::integral_constant<int, 1>{});
+  if (gs < gs1) do_step(gs++, std::integral_constant<int, 2>{});
+  static_assert(Rq::kPeel == 3, "steps 0, 1, 2 above");
   stamp(3);
-  for (; gs < gs1; ++gs) do_step(false);
+  for (; gs < gs1; ++gs) do_step(gs, std::integral_constant<int, -1>{});
   stamp(4);
-  hand_over(ob);
+  // the last step's epilogue, alone
+  f_wait_vm<0>();
   stamp(5);
-  f_lds_barrier();
+  if (gs1 > gs0) {
+    unsigned char* const obp = smem + obuf0 + ob * 1024;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    epi_read(obp, rv);
+    epi_math(obp, acc0 + acc1, rv);
+    epi_store(gs1 - 1, *reinterpret_cast<const u32x4*>(obp + lane * 16));
+  }
   stamp(6);
   stamp(7);
 }
@@ -388,16 +360,7 @@ int launch_stream1x1f(const ConvGemmParams& p, void* stream) {
   a.M = p.M, a.Cout = p.Cout, a.sxb = p.sx * 4, a.ypb = p.y_pix_stride * 4, a.dbg = p.dbg;
   const long grid = wsf_plan(a);
   if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
-  WsfKernel kern = f->k[p.resid ? 1 : 0][p.relu ? 1 : 0];
-  static const int abl = getenv("DC_WSF_ABL") ? atoi(getenv("DC_WSF_ABL")) : 0;  // timing ablations of the conv4_x form (wrong results): tools/stream1x1_probe.py
-  if (abl && p.klen == 256 && p.resid && p.relu) {
-    // 1: no operand reads in the loop, 2: neither reads nor barriers, 3: four accumulators instead of two (right results)
-    // 4: all eight waves multiply (two per SIMD, twice the products, no data moved), 5: 4 without reads and barriers
-    static const WsfKernel kAbl[6] = {nullptr, ws1x1f_kernel<256, 4, true, true, 1>, ws1x1f_kernel<256, 4, true, true, 2>, ws1x1f_kernel<256, 4, true, true, 3>,
-                                      ws1x1f_kernel<256, 4, true, true, 4>, ws1x1f_kernel<256, 4, true, true, 5>};
-    if (abl >= 1 && abl <= 5) kern = kAbl[abl];
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(f->k[p.resid ? 1 : 0][p.relu ? 1 : 0], dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

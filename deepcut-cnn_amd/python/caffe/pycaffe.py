@@ -144,6 +144,7 @@ def _load():
         "dc_wino_half_pack": (ci, [C.c_void_p, ci, ci, ci, C.c_void_p, C.c_void_p]),
         "dc_stream1x1_pack": (ci, [C.c_void_p, ci, ci, C.c_void_p]),
         "dc_stem7x7_pack": (ci, [C.c_void_p, ci, C.c_void_p]),
+        "dc_stream1x1f_pack": (ci, [C.c_void_p, ci, ci, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -188,6 +189,16 @@ def stream1x1_pack(g):
     cout, k = g.shape[0], int(np.prod(g.shape[1:]))
     out = np.empty((cout // 32, k // 16, 64, 8), np.float32)
     _check(_lib.dc_stream1x1_pack(g.ctypes.data_as(C.c_void_p), cout, k, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def stream1x1f_pack(g):
+    """dc_stream1x1f_pack: the filter image of the float32 streaming 1x1 form (csrc/stream1x1_f32.hip) of g [cout, k] (or [cout, k, 1, 1]) as
+    the lowering packs it: [cout/16][k/16][64 lanes][4] (tests / diagnostics)."""
+    g = np.ascontiguousarray(g, np.float32)
+    cout, k = g.shape[0], int(np.prod(g.shape[1:]))
+    out = np.empty((cout // 16, k // 16, 64, 4), np.float32)
+    _check(_lib.dc_stream1x1f_pack(g.ctypes.data_as(C.c_void_p), cout, k, out.ctypes.data_as(C.c_void_p)))
     return out
 
 

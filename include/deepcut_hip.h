@@ -330,6 +330,12 @@ int dc_wino_half_pack(const float* g, int cout, int cin, int rowscale, float* ou
  *    of a kernel row at lane 32 * ((e % 16) / 8) + co % 32, position e % 8 of K step e / 16, zeros elsewhere (csrc/stem_f16.hip).        */
 int dc_stream1x1_pack(const float* g, int cout, int k, float* out);
 int dc_stem7x7_pack(const float* g, int c, float* out);
+/*  dc_stream1x1f_pack: the float32 form of the streaming 1x1 kernel (csrc/stream1x1_f32.hip, tile `ws1x1f`): g = [cout][k] (cout % 16 == 0,
+ *    k % 16 == 0) -> out[cout * k] in the ROW-operand order of v_mfma_f32_16x16x4_f32 with the K range cut into four runs,
+ *    [cout/16][k/16 vectors][64 lanes][4]: lane = 16 q + co % 16 holds run q, element e of vector j = g[co][q k/4 + 4 j + e] — matrix step
+ *    4 j + e of a 16-pixel step multiplies column (q k/4 + 4 j + e) of the filters with the same element of the pixel rows (one 16-byte LDS
+ *    read of a pixel's row feeds four matrix steps).  tests/test_stream_pack.py.                                                        */
+int dc_stream1x1f_pack(const float* g, int cout, int k, float* out);
 
 /* ---- pyramid-grouped execution: several executors of ONE model, each at its own input shape, as ONE launch sequence ----
  * Replaces the scale loop of the demo (python/pose/estimate_pose.py:81-128: one net.forward() per scale, every shape change a

@@ -126,3 +126,32 @@ def test_the_autotuner_times_the_form_and_set_tile_takes_its_name(gpu_caffe, mon
     sig = rep[0]["signature"]
     net.set_tile(sig, "ws1x1f")
     assert "ws1x1f" in net.plan_text()
+
+
+def test_a_group_merges_members_on_the_form_as_the_direct_layer(gpu_caffe, synth152, monkeypatch):
+    """NetGroup (float32): members whose own plans run the expansions on ws1x1f still merge them into multi-problem gather-GEMM launches
+    (the form has no multi-problem kernel) — the same number of merged launches as with the form off, results within the float32 bound
+    of the members' own forwards."""
+    from deepcut_tools import deepercut_prototxt
+
+    path, _ = synth152
+    shapes = [(1, 72, 104), (1, 104, 136)]
+    imgs = [rand_image(70 + i, h, w, n=n) for i, (n, h, w) in enumerate(shapes)]
+    monkeypatch.setenv("DC_AUTOTUNE", "0")
+
+    def run(mode):
+        monkeypatch.setenv("DC_STREAM1X1", mode)
+        n, h, w = shapes[0]
+        net = gpu_caffe.Net(deepercut_prototxt(152, h, w, n), path, gpu_caffe.TEST, from_text=True, hipgraph=1)
+        grp = gpu_caffe.NetGroup.for_shapes(net, shapes, lanes=1)
+        outs = grp.forward_batch(imgs)
+        return outs, sum("conv_gemm_mp<" in ln for ln in grp.plan_text().splitlines()), net.plan_text()
+
+    on, merged_on, member_plan = run("1")
+    assert "ws1x1f" in member_plan
+    off, merged_off, member_plan_off = run("0")
+    assert "ws1x1f" not in member_plan_off
+    assert merged_on == merged_off and merged_on > 100, (merged_on, merged_off)
+    for a, b in zip(on, off):
+        for k in ("prob", "loc_pred", "next_pred"):
+            assert float(np.abs(a[k] - b[k]).max()) <= 1e-3 * max(1.0, float(np.abs(b[k]).max())), k

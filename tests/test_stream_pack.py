@@ -1,4 +1,4 @@
-"""CPU: the host half of the two float16 kernels of round 6 — the filter images the lowering packs for the streaming 1x1 form
+"""CPU: the host half of the streaming kernels of round 6 (the two float16 ones, and the float32 form of the 1x1 stream at the end) — the filter images the lowering packs for the streaming 1x1 form
 (csrc/stream1x1.hip) and the stem kernel (csrc/stem_f16.hip) — against first principles in NumPy: the operand layout of
 v_mfma_f32_32x32x16_f16 (row operand: lane l supplies row l % 32, K elements 8 (l / 32) .. + 7; column operand alike) emulated on the
 images reproduces the reference's convolutions (1x1: one GEMM per image, base_conv_layer.cpp:326-341; the 7x7 / 2 stem: im2col + GEMM,
@@ -34,6 +34,38 @@ def test_stream1x1_image_is_the_row_operand_of_the_matrix_instruction(cout, k):
             b_lanes = np.stack([x[lane % 32, kk * 16 + 8 * (lane // 32):kk * 16 + 8 * (lane // 32) + 8] for lane in range(64)])
             d += _mfma(img[f, kk], b_lanes)
         assert np.allclose(d, want[f * 32:(f + 1) * 32], rtol=0, atol=1e-5 * np.abs(want).max())
+
+
+def _mfma16(a_lanes, b_lanes):
+    """one v_mfma_f32_16x16x4_f32 step: lane 16 q + r holds A[r, q] (row operand) and B[q, r] (column operand); D = A B [16, 16]"""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
+    for lane in range(64):
+        A[lane % 16, lane // 16] = a_lanes[lane]
+        B[lane // 16, lane % 16] = b_lanes[lane]
+    return A @ B
+
+
+@pytest.mark.parametrize("cout,k", [(64, 256), (32, 512), (48, 64)])
+def test_stream1x1f_image_is_the_row_operand_of_the_float32_matrix_instruction(cout, k):
+    """The float32 form (csrc/stream1x1_f32.hip): the K range in four runs, lane 16 q + c on run q; a lane's 16-byte read of its pixel's row
+    at run q, vector j feeds the four matrix steps of filter vector j."""
+    rs = np.random.RandomState(cout + k)
+    g = rs.randn(cout, k).astype(np.float32)
+    img = caffe.stream1x1f_pack(g)
+    assert img.shape == (cout // 16, k // 16, 64, 4)
+    assert sorted(img.ravel().tolist()) == sorted(g.ravel().tolist())  # a permutation of the filters
+    x = rs.randn(16, k).astype(np.float32)  # 16 pixels
+    want = g.astype(np.float64) @ x.astype(np.float64).T  # [cout, pixel]
+    for f in range(cout // 16):
+        d = np.zeros((16, 16))
+        for j in range(k // 16):
+            xv = np.stack([x[lane % 16, (lane // 16) * (k // 4) + 4 * j:(lane // 16) * (k // 4) + 4 * j + 4] for lane in range(64)])  # the LDS read
+            for e in range(4):
+                d += _mfma16(img[f, j, :, e], xv[:, e])
+        assert np.allclose(d, want[f * 16:(f + 1) * 16], rtol=0, atol=1e-5 * np.abs(want).max())
+    with pytest.raises(caffe.DeepcutError):
+        caffe.stream1x1f_pack(np.zeros((24, 64), np.float32))
 
 
 @pytest.mark.parametrize("c", [3, 4, 1])
