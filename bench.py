@@ -757,7 +757,7 @@ def main():
                                       "tflops": total_images * flops_img / lat_dt / 1e12},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_gemm + wino_f23 / wino_h23 (%s gather-GEMM, all tile variants; Winograd F(2x2,3x3) where it is faster)" % (
+                "kernel": "conv_gemm + wino_f23 / wino_h23 + ws1x1f / ws1x1 / stem7x7 (%s gather-GEMM, all tile variants; Winograd F(2x2,3x3) and the streaming 1x1 forms where they are faster)" % (
                     "f16 v_mfma_f32_32x32x16_f16, fp32 accumulate" if args.dtype == "f16" else "fp32 v_mfma_f32_32x32x2_f32"),
                 "achieved": achieved,
                 "peak": PEAK_FP16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_FP32_MFMA_TFLOPS,
