@@ -96,17 +96,22 @@ struct ReqCount {
   static_assert(resid(kSteady) <= 63 && stage(kSteady) >= 0 && pro >= 0, "vmcnt is a 6-bit counter");
 };
 
-// K = input channels (256 or 512: a pixel's row is a whole number of 1 KiB requests), D = ring stages
+// K = input channels (64, 128, 256 or 512), D = ring stages.  A stage is 16 pixel rows as 1 KiB requests: PPR requests per row at K >= 256,
+// RPR = 2 / 4 rows per request at K = 128 / 64.  A request's 1 KiB is contiguous in LDS, so the 16 bytes of padding follow a BLOCK of RPR rows;
+// inside a block row r keeps its 16-byte chunks rotated by r runs (chunk c of row r at position (c + r K/16) mod (K/4): the request's lane l
+// simply fetches the chunk that belongs at position l), which puts the 16 lanes of a read — 16 rows, one chunk index — into 16 different
+// bank groups again and leaves the read offsets immediates (a lane's run starts at ((q + r) mod 4) K bytes of its row instead of q K).
 template <int K, int D, bool RES, bool RELU>
 __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
-  constexpr int ROWB = K * 4 + 16;   // bytes of a pixel's row in LDS (padded: lanes p = 0..15 of a read land in 16 different bank groups)
-  constexpr int STG = 16 * ROWB;     // a stage: 16 pixels
-  constexpr int PPR = K * 4 / 1024;  // 1 KiB requests per pixel row
-  constexpr int NA = 16 * PPR / 4;   // ... per wave and stage
+  constexpr int RPR = K * 4 >= 1024 ? 1 : 1024 / (K * 4);  // pixel rows per 1 KiB request
+  constexpr int PPR = K * 4 >= 1024 ? K * 4 / 1024 : 1;    // 1 KiB requests per pixel row
+  constexpr int BLKB = (K * 4 >= 1024 ? K * 4 : 1024) + 16;  // bytes between padded blocks in LDS: a row (K >= 256: lanes p = 0..15 of a read land in 16 different bank groups) or RPR rows
+  constexpr int STG = 16 / RPR * BLKB;  // a stage: 16 pixels
+  constexpr int NA = 16 * PPR / RPR / 4;  // requests per wave and stage
   constexpr int NJ = K / 16;         // 16-byte reads (= 4 matrix steps each) per wave and step
   constexpr int NR = RES ? 1 : 0, NS = 1;
-  static_assert(K % 256 == 0 && D >= 3 && D <= 4, "row = whole requests; the ring");
+  static_assert((K == 64 || K == 128 || K % 256 == 0) && D >= 3 && D <= 4 && NA >= 1, "rows and requests divide each other; the ring");
   using Rq = ReqCount<D, NA, NR, NS>;
   constexpr int LDSB = D * STG + 4 * 2 * 1024;
   static_assert(LDSB <= 160 * 1024, "LDS of a CU");
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
 
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const i32x4 xr = f_rsrc_words(a.x), rr = f_rsrc_words(RES ? a.resid : a.y), yr = f_rsrc_words(a.y);
-  const unsigned frag0 = (unsigned)(p16 * ROWB + q * K);                  // this lane's run of the pixel's row: + 16 j
+  const unsigned frag0 = (unsigned)(p16 / RPR * BLKB + p16 % RPR * K * 4 + ((q + p16 % RPR) & 3) * K);  // this lane's run of the pixel's row: + 16 j
   const unsigned obuf0 = (unsigned)(D * STG + wave * 2 * 1024);           // this wave's two 1 KiB tiles
   const unsigned ovec = (unsigned)((4 * p16 + q) * 16);                   // MFMA view: pixel p16, channels 4 q .. + 3
   const int orow = lane >> 2;                                             // memory view: pixel lane / 4, channels 4 (lane % 4) .. + 3
@@ -151,9 +156,17 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
   auto dma_req = [&](int gs, int slot, int i) {  // request i of the wave's NA for stage gs (issued whatever gs is: beyond the range it moves nothing)
     const int row0 = gs * 16;
     const int lim = gs < gs1 ? a.M - row0 : 0;
-    const int pc = wave + 4 * i, row = pc / PPR, part = pc - row * PPR;  // request pc of the stage: part `part` of row `row`
-    const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(part * 1024 + lane * 16) : kOOBf;
-    f_dma16(xr, lds0 + (unsigned)(slot * STG + row * ROWB + part * 1024), vo);
+    const int pc = wave + 4 * i;  // request pc of the stage
+    if (RPR == 1) {               // part `part` of row `row`
+      const int row = pc / PPR, part = pc - row * PPR;
+      const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(part * 1024 + lane * 16) : kOOBf;
+      f_dma16(xr, lds0 + (unsigned)(slot * STG + row * BLKB + part * 1024), vo);
+    } else {                      // rows pc RPR .. + RPR - 1, K / 4 lanes each
+      constexpr int LPR = 64 / RPR;  // lanes = 16-byte chunks per row
+      const int r = lane / LPR, row = pc * RPR + r;
+      const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(((lane - r * (LPR / 4)) & (LPR - 1)) * 16) : kOOBf;
+      f_dma16(xr, lds0 + (unsigned)(slot * STG + pc * BLKB), vo);
+    }
   };
   auto resid_step = [&](int gs, int buf) {  // NR requests, always
     if (!RES) return;
@@ -217,7 +230,10 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
     constexpr int KS = decltype(k_tag)::value;  // the step's number while the request counts still change (Rq), -1 in the steady state
     constexpr int KQ = KS < 0 ? Rq::kSteady : KS;
     constexpr bool EPI = KS != 0;               // step 0 has no step before it
-    constexpr int HB = 1, H1 = HB + NA + 1, H2 = H1 + 2, H3 = H2 + 2, H4 = H3 + 2;
+    // where the pieces sit among the step's NJ product groups (K = 64 has four: barrier behind the first, request + shortcut read in the
+    // second, epilogue arithmetic + tile turn in the third, store + next shortcut request in the fourth)
+    constexpr int SP = NJ >= 16 ? 2 : 1;
+    constexpr int HB = NJ == 4 ? 0 : 1, H1 = NJ == 4 ? HB + NA : HB + NA + 1, H2 = H1 + SP, H3 = NJ == 4 ? H2 : H2 + SP, H4 = H3 + SP;
     static_assert(H4 < NJ && HB < NJ - PD + 1, "the pieces inside the product loop; stage k+1 is read only behind its barrier");
     f32x4 sum = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
     u32x4 ov = {0u, 0u, 0u, 0u};
@@ -289,7 +305,7 @@ struct WsfForm {
 };
 #define DC_WSF_FORM(K_, D_) \
   {K_, {{ws1x1f_kernel<K_, D_, false, false>, ws1x1f_kernel<K_, D_, false, true>}, {ws1x1f_kernel<K_, D_, true, false>, ws1x1f_kernel<K_, D_, true, true>}}}
-const WsfForm kFormsF[] = {DC_WSF_FORM(256, 4), DC_WSF_FORM(512, 3)};
+const WsfForm kFormsF[] = {DC_WSF_FORM(64, 4), DC_WSF_FORM(128, 4), DC_WSF_FORM(256, 4), DC_WSF_FORM(512, 3)};
 const WsfForm* formf_of(int K) {
   for (const WsfForm& f : kFormsF)
     if (f.K == K) return &f;
@@ -306,10 +322,14 @@ void f_magic(unsigned dv, unsigned (&mg)[2]) {
   const unsigned long long qq = (unsigned long long)((((unsigned __int128)1) << sh) / dv);
   mg[0] = (unsigned)(qq + 1), mg[1] = (unsigned)(sh - 32);
 }
-long wsf_plan(WsfArgs& a) {
+long wsf_plan(WsfArgs& a, int klen) {
   a.tn = a.Cout / 64;
   a.S = (a.M + 15) / 16;
-  static const int slots = getenv("DC_WSF_SLOTS") ? std::max(8, atoi(getenv("DC_WSF_SLOTS"))) : 256;  // one workgroup per CU
+  // one workgroup per CU; two at K = 128, where a step is 1 024 cycles of products behind the same requests and barrier (conv3_x expansion at
+  // batch 1: 13.1 us with 256 workgroups, 12.1 with 512 or 768, 13.8 with 1 024; conv4_x, K = 256: 11.4 / 11.2 / 12.1 — and 2 048 waves start
+  // 0.7 us later than 1 024 inside a forward)
+  static const int slots_env = getenv("DC_WSF_SLOTS") ? std::max(8, atoi(getenv("DC_WSF_SLOTS"))) : 0;
+  const int slots = slots_env ? slots_env : klen <= 128 ? 512 : 256;
   long J = std::min<long>(a.S, std::max(1, slots / a.tn));
   if (J >= 8) J -= J % 8;
   a.J = (int)J;
@@ -334,7 +354,7 @@ bool stream1x1f_eligible(const ConvGemmParams& p) {
 long stream1x1f_grid(const ConvGemmParams& p) {
   WsfArgs a{};
   a.Cout = p.Cout, a.M = p.M;
-  return wsf_plan(a);
+  return wsf_plan(a, p.klen);
 }
 
 size_t stream1x1f_packed_elems(int Cout, int K) { return (size_t)Cout * K; }
@@ -358,7 +378,7 @@ int launch_stream1x1f(const ConvGemmParams& p, void* stream) {
   WsfArgs a{};
   a.x = p.x, a.w = p.w, a.scale = p.scale, a.shift = p.shift, a.y = p.y, a.resid = p.resid;
   a.M = p.M, a.Cout = p.Cout, a.sxb = p.sx * 4, a.ypb = p.y_pix_stride * 4, a.dbg = p.dbg;
-  const long grid = wsf_plan(a);
+  const long grid = wsf_plan(a, p.klen);
   if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(f->k[p.resid ? 1 : 0][p.relu ? 1 : 0], dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();

@@ -3,7 +3,7 @@ by default it is used only where the per-shape timing finds it faster.  Against 
 layers: one SGEMM per image, base_conv_layer.cpp:326-341, + BatchNorm / Scale / Eltwise / ReLU) at 2e-5 x range — the float32 path's
 stated bound for whole nets is 1e-3; a single layer of K <= 512 products differs by summation order only — and against a gather-GEMM tile on
 the same layer (not bit for bit: four interleaved K runs and two accumulators are another grouping of the same sums).
-Covers both K the kernel takes (256, 512), ragged pixel counts (M % 16 != 0, M < 16, a single pixel), walks of 0 / 1 / 2 / 3 / many steps per
+Covers every K the kernel takes (64, 128, 256, 512), ragged pixel counts (M % 16 != 0, M < 16, a single pixel), walks of 0 / 1 / 2 / 3 / many steps per
 workgroup (the peeled first steps, the steady loop), batches, shortcut + ReLU and plain epilogues, layers without BatchNorm / Scale, the
 shapes the form does not take, and the reference's own expansion layers inside the full net (ResNet-152.prototxt res4*_branch2c, res5*_branch2c)."""
 import os
@@ -39,6 +39,18 @@ CASES = [  # n, cin, cout, h, w, shortcut, relu, affine
     (1, 256, 1024, 25, 31, True, True, True),    # 775 pixels = 49 steps: 3-4 (all peeled steps, D = 4)
     (2, 256, 1024, 67, 70, True, False, True),   # 9380 pixels = 587 steps: 36-37 per range, the steady loop
     (2, 512, 1024, 40, 33, True, True, True),    # K = 512 (D = 3) in the steady loop: 165 steps over 16 ranges
+    # K = 128: two pixel rows per 1 KiB request (res3x_branch2c)
+    (1, 128, 512, 68, 92, True, True, True),     # res3x_branch2c at 544x736: 6256 pixels = 391 steps over 32 ranges, 12-13 each
+    (2, 128, 512, 33, 19, True, True, True),     # 1254 pixels (ragged: 78.4 steps), batch 2
+    (1, 128, 64, 5, 7, False, False, True),      # 35 pixels: 3 steps (the last one 3 rows: half a request), one slice, plain epilogue
+    (1, 128, 256, 1, 1, True, True, False),      # a single pixel, no affine
+    (3, 128, 128, 9, 11, False, True, True),     # 297 pixels = 19 steps over 19 ranges, batch 3
+    # K = 64: four pixel rows per request, four product groups per step (res2x_branch2c, res2a_branch1, res2a_branch2a)
+    (1, 64, 256, 136, 184, True, True, True),    # res2x_branch2c at 544x736: 25024 pixels = 1564 steps over 128 ranges
+    (2, 64, 256, 40, 56, False, False, True),    # res2a_branch1: no shortcut, no ReLU
+    (1, 64, 64, 7, 9, False, True, True),        # res2a_branch2a's channels; 63 pixels: the last step 15 rows
+    (1, 64, 128, 3, 2, True, True, False),       # 6 pixels: one step of two requests' worth, no affine
+    (3, 64, 256, 21, 23, True, False, True),     # 1449 pixels = 90.6 steps, batch 3, shortcut without ReLU
 ]
 
 
@@ -76,7 +88,7 @@ def test_single_layers_match_the_oracle_and_the_tiles(gpu_caffe, case, monkeypat
 
 
 def test_layers_the_form_does_not_take_keep_their_tiles(gpu_caffe, monkeypatch):
-    """K other than 256 / 512, stride 2, 3x3, a channel count that is not a whole 64-slice: lowered as before even when the form is forced."""
+    """K other than 64 / 128 / 256 / 512, stride 2, 3x3, a channel count that is not a whole 64-slice: lowered as before even when the form is forced."""
     monkeypatch.setenv("DC_STREAM1X1", "1")
     monkeypatch.setenv("DC_AUTOTUNE", "0")
 
@@ -86,10 +98,12 @@ def test_layers_the_form_does_not_take_keep_their_tiles(gpu_caffe, monkeypatch):
         return gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True).plan_text()
 
     for cin, conv in ((256, "num_output: 256 kernel_size: 1 stride: 2"), (256, "num_output: 256 kernel_size: 3 pad: 1"), (256, "num_output: 96 kernel_size: 1"),
-                      (128, "num_output: 512 kernel_size: 1"), (1024, "num_output: 256 kernel_size: 1")):
+                      (32, "num_output: 256 kernel_size: 1"), (192, "num_output: 256 kernel_size: 1"), (1024, "num_output: 256 kernel_size: 1")):
         assert "ws1x1f" not in plan(cin, conv), (cin, conv)
     assert "ws1x1f" in plan(256, "num_output: 256 kernel_size: 1")
     assert "ws1x1f" in plan(512, "num_output: 128 kernel_size: 1")
+    assert "ws1x1f" in plan(128, "num_output: 512 kernel_size: 1")
+    assert "ws1x1f" in plan(64, "num_output: 256 kernel_size: 1")
 
 
 @pytest.mark.parametrize("hw,n", [((104, 136), 2), ((240, 320), 1)])
@@ -105,10 +119,10 @@ def test_full_net_with_every_eligible_layer_on_the_form(gpu_caffe, synth152, hw,
     img = rand_image(11, h, w, n=n)
     net.blobs["data"].data[...] = img
     net.forward()
-    # the 36 + 3 branch2c expansions of conv4_x / conv5_x (K = 256 / 512), res5b / res5c_branch2a (2048 -> 512 is K = 2048: not taken),
-    # res3a_branch2a.. are K = 256 -> 128 at stride 2 (not taken), res4a_branch2a K = 512 stride 2 (not taken)
+    # the 3 + 8 + 36 + 3 branch2c expansions (K = 64 / 128 / 256 / 512), res2a_branch1 / _branch2a and the K = 256 / 512 reductions at stride 1
+    # (res5b / res5c_branch2a are K = 2048, conv4_x's K = 1024, the first reduction of a later stage has stride 2: not taken)
     took = [ln for ln in net.plan_text().splitlines() if "ws1x1f" in ln]
-    assert len(took) >= 39, len(took)
+    assert len(took) >= 52, len(took)
     ref = _oracle(proto, layers, data=img)
     assert float(np.abs(net.blobs["prob"].data - ref["prob"]).max()) <= 1e-3
     for k in ("loc_pred", "next_pred"):

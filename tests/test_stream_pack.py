@@ -46,7 +46,7 @@ def _mfma16(a_lanes, b_lanes):
     return A @ B
 
 
-@pytest.mark.parametrize("cout,k", [(64, 256), (32, 512), (48, 64)])
+@pytest.mark.parametrize("cout,k", [(64, 256), (32, 512), (64, 128), (48, 64)])
 def test_stream1x1f_image_is_the_row_operand_of_the_float32_matrix_instruction(cout, k):
     """The float32 form (csrc/stream1x1_f32.hip): the K range in four runs, lane 16 q + c on run q; a lane's 16-byte read of its pixel's row
     at run q, vector j feeds the four matrix steps of filter vector j."""

@@ -47,7 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--shapes", default="res4c,res3c,res2c,res5c,res2a1")
-    ap.add_argument("--dtype", default="f16", choices=("f16", "f32"), help="f32: the float32 form (csrc/stream1x1_f32.hip, 'ws1x1f': K = 256 / 512 only, not bit-identical to the tiles)")
+    ap.add_argument("--dtype", default="f16", choices=("f16", "f32"), help="f32: the float32 form (csrc/stream1x1_f32.hip, 'ws1x1f': K = 64 / 128 / 256 / 512, not bit-identical to the tiles)")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--stamps", action="store_true", help="only the forced streaming launch of every shape, graph off (run with DC_DEBUG_TIMING=0)")
     a = ap.parse_args()
