@@ -191,7 +191,7 @@ long stream1x1_grid(const ConvGemmParams& p);
 size_t stream1x1_packed_elems(int Cout, int K);
 void stream1x1_pack_filters(const float* g, int Cout, int K, float* out);
 int launch_stream1x1(const ConvGemmParams& p, void* stream);
-// ---- the float32 form (stream1x1_f32.hip): 16-pixel steps of v_mfma_f32_16x16x4_f32, one workgroup per CU; K = 256 or 512, Cout % 64 == 0
+// ---- the float32 form (stream1x1_f32.hip): 16-pixel steps of v_mfma_f32_16x16x4_f32, one workgroup per CU (two at K <= 128); K = 64, 128, 256 or 512, Cout % 64 == 0
 bool stream1x1f_eligible(const ConvGemmParams& p);
 long stream1x1f_grid(const ConvGemmParams& p);
 size_t stream1x1f_packed_elems(int Cout, int K);

@@ -719,7 +719,7 @@ void Net::build_plan() {
         if (stream_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStreamHalf);
       }
       if (!rowtap && !l.wino_w && stream_mode != 0 && op.wls.empty() && dtype == 0 && g.klen == C && g.Ktot == C && stream1x1f_eligible(g)) {
-        // float32 dense 1x1 layers with 256 / 512 input channels (stream1x1_f32.hip): the filters in the order of its 16x16x4 matrix steps
+        // float32 dense 1x1 layers with 64 / 128 / 256 / 512 input channels (stream1x1_f32.hip): the filters in the order of its 16x16x4 matrix steps
         l.wino_w = get_vec(dkey + "wsf:" + std::to_string(op.wl), [&](std::vector<float>& h) {
           h.assign(stream1x1f_packed_elems(OC, C), 0.f);
           stream1x1f_pack_filters(L.params[0]->st->host_ptr(), OC, C, h.data());

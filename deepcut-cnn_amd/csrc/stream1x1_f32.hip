@@ -1,6 +1,6 @@
-// stream1x1_f32.hip — the float32 form of stream1x1.hip ("ws1x1f"): the dense 1x1 expansions of a bottleneck block (+ shortcut + ReLU,
-// resNx_branch2c of ResNet-152.prototxt; reference: one SGEMM per image, base_conv_layer.cpp:326-341) with the filters resident in registers
-// and the pixels walked in 16-pixel steps.
+// stream1x1_f32.hip — the float32 form of stream1x1.hip ("ws1x1f"): the dense 1x1 layers with 64 / 128 / 256 / 512 input channels — above all
+// the expansions of a bottleneck block (+ shortcut + ReLU, resNx_branch2c of ResNet-152.prototxt; reference: one SGEMM per image,
+// base_conv_layer.cpp:326-341) — with the filters resident in registers and the pixels walked in 16-pixel steps.
 //
 // Why, in float32, where these layers are MFMA-bound and not byte-bound: at batch 1 (BASELINE configs[1], the headline) a conv4_x layer has
 // M = 34 x 46 = 1 564 pixels = 4 x 17 x 23, and every tiling of it into 32-row MFMA fragments leaves 56-60 of the 256 CUs without a

@@ -116,7 +116,8 @@ def test_layers_the_form_does_not_take_keep_their_tiles(gpu_caffe, monkeypatch):
         proto = "\n".join(base + ['layer { name: "c" type: "Convolution" bottom: "data" top: "c" convolution_param { %s bias_term: false } }' % conv]) + "\n"
         assert "ws1x1" not in gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True, dtype="f16").plan_text(), conv
     proto = "\n".join(base + ['layer { name: "c" type: "Convolution" bottom: "data" top: "c" convolution_param { num_output: 256 kernel_size: 1 bias_term: false } }']) + "\n"
-    assert "ws1x1" not in gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True).plan_text()  # float32
+    f32_plan = gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True).plan_text()  # float32: never this kernel (its own form is ws1x1f, round 6)
+    assert "ws1x1<" not in f32_plan and "ws1x1f<" in f32_plan
     assert "ws1x1" in gpu_caffe.Net(proto, gpu_caffe.TEST, from_text=True, dtype="f16").plan_text()
 
 
