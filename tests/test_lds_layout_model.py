@@ -44,3 +44,27 @@ def test_the_lds_dma_swizzles_are_conflict_free_in_the_model_too():
         assert M.ds_read_b128_cycles(addr) == 4, q
     # without the swizzle a 128-byte-pitch stage collides: 32 rows on 2 distinct bank offsets
     assert M.ds_read_b128_cycles([((lane & 31) * 128 + (lane >> 5) * 16) // 4 for lane in range(64)]) > 4
+
+
+def _ws1x1f_read(K, j):
+    """Float index per lane of ws1x1f's operand read j (csrc/stream1x1_f32.hip, frag0 + 16 j): lane = 16 q + p reads run q of pixel p's row;
+    RPR rows share a 1 KiB (+ 16 bytes) block, row r of a block keeps its chunks rotated by r runs."""
+    rpr = 1 if K >= 256 else 256 // K
+    blk = (max(K * 4, 1024) + 16) // 4  # floats between padded blocks
+    return [(p // rpr) * blk + (p % rpr) * K + ((q + p % rpr) & 3) * (K // 4) + 4 * j for q in range(4) for p in range(16)]
+
+
+def test_the_float32_stream_reads_its_pixel_rows_without_conflicts_for_every_k():
+    for K in (64, 128, 256, 512):
+        for j in range(K // 16):
+            assert M.ds_read_b128_cycles(_ws1x1f_read(K, j)) == 4, (K, j)
+    # what the rotation inside a block is for: without it two (K = 128) / four (K = 64) lanes of a group share a bank
+    for K, want in ((128, 8), (64, 16)):
+        rpr, blk = 256 // K, (1024 + 16) // 4
+        plain = [(p // rpr) * blk + (p % rpr) * K + q * (K // 4) for q in range(4) for p in range(16)]
+        assert M.ds_read_b128_cycles(plain) == want
+    # the epilogue's 16 x 16 tile in the matrix view (lane (p, q) at 16-byte slot 4 p + q: one write and one shortcut read per step) is two-way
+    # conflicted in the model, the memory view of the same tile (slot = lane) is not: part of what SQ_LDS_BANK_CONFLICT reads for the kernel
+    # (profiles/r06_pmc_lds_conflicts_f32.txt: 28.6 % of its LDS cycles — a few dozen cycles of a step beside 512-4 096 cycles of products)
+    assert M.ds_read_b128_cycles([(4 * p + q) * 4 for q in range(4) for p in range(16)]) == 8
+    assert M.ds_read_b128_cycles([lane * 4 for lane in range(64)]) == 4

@@ -18,7 +18,7 @@ def main(db):
     rows = c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
     agg = {}
     for k, n, v, cnt in rows:
-        a = agg.setdefault(kernel_names.label(k) if ("conv_gemm" in k or "wino" in k) else k[:90], {})
+        a = agg.setdefault(kernel_names.label(k) if ("conv_gemm" in k or "wino" in k or "ws1x1" in k or "stem7x7" in k) else k[:90], {})
         a[n] = a.get(n, 0.0) + v
         a["_n"] = max(a.get("_n", 0), cnt)
     print("%-86s %10s %16s %16s %8s" % ("kernel", "dispatches", "LDS_IDX_ACTIVE", "BANK_CONFLICT", "share"))
