@@ -10,16 +10,21 @@
 // slices x 16 pixel ranges at N = 1024 — and a workgroup walks 6 or 7 of the 98 steps of its range: 7 / 6.125 = 87.5 % of the chip's matrix
 // cycles are used where 196 / 256 = 76.6 % were, the filters (64 KB per workgroup) are fetched once, and there is no split-K exchange.
 //
-// Per workgroup (4 waves = 4 x 16 channels; a wave alone on its SIMD):
+// Per workgroup (4 waves = 4 x 16 channels; a wave alone on its SIMD at K >= 256, two workgroups per CU at K <= 128):
 //  * filters: registers, ROW operand (rows = 16 channels), K/4 of them per lane.  Lane (c, q) of the 16x16x4 instruction supplies
 //    A[c][q] and B[q][p]: with the K range cut into four runs of K/4 — lane q takes run q, matrix step m is element m of every run — one
 //    ds_read_b128 of the pixel's row feeds four matrix steps and the filters load as 16-byte vectors (stream1x1f_pack_filters);
-//  * pixels: LDS-DMA ring of D stages of 16 rows (one 1 KiB request = one pixel's K floats, rows padded by 16 bytes: conflict-free reads
-//    without a swizzle, so the 16 read offsets of a step are immediates), D-1 steps ahead, counted vmcnt, one barrier per step;
+//  * pixels: LDS-DMA ring of D stages of 16 rows in 1 KiB requests (a pixel's row at K = 256; several rows at K = 128 / 64: see the
+//    kernel), padded by 16 bytes per row or row block: conflict-free reads whose 16 offsets per step are immediates; counted vmcnt;
+//  * ONE stream of matrix instructions from the first step's first product to the last step's last: a step's barrier (stage k+1 published,
+//    the slot of step k-1 free), the ring's requests and the PREVIOUS step's epilogue sit between its products, the operand reads run
+//    three reads ahead across the step boundary;
 //  * two accumulators taken in turn (a matrix step does not wait for the one before it), added at the end;
 //  * shortcut and output tiles (16 pixels x 16 channels = 1 KiB) through a wave-private LDS buffer as whole 64-byte runs, the epilogue's
 //    affine / add / ReLU in fp32 in between.
-// Not bit-identical to the gather-GEMM tiles (another summation grouping); same 1e-3 bound against the oracle, measured ~1e-6.
+// Not bit-identical to the gather-GEMM tiles (another summation grouping); same 1e-3 bound against the oracle, measured ~3e-6.
+// Forms that were built and dropped (eight waves with four moving the bytes, the two waves of a SIMD sharing the products, the early-start
+// prologue) and the timing ablations: profiles/r06_stream1x1f_forms.txt, EXPERIMENTS.md L; measurements: DESIGN.md 4.1h.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
