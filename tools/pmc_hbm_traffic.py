@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM traffic per conv_gemm launch from two rocprofv3 --pmc passes (rocpd sqlite), as MI355X_MICROARCH.md's HBM
+"""HBM traffic per convolution launch (conv_gemm, wino_f23 / wino_h23, ws1x1 / ws1x1f, stem7x7) from two rocprofv3 --pmc passes (rocpd sqlite), as MI355X_MICROARCH.md's HBM
 section prescribes: FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes, both in KB, FETCH_SIZE x2 on gfx950 for
 wide (16 B/lane) coalesced reads, WRITE_SIZE taken as is.
    python tools/pmc_hbm_traffic.py fetch.db write.db "<description>" [minimum bytes per forward] > profiles/<name>.json
@@ -11,7 +11,7 @@ import sys
 
 def per_launch(path, counter):
     c = sqlite3.connect(path)
-    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and (kernel_name like '%conv_gemm%' or kernel_name like '%wino__23%')",
+    v, n = c.execute("select sum(value), count(*) from counters_collection where counter_name = ? and (kernel_name like '%conv_gemm%' or kernel_name like '%wino__23%' or kernel_name like '%ws1x1%' or kernel_name like '%stem7x7%')",
                      (counter,)).fetchone()
     return v / n, n
 
