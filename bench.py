@@ -707,7 +707,7 @@ def main():
     if rank == 0:
         total_images = args.steps * B * world
         launches = net.num_launches()
-        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln or "wino_h23<" in ln or "ws1x1<" in ln or "ws1x1f<" in ln or "stem7x7<" in ln)
+        conv_launches = sum(1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln or "wino_h23<" in ln or "ws1x1<" in ln or "ws1x1f<" in ln or "ws7x7f<" in ln or "stem7x7<" in ln)
         # roofline of the dominant kernel family (conv_gemm: every convolution/deconvolution launch):
         # algorithmic FLOPs per launch / average launch duration over the ONE-FORWARD-AT-A-TIME timed
         # region (launches do not overlap there, so the duration is the kernel's own and agrees with

@@ -164,7 +164,8 @@ constexpr int kStreamHalf = 1003;              // NOT Winograd: the float16 stre
                                                // image of its own (Launch::wino_w), timed against the tiles per shape
 constexpr int kStemHalf = 1004;                // NOT Winograd either: the float16 7x7 / stride-2 stem as a kernel of its own (stem_f16.hip, "stem7x7")
 constexpr int kStreamFloat = 1005;             // ... and the float32 form of the streaming 1x1 kernel (stream1x1_f32.hip, "ws1x1f")
-inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf || v == kStreamHalf || v == kStemHalf || v == kStreamFloat; }
+constexpr int kStemFloat = 1006;               // ... and the float32 7x7 / stride-2 stem on that kernel's skeleton (stream1x1_f32.hip, "ws7x7f")
+inline bool is_wino_variant(int v) { return v == kWinoVariant || v == kWinoVariant16 || v == kWinoHalf || v == kStreamHalf || v == kStemHalf || v == kStreamFloat || v == kStemFloat; }
 inline int wino_variant_esize(int v) { return v == kWinoHalf || v == kStreamHalf || v == kStemHalf ? 2 : 4; }  // element size of the nets the form serves
 const char* wino_variant_name(int variant);    // the tile name of tune caches / reports / set_tile
 const char* wino_kernel_label(int variant);    // the kernel column of plan texts
@@ -197,6 +198,13 @@ long stream1x1f_grid(const ConvGemmParams& p);
 size_t stream1x1f_packed_elems(int Cout, int K);
 void stream1x1f_pack_filters(const float* g, int Cout, int K, float* out);
 int launch_stream1x1f(const ConvGemmParams& p, void* stream);
+// ---- the float32 stem on the same skeleton ("ws7x7f"): conv1 7x7 / 2 over the NHWC4 image as the lowering's 7-row-tap launch describes it; a
+// 1 KiB request gathers an output pixel's 7 x 8 input pixels (K = 256: 224 of the row-tap image + zeros); `w` from stem_ws_pack_filters()
+bool stem_ws_eligible(const ConvGemmParams& p);
+long stem_ws_grid(const ConvGemmParams& p);
+size_t stem_ws_packed_elems();
+void stem_ws_pack_filters(const float* rowtap, float* out);  // rowtap: [64][224] = the row-tap image (k = ky 32 + kx 4 + ci)
+int launch_stem_ws(const ConvGemmParams& p, void* stream);
 // ---- the float16 stem (stem_f16.hip): conv1 7x7 / 2 over the NHWC4 image, as the lowering's 7-row-tap launch describes it (4 or 8 channels
 // per pixel, at most 4 of them real); `w` is the image made by stem7x7_pack_filters(), uploaded as _Float16
 bool stem7x7_eligible(const ConvGemmParams& p);

@@ -1788,6 +1788,7 @@ long wino_grid(const ConvGemmParams& p) {
   if (p.esize == 2 && p.nty == 1 && p.ntx == 1) return stream1x1_grid(p);  // (a 1x1 layer on a form of its own: the streaming one)
   if (p.esize == 4 && p.nty == 1 && p.ntx == 1) return stream1x1f_grid(p);
   if (p.esize == 2 && p.nty == 7 && p.ntx == 1) return stem7x7_grid(p);    // (the stem)
+  if (p.esize == 4 && p.nty == 7 && p.ntx == 1) return stem_ws_grid(p);
   if (p.esize == 2) return wino_half_grid(p);
   const int d = p.ddy;
   const int TY = ((p.OH + d - 1) / d + 1) / 2, TX = ((p.OW + d - 1) / d + 1) / 2;
@@ -1815,13 +1816,13 @@ void wino_pack_filters(const float* g, int Cout, int Cin, float* out) {
 }
 
 const char* wino_variant_name(int variant) {
-  return variant == kStreamFloat ? "ws1x1f" : variant == kStemHalf ? "stem7x7" : variant == kStreamHalf ? "ws1x1" : variant == kWinoHalf ? "wino_h23" : variant == kWinoVariant16 ? "wino_f23_w16" : "wino_f23";
+  return variant == kStemFloat ? "ws7x7f" : variant == kStreamFloat ? "ws1x1f" : variant == kStemHalf ? "stem7x7" : variant == kStreamHalf ? "ws1x1" : variant == kWinoHalf ? "wino_h23" : variant == kWinoVariant16 ? "wino_f23_w16" : "wino_f23";
 }
 const char* wino_kernel_label(int variant) {
-  return variant == kStreamFloat ? "ws1x1f<16xN>" : variant == kStemHalf ? "stem7x7<8x64>" : variant == kStreamHalf ? "ws1x1<32xN>" : variant == kWinoHalf ? "wino_h23<2x4x8x64>" : variant == kWinoVariant16 ? "wino_f23<4x8x16_w16>" : "wino_f23<4x8x16>";
+  return variant == kStemFloat ? "ws7x7f<16x64>" : variant == kStreamFloat ? "ws1x1f<16xN>" : variant == kStemHalf ? "stem7x7<8x64>" : variant == kStreamHalf ? "ws1x1<32xN>" : variant == kWinoHalf ? "wino_h23<2x4x8x64>" : variant == kWinoVariant16 ? "wino_f23<4x8x16_w16>" : "wino_f23<4x8x16>";
 }
 int wino_variant_by_name(const char* name) {
-  for (int v : {kWinoVariant, kWinoVariant16, kWinoHalf, kStreamHalf, kStemHalf, kStreamFloat})
+  for (int v : {kWinoVariant, kWinoVariant16, kWinoHalf, kStreamHalf, kStemHalf, kStreamFloat, kStemFloat})
     if (name && std::strcmp(name, wino_variant_name(v)) == 0) return v;
   return -1;
 }
@@ -1830,6 +1831,7 @@ int launch_wino_conv(const ConvGemmParams& p, void* stream, int variant) {
   if (variant == kStreamHalf) return launch_stream1x1(p, stream);
   if (variant == kStemHalf) return launch_stem7x7(p, stream);
   if (variant == kStreamFloat) return launch_stream1x1f(p, stream);
+  if (variant == kStemFloat) return launch_stem_ws(p, stream);
   if (variant == kWinoHalf) return launch_wino_half(p, stream);
   if (p.esize != 4 || !wino_eligible(p) || !is_wino_variant(variant)) return (int)hipErrorInvalidValue;
   const long grid = wino_grid(p);

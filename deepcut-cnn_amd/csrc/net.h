@@ -175,7 +175,7 @@ struct Launch {
   // a Winograd form this launch can run as: the image exists and the form serves the net's element type
   bool takes_wino(int v) const {
     return is_wino_variant(v) && (bool)wino_w && wino_variant_esize(v) == cg.esize && cg.ncls <= 1 && (v == kStreamHalf || v == kStreamFloat) == (cg.nty == 1 && cg.ntx == 1) &&
-           (v == kStemHalf) == (cg.nty == 7 && cg.ntx == 1);
+           (v == kStemHalf || v == kStemFloat) == (cg.nty == 7 && cg.ntx == 1);
   }
   long y_off = 0;                      // element offset of this launch's first output (deconvolution classes, channel splits)
   long w_off = 0;                      // element offset of this launch's first filter row inside `w` (channel splits)

@@ -743,6 +743,22 @@ void Net::build_plan() {
         l.wino_w->as_half = true;
         if (stem_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStemHalf);
       }
+      if (rowtap && stem_mode != 0 && op.wls.empty() && dtype == 0 && C <= 4 && stem_ws_eligible(g)) {
+        // float32 stem on the streaming skeleton (stream1x1_f32.hip, "ws7x7f"): the row-tap image's 224 columns + 32 of zeros in the order of
+        // its 16x16x4 matrix steps; scale / shift are the launch's own.  The per-shape timing decides (DC_STEM=1: forced, 0: never)
+        std::shared_ptr<DevVec> direct = l.w;
+        l.wino_w = get_vec(dkey + "stemws:" + std::to_string(op.wl), [&](std::vector<float>& h) {
+          const float* w = L.params[0]->st->host_ptr();  // [64][C][7][7]
+          std::vector<float> rt((size_t)64 * 224, 0.f);  // the row-tap order: k = ky 32 + kx 4 + ci
+          for (int co = 0; co < 64; ++co)
+            for (int ci = 0; ci < C; ++ci)
+              for (int ky = 0; ky < 7; ++ky)
+                for (int kx = 0; kx < 7; ++kx) rt[(size_t)co * 224 + ky * 32 + kx * 4 + ci] = w[(((size_t)co * C + ci) * 7 + ky) * 7 + kx];
+          h.assign(stem_ws_packed_elems(), 0.f);
+          stem_ws_pack_filters(rt.data(), h.data());
+        });
+        if (stem_mode >= 1 && (force_variant < 0 || is_wino_variant(force_variant))) use_wino(l, kStemFloat);
+      }
       if (l.wino_w || rowtap) plan.push_back(std::move(l));
       else push_split(std::move(l), kgcd);
     } else if (op.kind == LOp::DECONV) {

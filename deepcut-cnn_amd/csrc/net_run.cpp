@@ -114,7 +114,7 @@ void Net::run_launch(const Launch& l, void* s) {
       if (dbg_idx >= 0 && my_idx == dbg_idx) {
         // device-side phase timestamps of ONE launch (diagnostics only): per wave the shader cycle counter at up to 8 phase
         // boundaries (slots 0..7) and the chip-wide 100 MHz clock at start / end (slots 8, 9)
-        const int nwv = wino ? (l.variant == kWinoVariant16 ? 16 : l.variant == kStreamHalf || l.variant == kStemHalf || l.variant == kStreamFloat ? 4 : 8) : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
+        const int nwv = wino ? (l.variant == kWinoVariant16 ? 16 : l.variant == kStreamHalf || l.variant == kStemHalf || l.variant == kStreamFloat || l.variant == kStemFloat ? 4 : 8) : conv_variant(l.variant).WR * conv_variant(l.variant).WC * conv_variant(l.variant).WK;
         const long n = (l.grid * 2 + 64) * nwv * 12;  // the XCD-aware maps pad the grid (at most 8 x the longest XCD list)
         long long* d = nullptr;
         dev_alloc((void**)&d, n * sizeof(long long));
@@ -162,7 +162,7 @@ void Net::run_launch(const Launch& l, void* s) {
         std::string line;
         for (int k = 1; k < 8; ++k) {
           char buf[96];
-          std::snprintf(buf, sizeof buf, "%s%s %.0f", k > 1 ? " | " : "", (l.variant == kStreamHalf || l.variant == kStreamFloat ? kStream : wino ? kWino : kGemm)[k - 1], dsum[k] / std::max(cnt, 1L));
+          std::snprintf(buf, sizeof buf, "%s%s %.0f", k > 1 ? " | " : "", (l.variant == kStreamHalf || l.variant == kStreamFloat || l.variant == kStemFloat ? kStream : wino ? kWino : kGemm)[k - 1], dsum[k] / std::max(cnt, 1L));
           line += buf;
         }
         std::fprintf(stderr, "[dc timing] launch %d %s %s\n  mean cycles per wave: %s\n", my_idx, l.kernel.c_str(), l.label.c_str(), line.c_str());

@@ -107,7 +107,7 @@ void Net::autotune() {
       c.push_back({burst_ms(trial), v});
     }
     if (l.wino_w)  // the Winograd forms of this layer (8 and 16 waves per workgroup) compete with the direct tiles
-      for (int wv : {kWinoVariant, kWinoVariant16, kWinoHalf, kStreamHalf, kStemHalf, kStreamFloat}) {
+      for (int wv : {kWinoVariant, kWinoVariant16, kWinoHalf, kStreamHalf, kStemHalf, kStreamFloat, kStemFloat}) {
         if (!l.takes_wino(wv)) continue;
         Launch trial = l;
         trial.variant = wv;
@@ -237,7 +237,7 @@ void Net::autotune() {
     };
     for (auto& kv : timed) {
       auto it = tune_cache_.find(kv.first);
-      if (it == tune_cache_.end() || !is_wino_variant(it->second) || it->second == kWinoHalf || it->second == kStreamHalf || it->second == kStemHalf || it->second == kStreamFloat) continue;
+      if (it == tune_cache_.end() || !is_wino_variant(it->second) || it->second == kWinoHalf || it->second == kStreamHalf || it->second == kStemHalf || it->second == kStreamFloat || it->second == kStemFloat) continue;
       bool both = false;
       for (auto& c : kv.second) both = both || (is_wino_variant(c.second) && c.second != it->second);
       if (!both) continue;

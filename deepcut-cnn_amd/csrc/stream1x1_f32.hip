@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "kernels.h"
 
@@ -55,6 +56,9 @@ struct WsfArgs {
   int tn, J, S, sbase, srem;  // J pixel ranges of sbase steps, the first srem of them one more (those are dispatched first)
   unsigned div_tn[2];
   long long* dbg;
+  // the stem form ("ws7x7f"): output map and image geometry (a 1 KiB request gathers an output pixel's 7 rows x 8 pixels of 4 channels)
+  int OW, OHW, H, W, xrsb, ximgb;  // output width, output pixels per image, image rows / pixels per row, bytes between image rows / images
+  unsigned div_ow[2], div_ohw[2];
 };
 
 __device__ __forceinline__ unsigned f_uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
@@ -106,8 +110,9 @@ struct ReqCount {
 // inside a block row r keeps its 16-byte chunks rotated by r runs (chunk c of row r at position (c + r K/16) mod (K/4): the request's lane l
 // simply fetches the chunk that belongs at position l), which puts the 16 lanes of a read — 16 rows, one chunk index — into 16 different
 // bank groups again and leaves the read offsets immediates (a lane's run starts at ((q + r) mod 4) K bytes of its row instead of q K).
-template <int K, int D, bool RES, bool RELU>
+template <int K, int D, bool RES, bool RELU, bool STEM = false>
 __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
+  static_assert(!STEM || (K == 256 && !RES), "the stem form: 7 x 32 image floats + 32 zeros per output pixel, no shortcut");
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
   constexpr int RPR = K * 4 >= 1024 ? 1 : 1024 / (K * 4);  // pixel rows per 1 KiB request
   constexpr int PPR = K * 4 >= 1024 ? K * 4 / 1024 : 1;    // 1 KiB requests per pixel row
@@ -162,7 +167,15 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
     const int row0 = gs * 16;
     const int lim = gs < gs1 ? a.M - row0 : 0;
     const int pc = wave + 4 * i;  // request pc of the stage
-    if (RPR == 1) {               // part `part` of row `row`
+    if (STEM) {  // output pixel row0 + pc: lane 8 tap + px fetches pixel (2 ox - 3 + px) of image row (2 oy - 3 + tap); tap 7 and the pad are zeros
+      const int r = row0 + pc;
+      const int n = f_fastdiv(r, a.div_ohw), rem = r - n * a.OHW;
+      const int oy = f_fastdiv(rem, a.div_ow), ox = rem - oy * a.OW;
+      const int tap = lane >> 3, iy = 2 * oy - 3 + tap, ix = 2 * ox - 3 + (lane & 7);
+      const bool ok = pc < lim && tap < 7 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const unsigned vo = ok ? (unsigned)n * (unsigned)a.ximgb + (unsigned)iy * (unsigned)a.xrsb + (unsigned)ix * 16u : kOOBf;
+      f_dma16(xr, lds0 + (unsigned)(slot * STG + pc * BLKB), vo);
+    } else if (RPR == 1) {        // part `part` of row `row`
       const int row = pc / PPR, part = pc - row * PPR;
       const unsigned vo = row < lim ? (unsigned)(row0 + row) * (unsigned)a.sxb + (unsigned)(part * 1024 + lane * 16) : kOOBf;
       f_dma16(xr, lds0 + (unsigned)(slot * STG + row * BLKB + part * 1024), vo);
@@ -311,6 +324,7 @@ struct WsfForm {
 #define DC_WSF_FORM(K_, D_) \
   {K_, {{ws1x1f_kernel<K_, D_, false, false>, ws1x1f_kernel<K_, D_, false, true>}, {ws1x1f_kernel<K_, D_, true, false>, ws1x1f_kernel<K_, D_, true, true>}}}
 const WsfForm kFormsF[] = {DC_WSF_FORM(64, 4), DC_WSF_FORM(128, 4), DC_WSF_FORM(256, 4), DC_WSF_FORM(512, 3)};
+const WsfKernel kStemWs[2] = {ws1x1f_kernel<256, 4, false, false, true>, ws1x1f_kernel<256, 4, false, true, true>};  // [relu]
 const WsfForm* formf_of(int K) {
   for (const WsfForm& f : kFormsF)
     if (f.K == K) return &f;
@@ -327,14 +341,14 @@ void f_magic(unsigned dv, unsigned (&mg)[2]) {
   const unsigned long long qq = (unsigned long long)((((unsigned __int128)1) << sh) / dv);
   mg[0] = (unsigned)(qq + 1), mg[1] = (unsigned)(sh - 32);
 }
-long wsf_plan(WsfArgs& a, int klen) {
+long wsf_plan(WsfArgs& a, int klen, bool stem = false) {
   a.tn = a.Cout / 64;
   a.S = (a.M + 15) / 16;
   // one workgroup per CU; two at K = 128, where a step is 1 024 cycles of products behind the same requests and barrier (conv3_x expansion at
   // batch 1: 13.1 us with 256 workgroups, 12.1 with 512 or 768, 13.8 with 1 024; conv4_x, K = 256: 11.4 / 11.2 / 12.1 — and 2 048 waves start
   // 0.7 us later than 1 024 inside a forward)
   static const int slots_env = getenv("DC_WSF_SLOTS") ? std::max(8, atoi(getenv("DC_WSF_SLOTS"))) : 0;
-  const int slots = slots_env ? slots_env : klen <= 128 ? 512 : 256;
+  const int slots = slots_env ? slots_env : (klen <= 128 || stem) ? 512 : 256;  // (the stem: 39.1 us at 256, 34.8 at 512, 36.7 at 1 024; its tile 39.1)
   long J = std::min<long>(a.S, std::max(1, slots / a.tn));
   if (J >= 8) J -= J % 8;
   a.J = (int)J;
@@ -363,6 +377,48 @@ long stream1x1f_grid(const ConvGemmParams& p) {
 }
 
 size_t stream1x1f_packed_elems(int Cout, int K) { return (size_t)Cout * K; }
+
+// ---- the stem form: conv1 (7x7, stride 2, pad 3, <= 4 input channels as NHWC4 pixels, 64 output channels) as the lowering's row-tap launch
+bool stem_ws_eligible(const ConvGemmParams& p) {
+  if (p.esize != 4 || p.ncls > 1 || p.nprob > 0 || p.sigmoid_ch != 0 || p.resid) return false;
+  if (p.nty != 7 || p.ntx != 1 || p.klen != 32 || p.Ktot != 224 || p.dy0 != -3 || p.ddy != 1 || p.sy != 2 || p.sx != 8 || p.x0 != -12) return false;
+  if (p.Cout != 64 || p.x_rowlen % 4 != 0 || p.x_row_stride < p.x_rowlen || p.x_row_stride % 4 != 0 || p.x_img_stride % 4 != 0) return false;
+  const int W = p.x_rowlen / 4, H = p.x_rows;
+  if (p.OH != (H + 6 - 7) / 2 + 1 || p.OW != (W + 6 - 7) / 2 + 1 || p.M != (long)p.NB * p.OH * p.OW) return false;
+  if (p.y_row_stride != p.OW * p.y_pix_stride || p.y_img_stride != (long)p.OH * p.y_row_stride || (p.y_pix_stride * 4) % 16 != 0) return false;
+  if ((long)p.NB * p.x_img_stride * 4 >= 0x7fffffffL || (long)p.M * p.y_pix_stride * 4 >= 0x7fffffffL) return false;  // 32-bit byte offsets
+  return true;
+}
+
+long stem_ws_grid(const ConvGemmParams& p) {
+  WsfArgs a{};
+  a.Cout = p.Cout, a.M = p.M;
+  return wsf_plan(a, 256, true);
+}
+
+size_t stem_ws_packed_elems() { return (size_t)64 * 256; }
+
+void stem_ws_pack_filters(const float* rowtap, float* out) {
+  std::vector<float> g((size_t)64 * 256, 0.f);  // columns 224 .. 255: the eighth "row" of a request, zeros
+  for (int co = 0; co < 64; ++co)
+    for (int k = 0; k < 224; ++k) g[(size_t)co * 256 + k] = rowtap[(size_t)co * 224 + k];
+  stream1x1f_pack_filters(g.data(), 64, 256, out);
+}
+
+int launch_stem_ws(const ConvGemmParams& p, void* stream) {
+  if (!stem_ws_eligible(p)) return (int)hipErrorInvalidValue;
+  if (((uintptr_t)p.x & 15) || ((uintptr_t)p.y & 15) || ((uintptr_t)p.w & 15) || ((uintptr_t)p.scale & 15) || ((uintptr_t)p.shift & 15)) return (int)hipErrorInvalidValue;
+  WsfArgs a{};
+  a.x = p.x, a.w = p.w, a.scale = p.scale, a.shift = p.shift, a.y = p.y, a.resid = nullptr;
+  a.M = p.M, a.Cout = p.Cout, a.sxb = 0, a.ypb = p.y_pix_stride * 4, a.dbg = p.dbg;
+  a.OW = p.OW, a.OHW = p.OH * p.OW, a.H = p.x_rows, a.W = p.x_rowlen / 4, a.xrsb = p.x_row_stride * 4, a.ximgb = (int)(p.x_img_stride * 4);
+  f_magic((unsigned)a.OW, a.div_ow);
+  f_magic((unsigned)a.OHW, a.div_ohw);
+  const long grid = wsf_plan(a, 256, true);
+  if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(kStemWs[p.relu ? 1 : 0], dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 
 // g: [Cout][K] -> [Cout/16][K/16][64 lanes][4]: lane = 16 q + co % 16 holds run q of the K range (K/4 elements), 4 of them per vector:
 // element e of vector j = g[co][q K/4 + 4 j + e]

@@ -25,9 +25,9 @@ def test_tune_report_lists_every_signature_with_its_timings(gpu_caffe, synth152,
     monkeypatch.delenv("DC_TUNE_CACHE", raising=False)
     net = _net(gpu_caffe, synth152)
     rep = net.tune_report()
-    names = set(n for n, _ in gpu_caffe.conv_variants()) | {"wino_f23", "wino_f23_w16", "ws1x1f"}  # (float32: the forms outside the tile table)
+    names = set(n for n, _ in gpu_caffe.conv_variants()) | {"wino_f23", "wino_f23_w16", "ws1x1f", "ws7x7f"}  # (float32: the forms outside the tile table)
     assert len(rep) >= 20 and sum(r["launches"] for r in rep) == sum(
-        1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln or "ws1x1f<" in ln)
+        1 for ln in net.plan_text().splitlines() if "conv_gemm<" in ln or "wino_f23<" in ln or "ws1x1f<" in ln or "ws7x7f<" in ln)
     for r in rep:
         assert r["tile"] in names and r["launches"] >= 1
         assert r["timed"], r  # tuned in this process: every signature carries the isolated timings, fastest first

@@ -26,9 +26,9 @@ def per_stage(c, plan_path):
     labels, unprof = [], []
     for ln in open(plan_path):
         f = ln.rstrip("\n").split("\t")
-        if len(f) == 4 and f[0].isdigit() and ("conv_gemm" in f[1] or "wino_f23<" in f[1] or "wino_h23<" in f[1] or "ws1x1<" in f[1] or "ws1x1f<" in f[1] or "stem7x7<" in f[1]):  # conv_gemm< and conv_gemm_mp< (group plans)
+        if len(f) == 4 and f[0].isdigit() and ("conv_gemm" in f[1] or "wino_f23<" in f[1] or "wino_h23<" in f[1] or "ws1x1<" in f[1] or "ws1x1f<" in f[1] or "ws7x7f<" in f[1] or "stem7x7<" in f[1]):  # conv_gemm< and conv_gemm_mp< (group plans)
             labels.append(f[3])
-        if len(f) == 7 and f[0].isdigit() and ("conv_gemm" in f[1] or "wino_f23<" in f[1] or "wino_h23<" in f[1] or "ws1x1<" in f[1] or "ws1x1f<" in f[1] or "stem7x7<" in f[1]):
+        if len(f) == 7 and f[0].isdigit() and ("conv_gemm" in f[1] or "wino_f23<" in f[1] or "wino_h23<" in f[1] or "ws1x1<" in f[1] or "ws1x1f<" in f[1] or "ws7x7f<" in f[1] or "stem7x7<" in f[1]):
             unprof.append(float(f[2]))  # bench.py --breakdown: hipEvent microseconds of this launch, nothing profiled
     n = len(labels)
     rows = c.execute("select dispatch_id, counter_name, value, duration from counters_collection where (kernel_name like '%conv_gemm%' or kernel_name like '%wino__23%' or kernel_name like '%ws1x1%' or kernel_name like '%stem7x7%') "
@@ -106,7 +106,7 @@ def in_flight(c, plan_path, bench_path):
     matrix pipes are busy in that regime (at the 2.4 GHz the profiled clock is NOT: an upper bound on the clock, so a
     lower bound on the share)."""
     n = sum(1 for ln in open(plan_path) if len(ln.split("\t")) == 4 and ln.split("\t")[0].isdigit()
-            and ("conv_gemm" in ln.split("\t")[1] or "wino_f23<" in ln or "wino_h23<" in ln or "ws1x1<" in ln or "ws1x1f<" in ln or "stem7x7<" in ln))
+            and ("conv_gemm" in ln.split("\t")[1] or "wino_f23<" in ln or "wino_h23<" in ln or "ws1x1<" in ln or "ws1x1f<" in ln or "ws7x7f<" in ln or "stem7x7<" in ln))
     busy, disp = c.execute("select sum(value), count(*) from counters_collection where counter_name = 'SQ_VALU_MFMA_BUSY_CYCLES' "
                            "and (kernel_name like '%conv_gemm%' or kernel_name like '%wino__23%' or kernel_name like '%ws1x1%' or kernel_name like '%stem7x7%')").fetchone()
     if not n or not disp or disp % n:
