@@ -223,8 +223,9 @@ void NetGroup::merge(GroupPlan& gp) {
       // (a member on the float16 Winograd form merges as the direct layer it also is: the form is a one-round kernel that wins alone on
       //  a 240-workgroup grid — round 6: with the 544x736 member's conv4_x 3x3 launches kept out of the merge, the four scales of that
       //  layer ran as 17.8 + 31.2 + 17.0 + 14.3 us where the merged direct launch takes 60.5.  The float32 forms stay member by member.)
-      //  (The float32 streaming 1x1 form, round 6, merges the same way: it wins by a few per cent on one-round grids only.)
-      const bool wino_apart = is_wino_variant(l.variant) && l.variant != kWinoHalf && l.variant != kStreamHalf && l.variant != kStreamFloat;
+      //  (The float32 streaming forms, round 6 — ws1x1f and the stem on its skeleton —, merge the same way: they win by a few per cent
+      //   on a member's own grid only.)
+      const bool wino_apart = is_wino_variant(l.variant) && l.variant != kWinoHalf && l.variant != kStreamHalf && l.variant != kStreamFloat && l.variant != kStemFloat;
       if (l.kind != Launch::CONV || wino_apart || l.w != l0.w || l.scale != l0.scale || l.shift != l0.shift || l.c_off != l0.c_off ||
           l.w_off != l0.w_off ||
           (l.in2 >= 0) != (l0.in2 >= 0) || g.esize != g0.esize || g.klen != g0.klen || g.sy != g0.sy || g.sx != g0.sx || g.Cout != g0.Cout ||

@@ -414,6 +414,8 @@ int launch_stem_ws(const ConvGemmParams& p, void* stream) {
   a.OW = p.OW, a.OHW = p.OH * p.OW, a.H = p.x_rows, a.W = p.x_rowlen / 4, a.xrsb = p.x_row_stride * 4, a.ximgb = (int)(p.x_img_stride * 4);
   f_magic((unsigned)a.OW, a.div_ow);
   f_magic((unsigned)a.OHW, a.div_ohw);
+  static const int abl = getenv("DC_WSF_STEM_ABL") ? atoi(getenv("DC_WSF_STEM_ABL")) : 0;  // timing only (wrong results): 1 = every request out of range (no image bytes move)
+  if (abl == 1) a.H = 0;
   const long grid = wsf_plan(a, 256, true);
   if (grid <= 0 || grid > 0x7fffffffL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(kStemWs[p.relu ? 1 : 0], dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
