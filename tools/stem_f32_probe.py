@@ -18,3 +18,5 @@ net.blobs["data"].data[...] = rs.randn(1, 3, 544, 736) * 50
 net.forward()
 for e in net.tune_report():
     print(e["signature"], "chosen", e["tile"], " ".join("%s %.2f" % t for t in sorted(e["timed"], key=lambda t: t[1])[:6]))
+if os.environ.get("DC_DEBUG_TIMING") is None:
+    print(net.plan_text())
