@@ -112,7 +112,7 @@ struct ReqCount {
 // bank groups again and leaves the read offsets immediates (a lane's run starts at ((q + r) mod 4) K bytes of its row instead of q K).
 template <int K, int D, bool RES, bool RELU, bool STEM = false>
 __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
-  static_assert(!STEM || (K == 256 && !RES), "the stem form: 7 x 32 image floats + 32 zeros per output pixel, no shortcut");
+  static_assert(!STEM || (K == 224 && !RES), "the stem form: 7 taps x 32 image floats per output pixel (the request's eighth tap is never read), no shortcut");
   const long long t_entry = (long long)__builtin_amdgcn_s_memrealtime();
   constexpr int RPR = K * 4 >= 1024 ? 1 : 1024 / (K * 4);  // pixel rows per 1 KiB request
   constexpr int PPR = K * 4 >= 1024 ? K * 4 / 1024 : 1;    // 1 KiB requests per pixel row
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
   constexpr int NA = 16 * PPR / RPR / 4;  // requests per wave and stage
   constexpr int NJ = K / 16;         // 16-byte reads (= 4 matrix steps each) per wave and step
   constexpr int NR = RES ? 1 : 0, NS = 1;
-  static_assert((K == 64 || K == 128 || K % 256 == 0) && D >= 3 && D <= 4 && NA >= 1, "rows and requests divide each other; the ring");
+  static_assert((K == 64 || K == 128 || K % 256 == 0 || (STEM && K == 224)) && D >= 3 && D <= 4 && NA >= 1, "rows and requests divide each other; the ring");
   using Rq = ReqCount<D, NA, NR, NS>;
   constexpr int LDSB = D * STG + 4 * 2 * 1024;
   static_assert(LDSB <= 160 * 1024, "LDS of a CU");
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void ws1x1f_kernel(const WsfArgs a) {
   //  * the barrier that publishes stage k+1 (and frees the slot of step k-1 for stage k+D-1, requested right behind it) sits inside step k;
   //    the operand reads run PD-1 reads ahead across the step boundary;
   //  * the epilogue of step k-1 (shortcut wait, LDS round trips, store, next shortcut request) rides in step k.
-  constexpr int PD = 4;
+  constexpr int PD = NJ % 4 == 0 ? 4 : 7;  // (the stem's 14 reads per step: a ring of 7)
   static_assert(NJ % PD == 0, "the operand ring keeps its phase across steps");
   int slot = 0, ob = 0;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -324,7 +324,7 @@ struct WsfForm {
 #define DC_WSF_FORM(K_, D_) \
   {K_, {{ws1x1f_kernel<K_, D_, false, false>, ws1x1f_kernel<K_, D_, false, true>}, {ws1x1f_kernel<K_, D_, true, false>, ws1x1f_kernel<K_, D_, true, true>}}}
 const WsfForm kFormsF[] = {DC_WSF_FORM(64, 4), DC_WSF_FORM(128, 4), DC_WSF_FORM(256, 4), DC_WSF_FORM(512, 3)};
-const WsfKernel kStemWs[2] = {ws1x1f_kernel<256, 4, false, false, true>, ws1x1f_kernel<256, 4, false, true, true>};  // [relu]
+const WsfKernel kStemWs[2] = {ws1x1f_kernel<224, 4, false, false, true>, ws1x1f_kernel<224, 4, false, true, true>};  // [relu]
 const WsfForm* formf_of(int K) {
   for (const WsfForm& f : kFormsF)
     if (f.K == K) return &f;
@@ -396,14 +396,9 @@ long stem_ws_grid(const ConvGemmParams& p) {
   return wsf_plan(a, 256, true);
 }
 
-size_t stem_ws_packed_elems() { return (size_t)64 * 256; }
+size_t stem_ws_packed_elems() { return (size_t)64 * 224; }
 
-void stem_ws_pack_filters(const float* rowtap, float* out) {
-  std::vector<float> g((size_t)64 * 256, 0.f);  // columns 224 .. 255: the eighth "row" of a request, zeros
-  for (int co = 0; co < 64; ++co)
-    for (int k = 0; k < 224; ++k) g[(size_t)co * 256 + k] = rowtap[(size_t)co * 224 + k];
-  stream1x1f_pack_filters(g.data(), 64, 256, out);
-}
+void stem_ws_pack_filters(const float* rowtap, float* out) { stream1x1f_pack_filters(rowtap, 64, 224, out); }  // (K = 224: 14 vectors per lane)
 
 int launch_stem_ws(const ConvGemmParams& p, void* stream) {
   if (!stem_ws_eligible(p)) return (int)hipErrorInvalidValue;
