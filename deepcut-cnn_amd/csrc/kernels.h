@@ -199,7 +199,7 @@ size_t stream1x1f_packed_elems(int Cout, int K);
 void stream1x1f_pack_filters(const float* g, int Cout, int K, float* out);
 int launch_stream1x1f(const ConvGemmParams& p, void* stream);
 // ---- the float32 stem on the same skeleton ("ws7x7f"): conv1 7x7 / 2 over the NHWC4 image as the lowering's 7-row-tap launch describes it; a
-// 1 KiB request gathers an output pixel's 7 x 8 input pixels (K = 256: 224 of the row-tap image + zeros); `w` from stem_ws_pack_filters()
+// 1 KiB request gathers an output pixel's 7 x 8 input pixels (K = 224, the row-tap image's columns); `w` from stem_ws_pack_filters()
 bool stem_ws_eligible(const ConvGemmParams& p);
 long stem_ws_grid(const ConvGemmParams& p);
 size_t stem_ws_packed_elems();

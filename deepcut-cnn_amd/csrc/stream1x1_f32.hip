@@ -348,7 +348,7 @@ long wsf_plan(WsfArgs& a, int klen, bool stem = false) {
   // batch 1: 13.1 us with 256 workgroups, 12.1 with 512 or 768, 13.8 with 1 024; conv4_x, K = 256: 11.4 / 11.2 / 12.1 — and 2 048 waves start
   // 0.7 us later than 1 024 inside a forward)
   static const int slots_env = getenv("DC_WSF_SLOTS") ? std::max(8, atoi(getenv("DC_WSF_SLOTS"))) : 0;
-  const int slots = slots_env ? slots_env : (klen <= 128 || stem) ? 512 : 256;  // (the stem: 39.1 us at 256, 34.8 at 512, 36.7 at 1 024; its tile 39.1)
+  const int slots = slots_env ? slots_env : (klen <= 128 || stem) ? 512 : 256;  // (the stem: 36.7 us at 256, 32.2 at 512, 33.7 at 768; its tile 39.1)
   long J = std::min<long>(a.S, std::max(1, slots / a.tn));
   if (J >= 8) J -= J % 8;
   a.J = (int)J;
