@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/deepcut_asan}
 mkdir -p "$OUT"
-python "$R/deepcut-cnn_amd/build.py" > /dev/null        # (kernels.hip.o of the normal build)
+python "$R/deepcut-cnn_amd/build.py" > /dev/null        # (the *.hip.o of the normal build)
 HOST="formats.cpp hdf5_reader.cpp runtime.cpp net_init.cpp net_lower.cpp net_tune.cpp net_run.cpp net_image.cpp net_group.cpp streams.cpp multi_gpu.cpp c_api.cpp"
 for f in $HOST; do
   /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer \
@@ -14,7 +14,7 @@ for f in $HOST; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libasan -o "$OUT/libdeepcut_hip.so" \
-  $(for f in $HOST; do echo "$OUT/$f.o"; done) "$R/deepcut-cnn_amd/lib/kernels.hip.o"
+  $(for f in $HOST; do echo "$OUT/$f.o"; done) "$R"/deepcut-cnn_amd/lib/*.hip.o   # (every kernel translation unit as built)
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 export DEEPCUT_HIP_LIB="$OUT/libdeepcut_hip.so" LD_PRELOAD="$RT"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0:max_allocation_size_mb=8192:allocator_may_return_null=1
